@@ -1,0 +1,201 @@
+/*
+ * rvio_hip.h — C-ABI of the MI355X-native robocentric MSCKF hot path.
+ *
+ * The reference (rpng/R-VIO) has no FFI/plugin layer: its per-frame hot path
+ * sits behind three C++ member calls made from System::MonoVIO
+ * (src/rvio/System.cc:258,263,268).  Each entry point below replaces one of
+ * those calls (or a slice of MonoVIO itself) and cites it.  Everything is
+ * POD + plain pointers; no C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - state vector x  : [qG(4) pG(3) g(3) | qk(4) pk(3) v(3) bg(3) ba(3) | n x (q(4) p(3))]
+ *                       JPL quaternions [x y z w]   (System.cc:142-149,326-331)
+ *   - covariance  P   : (24+6n)^2 doubles, COLUMN-major (Eigen::MatrixXd layout),
+ *                       error state [thG pG g | thk pk v bg ba | n x (th p)]
+ *   - all functions return RVIO_OK (0) or a negative rvio_status; the silent
+ *     early-outs of the reference (too few features etc.) are reported through
+ *     rvio_frame_info, not through the return code.
+ *   - a handle owns one HIP stream and all device memory of one filter
+ *     instance; a handle is not thread-safe, distinct handles are independent.
+ *   - functions ending in _dev take DEVICE pointers, all others HOST pointers.
+ *   - every entry point is asynchronous on the handle's stream unless it
+ *     returns data to host memory (get_* / *_sync), which synchronise.
+ */
+#ifndef RVIO_HIP_H
+#define RVIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVIO_HIP_ABI_VERSION 1
+
+typedef enum rvio_status {
+    RVIO_OK = 0,
+    RVIO_ERR_INVALID = -1,     /* bad argument / size                                   */
+    RVIO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error (see last_error)    */
+    RVIO_ERR_UNSUPPORTED = -3, /* e.g. Camera.Fisheye=1                                  */
+    RVIO_ERR_STATE = -4        /* call out of sequence (e.g. update before set_state)    */
+} rvio_status;
+
+/* All parameters of config/rvio_euroc.yaml that the hot path consumes
+ * (key -> consumer table: SURVEY.md appendix A).  Types mirror what the
+ * reference stores them as (float32 intrinsics: Tracker.cc:39-62; float32
+ * sigma_im: Updater.cc:42-44). */
+typedef struct rvio_config {
+    /* IMU.*  (PreIntegrator.cc:32-44, System.cc:60-67) */
+    double imu_rate;      /* IMU.dps          */
+    double sigma_g;       /* IMU.sigma_g      */
+    double sigma_wg;      /* IMU.sigma_wg     */
+    double sigma_a;       /* IMU.sigma_a      */
+    double sigma_wa;      /* IMU.sigma_wa     */
+    double gravity;       /* IMU.nG           */
+    double small_angle;   /* IMU.nSmallAngle  */
+    /* Camera.* */
+    int32_t width, height;            /* FeatureDetector.cc:37-38               */
+    float fx, fy, cx, cy;             /* Tracker.cc:39-42                       */
+    float k1, k2, p1, p2, k3;         /* Tracker.cc:51-61                       */
+    float sigma_px, sigma_py;         /* Updater.cc:42-44 (sigma_im = max)      */
+    double T_bc[16];                  /* Camera.T_BC0, ROW-major 4x4 (Updater.cc:46-53) */
+    int32_t fisheye;                  /* Camera.Fisheye (1 -> RVIO_ERR_UNSUPPORTED) */
+    /* Tracker.* */
+    int32_t n_features;               /* Tracker.nFeatures          (Tracker.cc:73)  */
+    int32_t max_track_len;            /* Tracker.nMaxTrackingLength (Tracker.cc:78)  */
+    int32_t min_track_len;            /* Tracker.nMinTrackingLength (Tracker.cc:79)  */
+    float   min_dist;                 /* Tracker.nMinDist           (FeatureDetector.cc:31) */
+    float   qual_lvl;                 /* Tracker.nQualLvl           */
+    int32_t block_x, block_y;         /* Tracker.nBlockSizeX/Y      (FeatureDetector.cc:34-35) */
+    int32_t enable_equalizer;         /* Tracker.EnableEqualizer    (Tracker.cc:70-71) */
+    int32_t use_sampson;              /* Tracker.UseSampson         (Ransac.cc:34-35) */
+    double  inlier_thr;               /* Tracker.nInlierThrd        (Ransac.cc:37)    */
+    /* INI.* (System.cc:77-91) */
+    double  ini_thr_angle;            /* INI.nThresholdAngle */
+    double  ini_thr_displ;            /* INI.nThresholdDispl */
+    int32_t ini_enable_alignment;     /* INI.EnableAlignment */
+    int32_t reserved0;
+} rvio_config;
+
+/* Fill *cfg with the stock values of config/rvio_euroc.yaml:8-111. */
+void rvio_config_euroc(rvio_config* cfg);
+
+/* One IMU sample: struct ImuData (InputBuffer.h:35-51). */
+typedef struct rvio_imu {
+    double w[3];   /* AngularVel   */
+    double a[3];   /* LinearAccel  */
+    double t;      /* Timestamp    */
+    double dt;     /* TimeInterval */
+} rvio_imu;
+
+/* The Tracker -> Updater hand-over: mvFeatTypesForUpdate + mvlFeatMeasForUpdate
+ * (Tracker.h:67-74), flattened.  meas[f][k] is the k-th (oldest first)
+ * undistorted-normalised observation (cv::Point2f) of feature f. */
+typedef struct rvio_tracks {
+    int32_t n_feat;              /* mvFeatTypesForUpdate.size()                 */
+    int32_t max_len;             /* row stride of meas, >= every len[f]         */
+    const unsigned char* types;  /* n_feat x '1' (lost) | '2' (max length)      */
+    const int32_t* len;          /* n_feat track lengths                        */
+    const float* meas;           /* n_feat x max_len x 2 float32                */
+} rvio_tracks;
+
+/* What the reference only logs through ROS_DEBUG, made observable. */
+typedef struct rvio_frame_info {
+    int32_t n_clones;          /* nCloneStates after the frame                  */
+    int32_t n_tracked_in;      /* mnFeatsToTrack entering track()               */
+    int32_t n_klt_ok;          /* status!=0 after KLT                           */
+    int32_t n_ransac_inliers;  /* FindInliers return value                      */
+    int32_t n_feat_update;     /* features handed to update()                   */
+    int32_t n_feat_accepted;   /* nGoodFeatCount                                */
+    int32_t n_rows;            /* stacked rows nRowCount                        */
+    int32_t updated;           /* 1 if the EKF update was applied               */
+    int32_t n_tracked_out;     /* mnFeatsToTrack leaving track() (after refill) */
+    int32_t ransac_winner;     /* nWinnerHypothesisIdx                          */
+    int32_t reserved[6];
+} rvio_frame_info;
+
+typedef struct rvio_hip rvio_hip;  /* opaque; replaces the System-owned stage objects (System.h:89-92) */
+
+/* --- lifetime ------------------------------------------------------------- */
+/* new Tracker/Updater/PreIntegrator (System.cc:96-99).  device = HIP ordinal. */
+int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out);
+void rvio_hip_destroy(rvio_hip* h);
+const char* rvio_hip_last_error(const rvio_hip* h);
+int rvio_hip_abi_version(void);
+/* the hipStream_t (as void*) all work of this handle is enqueued on */
+void* rvio_hip_stream(rvio_hip* h);
+int rvio_hip_sync(rvio_hip* h);
+
+/* --- filter state --------------------------------------------------------- */
+/* System::xkk / Pkk (System.h:85-86).  xdim = 26+7n, d = 24+6n. */
+int rvio_hip_set_state(rvio_hip* h, const double* x, int xdim, const double* P, int d);
+int rvio_hip_get_state(rvio_hip* h, double* x, int* xdim, double* P, int* d);
+/* System::initialize (System.cc:115-170): gravity-aligned x(26), P(24x24). */
+int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n_imu);
+
+/* --- stage entry points (one per reference call site) ---------------------- */
+/* PreIntegrator::propagate (PreIntegrator.h:40, call site System.cc:263).
+ * Mutates the handle's (x,P) in place: they become xk1k / Pk1k. */
+int rvio_hip_propagate(rvio_hip* h, const rvio_imu* imu, int m);
+
+/* Updater::update (Updater.h:43-44, call site System.cc:268) on host-provided
+ * tracks.  (x,P) become xk1k1 / Pk1k1; pass-through if <=2 features survive
+ * (Updater.cc:460,621-627). */
+int rvio_hip_update(rvio_hip* h, const rvio_tracks* tracks);
+
+/* State augmentation + window slide + robocentric composition
+ * (System.cc:279-365).  do_augment mirrors `nImageCountAfterInit>1`. */
+int rvio_hip_augment_compose(rvio_hip* h, int do_augment);
+
+/* --- visual front end ------------------------------------------------------ */
+/* Tracker::track (Tracker.h:50, call site System.cc:258) on a W x H u8 image.
+ * `cand`/`n_cand` are the detector's corner list for this frame, i.e. the
+ * output of FeatureDetector::DetectWithSubPix (FeatureDetector.cc:55-75; the
+ * detector itself is outside the hot path); the grid-based
+ * selection FindNewer (FeatureDetector.cc:97-150) and the refill
+ * (Tracker.cc:344-387) run on the device.  Results stay on the device for
+ * rvio_hip_update_tracked and can be fetched with rvio_hip_get_tracks. */
+int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride,
+                   const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
+int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride,
+                       const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+/* Copy the device-resident mvFeatTypesForUpdate / mvlFeatMeasForUpdate out.
+ * Buffers must hold ceil(n_features/2) entries (x max_track_len x 2 floats). */
+int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas);
+/* Tracker's persistent members: mvFeatsToTrack (px) and track lengths. */
+int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len);
+/* Updater::update on the tracker's device-resident outputs. */
+int rvio_hip_update_tracked(rvio_hip* h);
+
+/* --- whole frame ----------------------------------------------------------- */
+/* The timed body of System::MonoVIO (System.cc:253-367): track -> propagate ->
+ * [update if nCloneStates > nMinTrackingLength-1] -> augment -> compose, all
+ * enqueued on the handle's stream with no host synchronisation. */
+int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
+                       const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info);
+/* pose line of stamped_pose_ests.dat (System.cc:371-374): pGk(3), qkG(4) */
+int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]);
+
+/* --- feature-sharded updater (no reference counterpart) ------ */
+/* Stage A: per-feature build + gate on the features f with f % world == rank,
+ * then local compression to the information block [A|b] = Hw^T [Hw | r]
+ * (6n x (6n+1) doubles, row-major, plus 2 trailing doubles: accepted-feature
+ * count and stacked-row count).  *d_block is a device pointer owned by the
+ * handle, *n_doubles its length: this is the payload of the all-gather. */
+int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int world,
+                          double** d_block, int* n_doubles);
+/* Stage B: sum `world` gathered blocks (device pointer, rank-major) in rank
+ * order and run the EKF update; bit-identical on every rank. */
+int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world);
+
+/* --- diagnostics for parity tests ------------------------------------------ */
+/* per-feature results of the last update: accept flag, Mahalanobis distance,
+ * nDOF, inverse-depth estimate (phi,psi,rho). arrays sized n_feat. */
+int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma,
+                             int32_t* ndof, double* pfinv /* n_feat x 3 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVIO_HIP_H */

@@ -1,0 +1,110 @@
+/*
+ * rvio_oracle.h — C API of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A dependency-free restatement (C++17, double precision with the reference's
+ * float32 islands reproduced) of the R-VIO per-frame hot path, each function
+ * citing the reference file:line it follows.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (r-vio_amd/) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests/golden vectors and its heavy
+ * arithmetic lives in un-vendored OpenCV/Eigen, neither of
+ * which exists in this image, so the reference itself cannot be compiled here.
+ * The pins that do exist: glibc rand() (the RANSAC index stream, Ransac.cc:63-69)
+ * is checked bit-for-bit against libc; everything else is pinned by analytic
+ * identities (tests/test_oracle_*.py) and frozen snapshots (tests/golden/).
+ */
+#ifndef RVIO_ORACLE_H
+#define RVIO_ORACLE_H
+#include "../include/rvio_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- N1: util/Numerics.h:30-167 ---- */
+void orc_quat_mul(const double q1[4], const double q2[4], double out[4]);
+void orc_quat_to_rot(const double q[4], double R_rowmajor[9]);
+void orc_rot_to_quat(const double R_rowmajor[9], double q[4]);
+double orc_chi2_95(int dof); /* CHI_THRESHOLD[dof-1], Numerics.h:173-224 */
+
+/* ---- System::initialize, System.cc:115-170 ---- */
+void orc_initialize(const rvio_config* cfg, const double w[3], const double a[3], int n_imu,
+                    double x[26], double P[24 * 24]);
+
+/* ---- P1: PreIntegrator::propagate, PreIntegrator.cc:51-194 ----
+ * x (xdim) in -> x_out; P (d x d col-major) is propagated IN PLACE. */
+void orc_propagate(const rvio_config* cfg, const double* x, int xdim, double* P, int d,
+                   const rvio_imu* imu, int m, double* x_out);
+
+/* ---- U1..U10: Updater::update, Updater.cc:72-628 ----
+ * diag arrays (may be NULL) are sized tracks->n_feat; info[0]=nGoodFeatCount,
+ * info[1]=nRowCount, info[2]=nRank (or -1 if fat / no update), info[3]=updated. */
+void orc_update(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
+                const rvio_tracks* tracks, double* x_out, double* P_out,
+                int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int32_t info[4]);
+
+/* Same update, but with the information-form compression [A|b]=Hw^T[Hw|r]
+ * sharded over `world` ranks (features f%world==rank) and summed in rank
+ * order — the CPU mirror of rvio_hip_update_local/_global, used by the gloo
+ * tests.  block: (6n*(6n+1)+2) doubles. */
+void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
+                      const rvio_tracks* tracks, int rank, int world, double* block);
+void orc_update_global(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
+                       const double* blocks, int world, double* x_out, double* P_out, int32_t info[4]);
+
+/* ---- S1+S2: System.cc:279-365.  x/P buffers must hold the grown state. ---- */
+void orc_augment_compose(const rvio_config* cfg, double* x, int* xdim, double* P, int* d,
+                         int do_augment, double pose_p[3], double pose_q[4]);
+
+/* ---- T4: Tracker::UndistortAndNormalize, Tracker.cc:100-132 (cv::undistortPoints) ---- */
+void orc_undistort(const rvio_config* cfg, const float* px_xy, int n, float* out_xy);
+
+/* ---- T5: Ransac, Ransac.cc:50-266.  p1/p2: 3 x n col-major; flags in/out.
+ * rng: 35 ints of oracle rand state (see orc_rand_*). returns #inliers, winner idx in *winner. */
+void orc_srand(int32_t state[35], unsigned seed);
+int orc_rand(int32_t state[35]);
+int orc_ransac(const rvio_config* cfg, const double* p1, const double* p2, int n,
+               const rvio_imu* imu, int m, unsigned char* flags, int32_t rng[35], int* winner,
+               int32_t* pairs /* 32 ints or NULL */);
+
+/* ---- T3: cv::calcOpticalFlowPyrLK restated ---- */
+/* pyrDown ([1 4 6 4 1]/16 separable, BORDER_REFLECT_101): (w,h) -> ((w+1)/2,(h+1)/2) */
+void orc_pyr_down(const uint8_t* src, int w, int h, int stride, uint8_t* dst);
+/* Scharr derivative, int16 interleaved (dx,dy) */
+void orc_scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy);
+/* LK on raw images: win 15x15, maxLevel 3, 30 it / eps 0.01, minEig 1e-3 (Tracker.cc:237-244) */
+void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+             const float* pts_xy, int n, float* out_xy, unsigned char* status);
+
+/* ---- T1/T6: Tracker::track, Tracker.cc:179-396 (detector replaced by caller-supplied corners) ---- */
+typedef struct orc_tracker orc_tracker;
+orc_tracker* orc_tracker_create(const rvio_config* cfg);
+void orc_tracker_destroy(orc_tracker*);
+void orc_tracker_track(orc_tracker*, const uint8_t* img, int stride, const rvio_imu* imu, int m,
+                       const float* cand_xy, int n_cand, rvio_frame_info* info);
+/* direct-track mode: caller supplies the KLT result (pixel positions + status) */
+void orc_tracker_track_points(orc_tracker*, const float* tracked_xy, const unsigned char* status,
+                              const rvio_imu* imu, int m, const float* cand_xy, int n_cand, rvio_frame_info* info);
+/* outputs: n_feat, types, len, meas[n_feat][max_track_len][2]; buffers sized ceil(F/2) */
+void orc_tracker_get_tracks(orc_tracker*, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas);
+void orc_tracker_get_points(orc_tracker*, int32_t* n, float* xy, int32_t* hist_len);
+
+/* ---- whole System::MonoVIO timed body (System.cc:253-367) ---- */
+typedef struct orc_system orc_system;
+orc_system* orc_system_create(const rvio_config* cfg);
+void orc_system_destroy(orc_system*);
+void orc_system_set_state(orc_system*, const double* x, int xdim, const double* P, int d);
+void orc_system_get_state(orc_system*, double* x, int* xdim, double* P, int* d);
+/* one frame; t_ms[0]=track, t_ms[1]=propagate, t_ms[2]=update, t_ms[3]=augment+compose */
+orc_tracker* orc_system_tracker(orc_system*);
+/* img==NULL selects direct-track mode (tracked_xy/status given) */
+void orc_system_frame(orc_system*, const uint8_t* img, int stride, const float* tracked_xy, const unsigned char* status,
+                      const rvio_imu* imu, int m,
+                      const float* cand_xy, int n_cand, rvio_frame_info* info, double t_ms[4],
+                      double pose_p[3], double pose_q[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
