@@ -159,6 +159,12 @@ int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride,
                    const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
 int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride,
                        const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+/* Direct-track mode: the caller supplies the result of the
+ * calcOpticalFlowPyrLK call (vFeatsTracked, vInlierFlag; Tracker.cc:244) for the
+ * n_pts currently tracked features; everything after Tracker.cc:246 (undistort,
+ * RANSAC, book-keeping, refill) runs on the device as in rvio_hip_track. */
+int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
+                          const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
 /* Copy the device-resident mvFeatTypesForUpdate / mvlFeatMeasForUpdate out.
  * Buffers must hold ceil(n_features/2) entries (x max_track_len x 2 floats). */
 int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas);
@@ -173,6 +179,9 @@ int rvio_hip_update_tracked(rvio_hip* h);
  * enqueued on the handle's stream with no host synchronisation. */
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
                        const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+/* same, direct-track mode, host inputs */
+int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
+                          const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
 int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info);
 /* pose line of stamped_pose_ests.dat (System.cc:371-374): pGk(3), qkG(4) */
 int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]);

@@ -1,0 +1,478 @@
+// frontend_kernels.hip — hand-written gfx950 kernels for the visual front end of the
+// R-VIO hot path.  Compiled with -ffp-contract=off: the
+// KLT arithmetic (integer fixed-point + float32) is bit-identical to oracle/frontend.cpp.
+//
+//   pyr_down_kernel   cv::pyrDown inside calcOpticalFlowPyrLK        (Tracker.cc:244)
+//   scharr_kernel     calcSharrDeriv (int16 dx,dy)                   (Tracker.cc:244)
+//   klt_kernel        LKTrackerInvoker, all pyramid levels, one wave per feature
+//   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
+//   bookkeep_kernel   track book-keeping + FindNewer + refill        (Tracker.cc:271-393, FeatureDetector.cc:78-150)
+#include "rvio_dev.h"
+#include "frontend_dev.h"
+#include "../../include/rvio_hip.h"
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
+    return i;
+}
+
+// ------------------------------------------------------------------ pyramid
+// [1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (v+128)>>8.  One thread per output pixel.
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, int w, int h, int stride,
+                                                       uint8_t* __restrict__ dst, int dw, int dh) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int xs[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, w);
+    int rows[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint8_t* s = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
+        rows[k] = s[xs[2]] * 6 + (s[xs[1]] + s[xs[3]]) * 4 + s[xs[0]] + s[xs[4]];
+    }
+    const int v = rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6;
+    dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+}
+
+// un-normalised 3x3 Scharr, reflect-101 neighbours, int16 interleaved (dx, dy)
+__global__ __launch_bounds__(256) void scharr_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, short* __restrict__ dxy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+    const uint8_t *r0 = src + (size_t)ym * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yp * stride;
+    const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
+    const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
+    dxy[((size_t)y * w + x) * 2] = (short)(t0p - t0m);
+    dxy[((size_t)y * w + x) * 2 + 1] = (short)((t1p + t1m) * 3 + t1c * 10);
+}
+
+// ------------------------------------------------------------------ KLT
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ int pixI(const uint8_t* img, int w, int h, int x, int y) { return img[(size_t)reflect101(y, h) * w + reflect101(x, w)]; }
+__device__ __forceinline__ int derI(const short* d, int w, int h, int x, int y, int c) {
+    return (x < 0 || y < 0 || x >= w || y >= h) ? 0 : d[((size_t)y * w + x) * 2 + c];
+}
+
+// One wave per feature; lane l owns window pixels p = l + 64 q (q < 4, p < 225).  The template
+// patch (I, Ix, Iy) lives in registers; the 64-bit integer sums are order-free (see oracle).
+__global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int levels, const int* n_pts_ptr,
+                                                 const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f >= *n_pts_ptr) return;
+    const float px = pts[2 * f], py = pts[2 * f + 1];
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const double eps2 = 0.01 * 0.01;
+    float nx = 0, ny = 0;
+    int st = 1;
+    int wx_[4], wy_[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { int p = lane + 64 * q; wx_[q] = p % 15; wy_[q] = p / 15; }
+    for (int level = levels - 1; level >= 0; --level) {
+        const uint8_t* I = prev.img[level]; const short* dI = prev.dxy[level]; const uint8_t* J = next.img[level];
+        const int w = prev.w[level], h = prev.h[level];
+        const float sc = (float)(1. / (1 << level));
+        float ppx = px * sc, ppy = py * sc;
+        if (level == levels - 1) { nx = ppx; ny = ppy; } else { nx = nx * 2.f; ny = ny * 2.f; }
+        ppx -= 7.f; ppy -= 7.f;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -15 || ipx >= w || ipy < -15 || ipy >= h) { if (level == 0) st = 0; continue; }
+        float a = ppx - ipx, b = ppy - ipy;
+        int iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));
+        int iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
+        int iw10 = (int)rintf((1.f - a) * b * (1 << 14));
+        int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+        int Iw[4], Ixw[4], Iyw[4];
+        long long s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Iw[q] = 0; Ixw[q] = 0; Iyw[q] = 0;
+            if (lane + 64 * q < 225) {
+                const int X = ipx + wx_[q], Y = ipy + wy_[q];
+                const int ival = descale(pixI(I, w, h, X, Y) * iw00 + pixI(I, w, h, X + 1, Y) * iw01 + pixI(I, w, h, X, Y + 1) * iw10 + pixI(I, w, h, X + 1, Y + 1) * iw11, 14 - 5);
+                const int ixv = descale(derI(dI, w, h, X, Y, 0) * iw00 + derI(dI, w, h, X + 1, Y, 0) * iw01 + derI(dI, w, h, X, Y + 1, 0) * iw10 + derI(dI, w, h, X + 1, Y + 1, 0) * iw11, 14);
+                const int iyv = descale(derI(dI, w, h, X, Y, 1) * iw00 + derI(dI, w, h, X + 1, Y, 1) * iw01 + derI(dI, w, h, X, Y + 1, 1) * iw10 + derI(dI, w, h, X + 1, Y + 1, 1) * iw11, 14);
+                Iw[q] = (short)ival; Ixw[q] = (short)ixv; Iyw[q] = (short)iyv;
+                s11 += (long long)Ixw[q] * Ixw[q]; s12 += (long long)Ixw[q] * Iyw[q]; s22 += (long long)Iyw[q] * Iyw[q];
+            }
+        }
+        s11 = wave_sum_i64(s11); s12 = wave_sum_i64(s12); s22 = wave_sum_i64(s22);
+        const float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * 15 * 15);
+        if (minEig < 1e-3f || D < 1.1920929e-07f) { if (level == 0) st = 0; continue; }
+        D = 1.f / D;
+        float npx = nx - 7.f, npy = ny - 7.f;
+        float pdx = 0, pdy = 0;
+        for (int j = 0; j < 30; ++j) {
+            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
+            if (inx < -15 || inx >= w || iny < -15 || iny >= h) { if (level == 0) st = 0; break; }
+            a = npx - inx; b = npy - iny;
+            iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));
+            iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
+            iw10 = (int)rintf((1.f - a) * b * (1 << 14));
+            iw11 = (1 << 14) - iw00 - iw01 - iw10;
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < 225) {
+                    const int X = inx + wx_[q], Y = iny + wy_[q];
+                    const int diff = descale(pixI(J, w, h, X, Y) * iw00 + pixI(J, w, h, X + 1, Y) * iw01 + pixI(J, w, h, X, Y + 1) * iw10 + pixI(J, w, h, X + 1, Y + 1) * iw11, 14 - 5) - Iw[q];
+                    sb1 += (long long)diff * Ixw[q]; sb2 += (long long)diff * Iyw[q];
+                }
+            }
+            sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
+            npx += dx; npy += dy;
+            nx = npx + 7.f; ny = npy + 7.f;
+            if ((double)dx * dx + (double)dy * dy <= eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { nx -= dx * 0.5f; ny -= dy * 0.5f; break; }
+            pdx = dx; pdy = dy;
+        }
+        if (st && level == 0) {
+            const float fx = nx - 7.f, fy = ny - 7.f;
+            const int rx = (int)rintf(fx), ry = (int)rintf(fy);
+            if (rx < -15 || rx >= w || ry < -15 || ry >= h) st = 0;
+        }
+    }
+    if (lane == 0) { out[2 * f] = nx; out[2 * f + 1] = ny; status[f] = (unsigned char)st; }
+}
+
+// ------------------------------------------------------------------ undistort (cv::undistortPoints, 5 fixed iterations)
+__device__ __forceinline__ void undistort_pt(const DevCfg& c, float u, float v, float* ox, float* oy) {
+    const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy;
+    const double k1 = c.k1, k2 = c.k2, p1 = c.p1, p2 = c.p2, k3 = c.k3;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = u, y = v;
+    x = (x - cx) * ifx; y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        x = (x0 - dX) * icdist; y = (y0 - dY) * icdist;
+    }
+    *ox = (float)x; *oy = (float)y;
+}
+
+// glibc random_r TYPE_3 (rand() as used by Ransac.cc:63-69); state layout as oracle/frontend.cpp
+__device__ void rng_seed(int* st, unsigned seed) {
+    if (seed == 0) seed = 1;
+    int word = (int)seed;
+    st[0] = word;
+    for (int i = 1; i < 31; ++i) {
+        long long hi = word / 127773, lo = word % 127773;
+        long long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int)w; st[i] = word;
+    }
+    st[31] = 3; st[32] = 0; st[33] = 1;
+    for (int i = 0; i < 310; ++i) {
+        unsigned v = (unsigned)st[st[31]] + (unsigned)st[st[32]];
+        st[st[31]] = (int)v;
+        st[31] = (st[31] + 1) % 31; st[32] = (st[32] + 1) % 31;
+    }
+}
+__device__ int rng_next(int* st) {
+    if (!st[33]) rng_seed(st, 1);
+    unsigned v = (unsigned)st[st[31]] + (unsigned)st[st[32]];
+    st[st[31]] = (int)v;
+    int out = (int)(v >> 1);
+    st[31] = (st[31] + 1) % 31; st[32] = (st[32] + 1) % 31;
+    return out;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
+__device__ int block_exscan(int v, int* total, int* s_w) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; tot += s_w[w]; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ double sampson_err(d3 p1, d3 p2, const m33& E) {  // Ransac.cc:250-258
+    const d3 F1 = mv33(E, p1), F2 = mv33(tr33(E), p2);
+    const double num = F2.x * p1.x + F2.y * p1.y + F2.z * p1.z;
+    return (num * num) / (F1.x * F1.x + F1.y * F1.y + F2.x * F2.x + F2.y * F2.y);
+}
+__device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  // Ransac.cc:261-266
+    const d3 F2 = mv33(tr33(E), p2);
+    return fabs(F2.x * p1.x + F2.y * p1.y + F2.z * p1.z);
+}
+
+// UndistortAndNormalize of the tracked points + Ransac::FindInliers.  One workgroup, 256 threads.
+// un1: previous-frame normalised coords (mPoints1ForRansac, z = 1), un2: output for this frame.
+__global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
+                                                     unsigned char* status, const rvio_imu* imu, int m, int* rng, int* cand_scratch,
+                                                     rvio_frame_info* info) {
+    __shared__ int s_w[4];
+    __shared__ int pairs[16][2];
+    __shared__ double hyp[16][9];
+    __shared__ int cnt[16];
+    __shared__ int s_winner, s_newout;
+    const int tid = threadIdx.x, N = *n_pts_ptr;
+    for (int i = tid; i < N; i += 256) undistort_pt(cfg, tracked[2 * i], tracked[2 * i + 1], &un2[2 * i], &un2[2 * i + 1]);
+    // ordered compaction of candidate indices (status != 0)
+    int nc = 0;
+    for (int base = 0; base < N; base += 256) {
+        const int i = base + tid;
+        const int fl = (i < N && status[i]) ? 1 : 0;
+        int tot;
+        const int pos = block_exscan(fl, &tot, s_w);
+        if (fl) cand_scratch[nc + pos] = i;
+        nc += tot;
+    }
+    if (tid < 16) cnt[tid] = 0;
+    if (tid == 0) { s_winner = 0; s_newout = 0; info->n_tracked_in = N; info->n_klt_ok = nc; info->n_ransac_inliers = 0; info->ransac_winner = 0; }
+    __syncthreads();
+    if (nc < 32) return;   // Ransac.cc:201-205; 17..31 would spin forever in the reference
+    if (tid == 0) {        // SetPointPair, Ransac.cc:50-83 — serial by construction (rand() stream)
+        // "used" marks live in status-independent scratch: reuse cand_scratch[N..2N) as the -1 table
+        int* used = cand_scratch + N;
+        for (int i = 0; i < nc; ++i) used[i] = 0;
+        for (int it = 0; it < 16; ++it) {
+            int a, b;
+            do { a = rng_next(rng) % nc; } while (used[a]);
+            do { b = rng_next(rng) % nc; } while (used[b] || a == b);
+            pairs[it][0] = cand_scratch[a]; pairs[it][1] = cand_scratch[b];
+            used[a] = 1; used[b] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal)
+        const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci), I = eye33();
+        m33 R = I;
+        for (int s = 0; s < m; ++s) {
+            const d3 wm = mk3(imu[s].w[0], imu[s].w[1], imu[s].w[2]);
+            const double dt = imu[s].dt, w1 = nrm3(wm), wdt = w1 * dt;
+            const m33 wx = skew33(wm), wx2 = mul33(wx, wx);
+            m33 dR;
+            if (w1 < cfg.small_angle) dR = add33(sub33(I, scl33(dt, wx)), scl33(.5 * dt * dt, wx2));
+            else dR = add33(sub33(I, scl33(sin(wdt) / w1, wx)), scl33((1 - cos(wdt)) / (w1 * w1), wx2));
+            R = mul33(dR, R);
+        }
+        R = mul33(mul33(Rci, R), Ric);
+        // SetRansacModel, Ransac.cc:86-117
+        const int ia = pairs[tid][0], ib = pairs[tid][1];
+        const d3 A1 = mk3(un1[2 * ia], un1[2 * ia + 1], 1.0), A2 = mk3(un2[2 * ia], un2[2 * ia + 1], 1.0);
+        const d3 B1 = mk3(un1[2 * ib], un1[2 * ib + 1], 1.0), B2 = mk3(un2[2 * ib], un2[2 * ib + 1], 1.0);
+        const d3 A0 = mv33(R, A1), B0 = mv33(R, B1);
+        const double c1 = A2.x * A0.y - A0.x * A2.y, c2 = A0.y * A2.z - A2.y * A0.z, c3 = A2.x * A0.z - A0.x * A2.z;
+        const double c4 = B2.x * B0.y - B0.x * B2.y, c5 = B0.y * B2.z - B2.y * B0.z, c6 = B2.x * B0.z - B0.x * B2.z;
+        const double alpha = atan2(c3 * c5 - c2 * c6, c1 * c6 - c3 * c4);
+        const double beta = atan2(-c3, c1 * sin(alpha) + c2 * cos(alpha));
+        const d3 t = mk3(sin(beta) * cos(alpha), cos(beta), -sin(beta) * sin(alpha));
+        const m33 E = mul33(skew33(t), R);
+        for (int k = 0; k < 9; ++k) hyp[tid][k] = E.m[k];
+    }
+    __syncthreads();
+    // CountInliers, Ransac.cc:158-177: thread <-> candidate, all 16 hypotheses
+    for (int base = 0; base < nc; base += 256) {
+        const int k = base + tid;
+        d3 p1 = mk3(0, 0, 1), p2 = mk3(0, 0, 1);
+        if (k < nc) { const int idx = cand_scratch[k]; p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0); p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0); }
+        for (int it = 0; it < 16; ++it) {
+            m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[it][q];
+            const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
+            const unsigned long long bal = __ballot((k < nc) && (dist < cfg.inlier_thr));
+            if ((tid & 63) == 0 && bal) atomicAdd(&cnt[it], __popcll(bal));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0, bi = 0;
+        for (int it = 0; it < 16; ++it) if (cnt[it] > best) { best = cnt[it]; bi = it; }
+        s_winner = bi;
+    }
+    __syncthreads();
+    {
+        m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[s_winner][q];
+        for (int k = tid; k < nc; k += 256) {
+            const int idx = cand_scratch[k];
+            const d3 p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0), p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0);
+            const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
+            if (dist > cfg.inlier_thr || isnan(dist)) { status[idx] = 0; atomicAdd(&s_newout, 1); }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { info->n_ransac_inliers = nc - s_newout; info->ransac_winner = s_winner; }
+}
+
+// ------------------------------------------------------------------ T6 book-keeping + refill
+// One workgroup, 256 threads.  Track histories are per-slot arrays hist[F][max_len] (float2) with
+// lengths hist_len[F]; which free slot a new feature takes is storage only and never reaches an output.
+__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand) {
+    __shared__ int s_w[4];
+    __shared__ int s_nmeas;
+    const int tid = threadIdx.x, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
+    const int N = *t.n_pts;
+    float2* hist = (float2*)t.hist;
+    float2* meas = (float2*)t.meas;
+    const float2* tr2 = (const float2*)t.tracked;
+    const float2* un2 = (const float2*)t.un2;
+    float2* feats = (float2*)t.feats;
+    float2* un1 = (float2*)t.un1;
+    float2* tf = (float2*)t.tmp_feats;
+    float2* tu = (float2*)t.tmp_un;
+    int nMeas = 0;
+    if (*t.first) {
+        // first image, Tracker.cc:204-234: seed every slot with a detector corner
+        const int n0 = n_cand < F ? n_cand : F;
+        for (int i = tid; i < F; i += 256) {
+            if (i < n0) {
+                float ux, uy;
+                undistort_pt(cfg, cand[2 * i], cand[2 * i + 1], &ux, &uy);
+                feats[i] = make_float2(cand[2 * i], cand[2 * i + 1]);
+                un1[i] = make_float2(ux, uy);
+                hist[(size_t)i * ML] = make_float2(ux, uy);
+                t.hist_len[i] = 1; t.slot[i] = i;
+            } else t.hist_len[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            *t.n_pts = n0; *t.n_feat = 0;
+            if (n0 > 0) *t.first = 0;
+            t.info->n_tracked_in = 0; t.info->n_klt_ok = 0; t.info->n_ransac_inliers = 0; t.info->ransac_winner = 0;
+            t.info->n_tracked_out = n0; t.info->n_feat_update = 0;
+        }
+        return;
+    }
+    // ---- lost tracks -> type '1' (Tracker.cc:279-303), in feature order
+    for (int base = 0; base < N; base += 256) {
+        const int i = base + tid;
+        int emit = 0, slot = 0, hl = 0;
+        const bool lost = (i < N) && !t.status[i];
+        if (lost) { slot = t.slot[i]; hl = t.hist_len[slot]; emit = (hl >= cfg.min_len) ? 1 : 0; }
+        int tot;
+        const int pos = nMeas + block_exscan(emit, &tot, s_w);
+        if (emit && pos < Fu) {
+            t.types[pos] = '1'; t.len[pos] = hl;
+            for (int k = 0; k < hl; ++k) meas[(size_t)pos * ML + k] = hist[(size_t)slot * ML + k];
+        }
+        if (lost) t.hist_len[slot] = 0;
+        nMeas = (nMeas + tot < Fu) ? nMeas + tot : Fu;
+    }
+    // ---- tracked features (Tracker.cc:305-342): type '2' at max length, history roll, new order
+    int nIn = 0;
+    const int keep = ML - ((ML + 1) / 2 - 1);   // mnMaxTrackingLength-(ceil(.5*max)-1), Tracker.cc:326
+    for (int base = 0; base < N; base += 256) {
+        const int i = base + tid;
+        const bool trk = (i < N) && t.status[i];
+        int slot = 0, hl = 0, full = 0;
+        if (trk) { slot = t.slot[i]; hl = t.hist_len[slot]; full = (hl == ML) ? 1 : 0; }
+        int tot2, totT;
+        const int pos2 = nMeas + block_exscan(full, &tot2, s_w);
+        const int posT = nIn + block_exscan(trk ? 1 : 0, &totT, s_w);
+        if (trk) {
+            float2* hs = hist + (size_t)slot * ML;
+            if (full) {
+                int shift = 1;
+                if (pos2 < Fu) {
+                    t.types[pos2] = '2'; t.len[pos2] = hl;
+                    for (int k = 0; k < hl; ++k) meas[(size_t)pos2 * ML + k] = hs[k];
+                    shift = ML - keep;
+                }
+                for (int k = 0; k + shift < hl; ++k) hs[k] = hs[k + shift];
+                hl -= shift;
+            }
+            hs[hl] = un2[i];
+            t.hist_len[slot] = hl + 1;
+            tf[posT] = tr2[i]; tu[posT] = un2[i]; t.tmp_slot[posT] = slot;
+        }
+        nMeas = (nMeas + tot2 < Fu) ? nMeas + tot2 : Fu;
+        nIn += totT;
+    }
+    __syncthreads();
+    // ---- refill (Tracker.cc:344-387) through FindNewer/ChessGrid (FeatureDetector.cc:78-150)
+    int nNew = 0;
+    if (nIn < F && n_cand > 0) {
+        const int cells = cfg.grid_cols * cfg.grid_rows;
+        const float W = (float)cfg.W, H = (float)cfg.H, offX = cfg.off_x, offY = cfg.off_y;
+        const int nc = n_cand < F ? n_cand : F;
+        for (int c = tid; c < nc; c += 256) t.cand_acc[c] = 0;
+        __syncthreads();
+        // thread <-> grid cell: gather the cell's tracked points, then walk the candidates in order
+        for (int cell = tid; cell < cells; cell += 256) {
+            float2* cp = (float2*)t.cell_pts + (size_t)cell * (2 * F);
+            int cn = 0;
+            for (int i = 0; i < nIn; ++i) {
+                const float2 p = tf[i];
+                if (p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY)) continue;
+                const int col = (int)floorf((p.x - offX) / cfg.block_x), row = (int)floorf((p.y - offY) / cfg.block_y);
+                if (row * cfg.grid_cols + col == cell) cp[cn++] = p;
+            }
+            for (int c = 0; c < nc; ++c) {
+                const float2 p = make_float2(cand[2 * c], cand[2 * c + 1]);
+                if (p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY)) continue;
+                const int col = (int)floorf((p.x - offX) / cfg.block_x), row = (int)floorf((p.y - offY) / cfg.block_y);
+                if (row * cfg.grid_cols + col != cell) continue;
+                const float xl = col * cfg.block_x + offX, xr = xl + cfg.block_x, yt = row * cfg.block_y + offY, yb = yt + cfg.block_y;
+                if (fabsf(p.x - xl) < cfg.min_dist || fabsf(p.x - xr) < cfg.min_dist || fabsf(p.y - yt) < cfg.min_dist || fabsf(p.y - yb) < cfg.min_dist) continue;
+                if (!((double)(float)cn < .75 * (double)cfg.max_per_block)) continue;
+                bool ok = true;
+                for (int q = 0; q < cn; ++q) {
+                    const float dx = p.x - cp[q].x, dy = p.y - cp[q].y;
+                    const double dist = sqrt((double)dx * dx + (double)dy * dy);
+                    if (!(dist > (double)cfg.min_dist)) { ok = false; break; }
+                }
+                if (ok) { cp[cn++] = p; t.cand_acc[c] = 1; }
+            }
+        }
+        __syncthreads();
+        // accepted candidates keep detector order; the k-th accepted takes the k-th free slot
+        const int room = F - nIn;
+        for (int base = 0; base < nc; base += 256) {
+            const int c = base + tid;
+            const int ac = (c < nc) ? t.cand_acc[c] : 0;
+            int tot;
+            const int k = nNew + block_exscan(ac, &tot, s_w);
+            if (ac && k < room) { tf[nIn + k] = make_float2(cand[2 * c], cand[2 * c + 1]); }
+            nNew = (nNew + tot < room) ? nNew + tot : room;
+        }
+        __syncthreads();
+        int nFree = 0;
+        for (int base = 0; base < F; base += 256) {
+            const int s = base + tid;
+            const int fr = (s < F && t.hist_len[s] == 0) ? 1 : 0;
+            int tot;
+            const int k = nFree + block_exscan(fr, &tot, s_w);
+            if (fr && k < nNew) {
+                float ux, uy;
+                const float2 p = tf[nIn + k];
+                undistort_pt(cfg, p.x, p.y, &ux, &uy);
+                tu[nIn + k] = make_float2(ux, uy);
+                t.tmp_slot[nIn + k] = s;
+                hist[(size_t)s * ML] = make_float2(ux, uy);
+                t.hist_len[s] = 1;
+            }
+            nFree += tot;
+        }
+    }
+    __syncthreads();
+    const int nOut = nIn + nNew;
+    for (int i = tid; i < nOut; i += 256) { feats[i] = tf[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
+    if (tid == 0) {
+        *t.n_pts = nOut; *t.n_feat = nMeas;
+        t.info->n_tracked_out = nOut; t.info->n_feat_update = nMeas;
+    }
+}
+
+// direct-track mode: the caller supplies vFeatsTracked / vInlierFlag (the KLT result)
+__global__ void load_points_kernel(const int* n_pts_ptr, const float* in_xy, const unsigned char* in_st, float* tracked, unsigned char* status) {
+    const int N = *n_pts_ptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        tracked[2 * i] = in_xy[2 * i]; tracked[2 * i + 1] = in_xy[2 * i + 1]; status[i] = in_st[i];
+    }
+}

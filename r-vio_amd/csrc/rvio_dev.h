@@ -1,0 +1,149 @@
+// rvio_dev.h — device-side data layout and small math helpers (gfx950 only).
+//
+// HBM layout of one filter instance (all owned by the rvio_hip handle):
+//   FilterState[2]   double-buffered (x, P): every stage that is not a
+//                    single-workgroup in-place update reads buffer `cur` and
+//                    writes `cur^1`; the host toggles `cur` (the toggle count
+//                    per entry point is data-independent, so no host sync).
+//   x     : xdmax doubles  [qG pG g | qk pk v bg ba | n x (q p)]
+//   P     : dmax x dmax doubles, COLUMN-major, ld = dmax; the active matrix is
+//           the leading d x d block, d = 24 + 6 n.
+//   n_clones lives in device memory (FilterMeta) so captured graphs stay valid
+//   while the window fills.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RVIO_MAX_IMU 64      // IMU samples per frame the propagate kernel accepts
+#define RVIO_MAX_LEN 32      // max Tracker.nMaxTrackingLength supported (cfg E: 31)
+
+struct DevCfg {
+    double gravity, small_angle;
+    double sg2, swg2, sa2, swa2;  // squared IMU sigmas (ImuNoiseMatrix diagonal, PreIntegrator.cc:40-44)
+    double sigma_im;              // max(sigma_px, sigma_py) as float->double (Updater.cc:42-44)
+    double inlier_thr;
+    double Ric[9], Rci[9], tic[3], tci[3];  // row-major 3x3 (Updater.cc:46-53)
+    float fx, fy, cx, cy, k1, k2, p1, p2, k3;
+    float min_dist, off_x, off_y, max_per_block;  // FeatureDetector.cc:29-52
+    int W, H;
+    int F, Fu, max_len, min_len;
+    int nmax, dmax, xdmax;
+    int rho_max;   // max nullspace rows per feature = 2*max_len - 2
+    int ldh;       // row stride (doubles) of stacked [Hx | r] rows = 6*nmax + 1
+    int grid_cols, grid_rows, block_x, block_y;
+    int use_sampson;
+    int levels;    // pyramid levels actually used (maxLevel+1)
+};
+
+struct FilterMeta {
+    int n_clones;      // nCloneStates (System.cc:175)
+    int img_count;     // nImageCountAfterInit (System.cc:176)
+    int n_good;        // nGoodFeatCount of the last update
+    int n_rows;        // nRowCount of the last update
+    int updated;       // last update applied?
+    int err;           // sticky device-side error flag (singular pivot etc.)
+    int pad[2];
+};
+
+// ---------------------------------------------------------------- small math
+struct d3 { double x, y, z; };
+struct m33 { double m[9]; };  // row-major
+
+__device__ __forceinline__ d3 mk3(double a, double b, double c) { d3 r; r.x = a; r.y = b; r.z = c; return r; }
+__device__ __forceinline__ d3 add3(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 sub3(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 scl3(double s, d3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ double nrm3(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ d3 unit3(d3 a) { double n = nrm3(a); return mk3(a.x / n, a.y / n, a.z / n); }
+__device__ __forceinline__ d3 ld3(const double* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(double* p, d3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+__device__ __forceinline__ m33 eye33() { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0; return r; }
+__device__ __forceinline__ m33 ldm33(const double* p) { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
+__device__ __forceinline__ m33 mul33(const m33& A, const m33& B) {
+    m33 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+__device__ __forceinline__ d3 mv33(const m33& A, d3 v) {
+    return mk3(A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z, A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z);
+}
+__device__ __forceinline__ m33 tr33(const m33& A) { m33 C; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * j + i]; return C; }
+__device__ __forceinline__ m33 add33(const m33& A, const m33& B) { m33 C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] + B.m[i]; return C; }
+__device__ __forceinline__ m33 sub33(const m33& A, const m33& B) { m33 C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] - B.m[i]; return C; }
+__device__ __forceinline__ m33 scl33(double s, const m33& A) { m33 C; for (int i = 0; i < 9; ++i) C.m[i] = s * A.m[i]; return C; }
+// SkewSymm, util/Numerics.h:97-105
+__device__ __forceinline__ m33 skew33(d3 w) {
+    m33 S;
+    S.m[0] = 0; S.m[1] = -w.z; S.m[2] = w.y;
+    S.m[3] = w.z; S.m[4] = 0; S.m[5] = -w.x;
+    S.m[6] = -w.y; S.m[7] = w.x; S.m[8] = 0;
+    return S;
+}
+
+struct q4 { double x, y, z, w; };
+__device__ __forceinline__ q4 ldq(const double* p) { q4 q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
+__device__ __forceinline__ void stq(double* p, q4 q) { p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w; }
+__device__ __forceinline__ q4 qnorm_pos(q4 q) {
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    return q;
+}
+// QuatMul, util/Numerics.h:30-63 (JPL; normalises, forces w>=0)
+__device__ __forceinline__ q4 qmul(q4 a, q4 b) {
+    q4 q;
+    q.x = a.w * b.x + a.z * b.y - a.y * b.z + a.x * b.w;
+    q.y = -a.z * b.x + a.w * b.y + a.x * b.z + a.y * b.w;
+    q.z = a.y * b.x - a.x * b.y + a.w * b.z + a.z * b.w;
+    q.w = -a.x * b.x - a.y * b.y - a.z * b.z + a.w * b.w;
+    return qnorm_pos(q);
+}
+// QuatToRot, util/Numerics.h:111-120: I - 2 w [q]x + 2 [q]x^2
+__device__ __forceinline__ m33 q2r(q4 q) {
+    m33 qx = skew33(mk3(q.x, q.y, q.z));
+    return add33(sub33(eye33(), scl33(2 * q.w, qx)), scl33(2.0, mul33(qx, qx)));
+}
+// RotToQuat, util/Numerics.h:126-167 (Breckenridge 4-branch)
+__device__ __forceinline__ q4 r2q(const m33& R) {
+    q4 q;
+    const double r00 = R.m[0], r11 = R.m[4], r22 = R.m[8];
+    const double T = r00 + r11 + r22;
+    if (r00 > T && r00 > r11 && r00 > r22) {
+        q.x = sqrt((1 + 2 * r00 - T) / 4); double k = 1 / (4 * q.x);
+        q.y = k * (R.m[1] + R.m[3]); q.z = k * (R.m[2] + R.m[6]); q.w = k * (R.m[5] - R.m[7]);
+    } else if (r11 > T && r11 > r00 && r11 > r22) {
+        q.y = sqrt((1 + 2 * r11 - T) / 4); double k = 1 / (4 * q.y);
+        q.x = k * (R.m[1] + R.m[3]); q.z = k * (R.m[5] + R.m[7]); q.w = k * (R.m[6] - R.m[2]);
+    } else if (r22 > T && r22 > r00 && r22 > r11) {
+        q.z = sqrt((1 + 2 * r22 - T) / 4); double k = 1 / (4 * q.z);
+        q.x = k * (R.m[2] + R.m[6]); q.y = k * (R.m[5] + R.m[7]); q.w = k * (R.m[1] - R.m[3]);
+    } else {
+        q.w = sqrt((1 + T) / 4); double k = 1 / (4 * q.w);
+        q.x = k * (R.m[5] - R.m[7]); q.y = k * (R.m[6] - R.m[2]); q.z = k * (R.m[1] - R.m[3]);
+    }
+    return qnorm_pos(q);
+}
+// dq from an error angle (Updater.cc:549-563)
+__device__ __forceinline__ q4 small_q(double ex, double ey, double ez) {
+    q4 q; q.x = .5 * ex; q.y = .5 * ey; q.z = .5 * ez;
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n < 1) q.w = sqrt(1 - n * n);
+    else { double k = 1 / sqrt(1 + n * n); q.x *= k; q.y *= k; q.z *= k; q.w = k; }
+    return q;
+}
+
+// ---------------------------------------------------------------- wave helpers (wave64)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

@@ -1,0 +1,606 @@
+// rvio_hip.hip — the C-ABI of include/rvio_hip.h: handle, HBM allocation, kernel sequencing.
+// Single translation unit: the two kernel files are included so that one hipcc call
+// builds the whole library (frontend_kernels.hip switches FP contraction off for itself).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rvio_hip.h"
+#include "rvio_dev.h"
+#include "frontend_dev.h"
+#include "filter_kernels.hip"
+#pragma clang fp contract(off)
+#include "frontend_kernels.hip"
+#pragma clang fp contract(fast)
+
+struct rvio_hip {
+    rvio_config cfg;
+    DevCfg dc;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // filter state (double-buffered)
+    FilterMeta* meta = nullptr;
+    double* x[2] = {nullptr, nullptr};
+    double* P[2] = {nullptr, nullptr};
+    int cur = 0;
+    int img_count = 0;      // host mirror of nImageCountAfterInit (data-independent)
+    int n_clones_host = 0;  // host mirror of nCloneStates (data-independent)
+    // update scratch
+    double *Hstack = nullptr, *partial = nullptr, *block = nullptr, *Ab = nullptr, *Aug = nullptr, *U = nullptr, *G = nullptr,
+           *Pt1 = nullptr, *Pt2 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
+    int *nrows = nullptr, *acc = nullptr, *ndof = nullptr;
+    int n_groups = 0, feat_threads = 64;
+    size_t feat_lds = 0, gj_lds = 0;
+    int gj_use_lds = 0;
+    // staging
+    rvio_imu* d_imu = nullptr;
+    float* d_cand = nullptr;
+    uint8_t* d_img = nullptr;
+    float* d_in_xy = nullptr;
+    unsigned char* d_in_st = nullptr;
+    // tracker
+    TrackerDev t;
+    PyrDev pyr[2];
+    int pyr_cur = 0;
+    std::vector<void*> allocs;
+    int* rng = nullptr;
+    int* cand_scratch = nullptr;
+    rvio_frame_info* d_info = nullptr;
+    double* d_pose = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return RVIO_ERR_NO_DEVICE;                                                           \
+        }                                                                                        \
+    } while (0)
+
+template <typename T>
+static int dalloc(rvio_hip* h, T** p, size_t n) {
+    void* q = nullptr;
+    size_t bytes = n * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    HIPCHK(h, hipMalloc(&q, bytes));
+    HIPCHK(h, hipMemsetAsync(q, 0, bytes, h->stream));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return RVIO_OK;
+}
+#define DALLOC(h, p, n)                               \
+    do {                                              \
+        int rc_ = dalloc((h), &(p), (n));             \
+        if (rc_ != RVIO_OK) return rc_;               \
+    } while (0)
+
+extern "C" {
+
+int rvio_hip_abi_version(void) { return RVIO_HIP_ABI_VERSION; }
+
+// config/rvio_euroc.yaml:8-111
+void rvio_config_euroc(rvio_config* c) {
+    std::memset(c, 0, sizeof *c);
+    c->imu_rate = 200;
+    c->sigma_g = 1.6968e-04; c->sigma_wg = 1.9393e-05; c->sigma_a = 2.0e-3; c->sigma_wa = 3.0e-3;
+    c->gravity = 9.8082; c->small_angle = 0.001745329;
+    c->width = 752; c->height = 480;
+    c->fx = 458.654f; c->fy = 457.296f; c->cx = 367.215f; c->cy = 248.375f;
+    c->k1 = -0.28340811f; c->k2 = 0.07395907f; c->p1 = 0.00019359f; c->p2 = 1.76187114e-05f; c->k3 = 0.f;
+    c->sigma_px = 0.002180293f; c->sigma_py = 0.002186767f;
+    const double T[16] = {0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975,
+                          0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768,
+                          -0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949,
+                          0.0, 0.0, 0.0, 1.0};
+    std::memcpy(c->T_bc, T, sizeof T);
+    c->fisheye = 0;
+    c->n_features = 200; c->max_track_len = 15; c->min_track_len = 3;
+    c->min_dist = 15; c->qual_lvl = 0.01f; c->block_x = 150; c->block_y = 120;
+    c->enable_equalizer = 1; c->use_sampson = 1; c->inlier_thr = 1e-5;
+    c->ini_thr_angle = 0.005; c->ini_thr_displ = 0.01; c->ini_enable_alignment = 1;
+}
+
+static void fill_devcfg(const rvio_config* c, DevCfg* d) {
+    std::memset(d, 0, sizeof *d);
+    d->gravity = c->gravity; d->small_angle = c->small_angle;
+    d->sg2 = c->sigma_g * c->sigma_g; d->swg2 = c->sigma_wg * c->sigma_wg;
+    d->sa2 = c->sigma_a * c->sigma_a; d->swa2 = c->sigma_wa * c->sigma_wa;
+    d->sigma_im = (double)std::max(c->sigma_px, c->sigma_py);   // float max, widened (Updater.cc:42-44)
+    d->inlier_thr = c->inlier_thr;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { d->Ric[3 * i + j] = c->T_bc[4 * i + j]; d->Rci[3 * j + i] = c->T_bc[4 * i + j]; }
+        d->tic[i] = c->T_bc[4 * i + 3];
+    }
+    for (int i = 0; i < 3; ++i) d->tci[i] = -(d->Rci[3 * i] * d->tic[0] + d->Rci[3 * i + 1] * d->tic[1] + d->Rci[3 * i + 2] * d->tic[2]);
+    d->fx = c->fx; d->fy = c->fy; d->cx = c->cx; d->cy = c->cy;
+    d->k1 = c->k1; d->k2 = c->k2; d->p1 = c->p1; d->p2 = c->p2; d->k3 = c->k3;
+    d->W = c->width; d->H = c->height;
+    d->F = c->n_features; d->Fu = (int)std::ceil(.5 * c->n_features);
+    d->max_len = c->max_track_len; d->min_len = c->min_track_len;
+    d->nmax = c->max_track_len - 1; d->dmax = 24 + 6 * d->nmax; d->xdmax = 26 + 7 * d->nmax;
+    d->rho_max = 2 * c->max_track_len - 2;
+    d->ldh = 6 * d->nmax + 1;
+    // FeatureDetector ctor, FeatureDetector.cc:29-52
+    d->min_dist = c->min_dist;
+    d->block_x = c->block_x; d->block_y = c->block_y;
+    d->grid_cols = (int)std::floor((double)(c->width / c->block_x));
+    d->grid_rows = (int)std::floor((double)(c->height / c->block_y));
+    d->off_x = (float)(.5 * (c->width - d->grid_cols * c->block_x));
+    d->off_y = (float)(.5 * (c->height - d->grid_rows * c->block_y));
+    d->max_per_block = (float)c->n_features / (float)(d->grid_cols * d->grid_rows);
+    d->use_sampson = c->use_sampson;
+    // buildOpticalFlowPyramid: stop when a level is not larger than the window
+    int w = c->width, hgt = c->height, lv = 1;
+    for (int l = 1; l <= 3; ++l) { w = (w + 1) / 2; hgt = (hgt + 1) / 2; if (w <= 15 || hgt <= 15) break; lv++; }
+    d->levels = lv;
+}
+
+int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
+    if (!cfg || !out) return RVIO_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->fisheye) return RVIO_ERR_UNSUPPORTED;
+    if (cfg->max_track_len < 3 || cfg->max_track_len > RVIO_MAX_LEN || cfg->n_features < 2 || cfg->min_track_len < 2) return RVIO_ERR_INVALID;
+    if (cfg->enable_equalizer) return RVIO_ERR_UNSUPPORTED;   // CLAHE (Tracker.cc:198-202) is a SURVEY 8(f) "next" row
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) return RVIO_ERR_NO_DEVICE;
+    rvio_hip* h = new rvio_hip();
+    h->cfg = *cfg; h->device = device;
+    fill_devcfg(cfg, &h->dc);
+    const DevCfg& d = h->dc;
+    if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
+    *out = h;   // returned even on allocation failure so last_error is readable
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
+    DALLOC(h, h->meta, 1);
+    for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
+    DALLOC(h, h->Hstack, (size_t)d.Fu * d.rho_max * ldh);
+    h->n_groups = (d.Fu + GRAM_FG - 1) / GRAM_FG;
+    DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
+    DALLOC(h, h->block, ldh * ldh);
+    DALLOC(h, h->Ab, ldh * ldh);
+    DALLOC(h, h->Aug, ldh * 2 * ldh);
+    DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
+    DALLOC(h, h->Pt1, PP); DALLOC(h, h->Pt2, PP);
+    DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
+    DALLOC(h, h->nrows, d.Fu); DALLOC(h, h->acc, d.Fu); DALLOC(h, h->ndof, d.Fu);
+    DALLOC(h, h->d_imu, RVIO_MAX_IMU);
+    DALLOC(h, h->d_cand, (size_t)2 * d.F);
+    DALLOC(h, h->d_img, (size_t)d.W * d.H);
+    DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
+    DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
+    DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
+    // tracker
+    TrackerDev& t = h->t;
+    DALLOC(h, t.first, 1); DALLOC(h, t.n_pts, 1); DALLOC(h, t.n_feat, 1);
+    DALLOC(h, t.feats, (size_t)2 * d.F); DALLOC(h, t.un1, (size_t)2 * d.F); DALLOC(h, t.slot, d.F);
+    DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
+    DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
+    DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
+    DALLOC(h, t.cand_acc, d.F);
+    DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
+    DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
+    t.info = h->d_info;
+    { int one = 1; HIPCHK(h, hipMemcpyAsync(t.first, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); }
+    for (int b = 0; b < 2; ++b) {
+        int w = d.W, hg = d.H;
+        for (int l = 0; l < 4; ++l) {
+            uint8_t* im = nullptr; short* dx = nullptr;
+            if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
+            h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
+            w = (w + 1) / 2; hg = (hg + 1) / 2;
+        }
+    }
+    // launch geometry
+    h->feat_threads = (d.ldh <= 64) ? 64 : (d.ldh <= 128 ? 128 : 256);
+    h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
+    if (h->feat_lds > 150 * 1024) {
+        h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, false) * sizeof(double);
+        DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
+    }
+    if (h->feat_lds > 160 * 1024) { h->err = "per-feature LDS footprint exceeds 160 KiB"; return RVIO_ERR_UNSUPPORTED; }
+    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    {
+        const size_t ncol = 2 * ldh, ldm = ncol | 1;
+        h->gj_lds = (size_t)(d.ldh - 1) * ldm * sizeof(double);
+        h->gj_use_lds = h->gj_lds <= 150 * 1024;
+        if (!h->gj_use_lds) h->gj_lds = 0;
+        HIPCHK(h, hipFuncSetAttribute((const void*)gj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gj_lds));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+void rvio_hip_destroy(rvio_hip* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+const char* rvio_hip_last_error(const rvio_hip* h) { return h ? h->err.c_str() : "null handle"; }
+void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
+int rvio_hip_sync(rvio_hip* h) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+// ------------------------------------------------------------------ state
+int rvio_hip_set_state(rvio_hip* h, const double* x, int xdim, const double* P, int d) {
+    if (!h || !x || !P) return RVIO_ERR_INVALID;
+    const int n = (xdim - 26) / 7;
+    if (xdim != 26 + 7 * n || d != 24 + 6 * n || n < 0 || n > h->dc.nmax) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->P[h->cur], 0, sizeof(double) * h->dc.dmax * h->dc.dmax, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->x[h->cur], x, sizeof(double) * xdim, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->P[h->cur], sizeof(double) * h->dc.dmax, P, sizeof(double) * d, sizeof(double) * d, d,
+                               hipMemcpyHostToDevice, h->stream));
+    FilterMeta m; std::memset(&m, 0, sizeof m);
+    m.n_clones = n; m.img_count = h->img_count;
+    HIPCHK(h, hipMemcpyAsync(h->meta, &m, sizeof m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_clones_host = n;
+    return RVIO_OK;
+}
+
+int rvio_hip_get_state(rvio_hip* h, double* x, int* xdim, double* P, int* d) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    FilterMeta m;
+    HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int n = m.n_clones, dd = 24 + 6 * n, xd = 26 + 7 * n;
+    if (xdim) *xdim = xd;
+    if (d) *d = dd;
+    if (x) HIPCHK(h, hipMemcpyAsync(x, h->x[h->cur], sizeof(double) * xd, hipMemcpyDeviceToHost, h->stream));
+    if (P) HIPCHK(h, hipMemcpy2DAsync(P, sizeof(double) * dd, h->P[h->cur], sizeof(double) * h->dc.dmax, sizeof(double) * dd, dd,
+                                      hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+// System::initialize (System.cc:115-170): runs once, on the host; result uploaded.
+int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n_imu) {
+    if (!h || !w || !a) return RVIO_ERR_INVALID;
+    const rvio_config& c = h->cfg;
+    double an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    double g[3] = {a[0] / an, a[1] / an, a[2] / an};
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (c.ini_enable_alignment) {
+        double xv[3], yv[3];
+        const double ex[3] = {1, 0, 0};
+        for (int i = 0; i < 3; ++i) xv[i] = ex[i] - (g[i] * g[0] * ex[0] + g[i] * g[1] * ex[1] + g[i] * g[2] * ex[2]);
+        double xn = std::sqrt(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
+        for (int i = 0; i < 3; ++i) xv[i] /= xn;
+        yv[0] = -g[2] * xv[1] + g[1] * xv[2]; yv[1] = g[2] * xv[0] - g[0] * xv[2]; yv[2] = -g[1] * xv[0] + g[0] * xv[1];
+        double yn = std::sqrt(yv[0] * yv[0] + yv[1] * yv[1] + yv[2] * yv[2]);
+        for (int i = 0; i < 3; ++i) yv[i] /= yn;
+        for (int i = 0; i < 3; ++i) { R[3 * i] = xv[i]; R[3 * i + 1] = yv[i]; R[3 * i + 2] = g[i]; }
+    }
+    // RotToQuat (Numerics.h:126-167), host copy
+    double q[4]; const double T = R[0] + R[4] + R[8];
+    if (R[0] > T && R[0] > R[4] && R[0] > R[8]) { q[0] = std::sqrt((1 + 2 * R[0] - T) / 4); double k = 1 / (4 * q[0]); q[1] = k * (R[1] + R[3]); q[2] = k * (R[2] + R[6]); q[3] = k * (R[5] - R[7]); }
+    else if (R[4] > T && R[4] > R[0] && R[4] > R[8]) { q[1] = std::sqrt((1 + 2 * R[4] - T) / 4); double k = 1 / (4 * q[1]); q[0] = k * (R[1] + R[3]); q[2] = k * (R[5] + R[7]); q[3] = k * (R[6] - R[2]); }
+    else if (R[8] > T && R[8] > R[0] && R[8] > R[4]) { q[2] = std::sqrt((1 + 2 * R[8] - T) / 4); double k = 1 / (4 * q[2]); q[0] = k * (R[2] + R[6]); q[1] = k * (R[5] + R[7]); q[3] = k * (R[1] - R[3]); }
+    else { q[3] = std::sqrt((1 + T) / 4); double k = 1 / (4 * q[3]); q[0] = k * (R[5] - R[7]); q[1] = k * (R[6] - R[2]); q[2] = k * (R[1] - R[3]); }
+    double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= qn;
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    double x[26] = {0}; double P[576] = {0};
+    for (int i = 0; i < 4; ++i) x[i] = q[i];
+    for (int i = 0; i < 3; ++i) x[7 + i] = g[i];
+    if (n_imu > 1) for (int i = 0; i < 3; ++i) { x[20 + i] = w[i]; x[23 + i] = a[i] - c.gravity * g[i]; }
+    const double dt = 1. / c.imu_rate;
+    auto D = [&](int i, double v) { P[i * 24 + i] = v; };
+    for (int i = 0; i < 6; ++i) D(i, std::pow(1e-3, 2));
+    for (int i = 6; i < 9; ++i) D(i, n_imu * dt * std::pow(c.sigma_a, 2));
+    for (int i = 18; i < 21; ++i) D(i, n_imu * dt * std::pow(c.sigma_wg, 2));
+    for (int i = 21; i < 24; ++i) D(i, n_imu * dt * std::pow(c.sigma_wa, 2));
+    h->img_count = 0;
+    return rvio_hip_set_state(h, x, 26, P, 24);
+}
+
+// ------------------------------------------------------------------ P1
+static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
+    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->x[h->cur], h->P[h->cur], d_imu, m);
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+int rvio_hip_propagate(rvio_hip* h, const rvio_imu* imu, int m) {
+    if (!h || !imu || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    return propagate_dev(h, h->d_imu, m);
+}
+
+// ------------------------------------------------------------------ U1..U10
+static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
+    const DevCfg& d = h->dc;
+    if (!tr || tr->n_feat < 0 || tr->n_feat > d.Fu) return RVIO_ERR_INVALID;
+    std::vector<float> meas((size_t)d.Fu * d.max_len * 2, 0.f);
+    for (int f = 0; f < tr->n_feat; ++f) {
+        if (tr->len[f] < 2 || tr->len[f] > d.max_len || tr->len[f] > tr->max_len) return RVIO_ERR_INVALID;
+        if (tr->len[f] - 1 > h->n_clones_host) return RVIO_ERR_INVALID;
+        std::memcpy(&meas[(size_t)f * d.max_len * 2], tr->meas + (size_t)f * tr->max_len * 2, sizeof(float) * 2 * tr->len[f]);
+    }
+    int nf = tr->n_feat;
+    HIPCHK(h, hipMemcpyAsync(h->t.n_feat, &nf, sizeof nf, hipMemcpyHostToDevice, h->stream));
+    if (nf > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->t.types, tr->types, nf, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->t.len, tr->len, sizeof(int) * nf, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->t.meas, meas.data(), sizeof(float) * meas.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // `meas` is a stack-lifetime staging buffer
+    return RVIO_OK;
+}
+
+static int update_local_dev(rvio_hip* h, int rank, int world) {
+    const DevCfg& d = h->dc;
+    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, h->meta, h->x[h->cur], h->P[h->cur],
+                       h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
+                       h->tm_global);
+    hipLaunchKernelGGL(gram_kernel, dim3(h->n_groups, (d.ldh - 1 + 15) / 16), dim3(256), 0, h->stream, d, h->meta, h->Hstack, h->nrows, h->partial);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (d.ldh * d.ldh + 255) / 256))), dim3(256), 0, h->stream, d, h->meta,
+                       h->partial, h->n_groups, h->nrows, h->block);
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
+static void gemm(rvio_hip* h, int mode, int need_update, double alpha, const double* A, long sar, long sac, const double* B, long sbr, long sbc,
+                 double beta, const double* Cin, long scr, long scc, double* Cout, long sor, long soc) {
+    GemmArgs g;
+    g.A = A; g.sar = sar; g.sac = sac; g.B = B; g.sbr = sbr; g.sbc = sbc;
+    g.Cin = Cin; g.scr = scr; g.scc = scc; g.Cout = Cout; g.sor = sor; g.soc = soc;
+    g.alpha = alpha; g.beta = beta; g.mode = mode; g.need_update = need_update;
+    const int tiles = (h->dc.dmax + 31) / 32;
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles, tiles), dim3(256), 0, h->stream, h->meta, g);
+}
+
+static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
+    const DevCfg& d = h->dc;
+    const long ld = d.dmax, ldh = d.ldh, lda = 2 * ldh;
+    const double s2 = d.sigma_im * d.sigma_im;
+    double* Pc = h->P[h->cur];
+    double* Pn = h->P[h->cur ^ 1];
+    const int eg = std::max(1, std::min(64, (int)((ldh * ldh + 255) / 256)));
+    hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, h->meta, d_blocks, world, (size_t)(ldh * ldh), h->Ab, h->Aug);
+    // T = s2 I + A Pcc                      (c6 x c6 x c6)
+    gemm(h, 2, 1, 1.0, h->Ab, ldh, 1, Pc + 24 + 24 * ld, 1, ld, 1.0, h->Aug, lda, 1, h->Aug, lda, 1);
+    hipLaunchKernelGGL(gj_kernel, dim3(1), dim3(1024), h->gj_lds, h->stream, d, h->meta, h->Aug, h->gj_use_lds);
+    hipLaunchKernelGGL(inject_kernel, dim3(1), dim3(256), 0, h->stream, d, h->meta, h->x[h->cur], Pc, h->Aug, h->x[h->cur ^ 1]);
+    // U = Pc W, G = U A  (K H = [0 | G]),  Joseph form (Updater.cc:615-619) in the information parametrisation:
+    //   P+ = (I-KH) P (I-KH)^T + s2 K K^T,  (I-KH)P = P - G Pc^T,  s2 K K^T = s2 G U^T
+    gemm(h, 0, 1, 1.0, Pc + 24 * ld, 1, ld, h->Aug + ldh, lda, 1, 0.0, nullptr, 0, 0, h->U, ldh, 1);
+    gemm(h, 0, 1, 1.0, h->U, ldh, 1, h->Ab, ldh, 1, 0.0, nullptr, 0, 0, h->G, ldh, 1);
+    gemm(h, 1, 1, -1.0, h->G, ldh, 1, Pc + 24 * ld, ld, 1, 1.0, Pc, 1, ld, h->Pt1, 1, ld);
+    gemm(h, 1, 1, -1.0, h->Pt1 + 24 * ld, 1, ld, h->G, 1, ldh, 1.0, h->Pt1, 1, ld, h->Pt2, 1, ld);
+    gemm(h, 1, 1, s2, h->G, ldh, 1, h->U, 1, ldh, 1.0, h->Pt2, 1, ld, h->Pt2, 1, ld);
+    const int sg = std::max(1, std::min(256, (int)((ld * ld + 255) / 256)));
+    hipLaunchKernelGGL(symm_out_kernel, dim3(sg), dim3(256), 0, h->stream, d, h->meta, h->Pt2, Pc, Pn);
+    HIPCHK(h, hipGetLastError());
+    h->cur ^= 1;
+    return RVIO_OK;
+}
+
+int rvio_hip_update_tracked(rvio_hip* h) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = update_local_dev(h, 0, 1);
+    if (rc != RVIO_OK) return rc;
+    return update_global_dev(h, h->block, 1);
+}
+int rvio_hip_update(rvio_hip* h, const rvio_tracks* tracks) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = upload_tracks(h, tracks);
+    if (rc != RVIO_OK) return rc;
+    return rvio_hip_update_tracked(h);
+}
+int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int world, double** d_block, int* n_doubles) {
+    if (!h || world < 1 || rank < 0 || rank >= world) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (tracks) { int rc = upload_tracks(h, tracks); if (rc != RVIO_OK) return rc; }
+    int rc = update_local_dev(h, rank, world);
+    if (d_block) *d_block = h->block;
+    if (n_doubles) *n_doubles = h->dc.ldh * h->dc.ldh;
+    return rc;
+}
+int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
+    if (!h || !d_blocks || world < 1) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return update_global_dev(h, d_blocks, world);
+}
+
+int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int nf = 0;
+    HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_feat) *n_feat = nf;
+    if (nf > 0) {
+        if (accepted) HIPCHK(h, hipMemcpyAsync(accepted, h->acc, sizeof(int) * nf, hipMemcpyDeviceToHost, h->stream));
+        if (gamma) HIPCHK(h, hipMemcpyAsync(gamma, h->gamma, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
+        if (ndof) HIPCHK(h, hipMemcpyAsync(ndof, h->ndof, sizeof(int) * nf, hipMemcpyDeviceToHost, h->stream));
+        if (pfinv) HIPCHK(h, hipMemcpyAsync(pfinv, h->pfinv, sizeof(double) * 3 * nf, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+// ------------------------------------------------------------------ S1 + S2
+static int augment_compose_dev(rvio_hip* h, int do_augment) {
+    const DevCfg& d = h->dc;
+    const int c = h->cur, o = c ^ 1;
+    const int ag = std::max(1, std::min(256, (d.dmax * d.dmax + 255) / 256));
+    hipLaunchKernelGGL(augment_kernel, dim3(ag), dim3(256), 0, h->stream, d, h->meta, h->x[c], h->P[c], h->x[o], h->P[o], do_augment);
+    hipLaunchKernelGGL(meta_after_augment_kernel, dim3(1), dim3(64), 0, h->stream, d, h->meta, do_augment);
+    const int cg = 1 + std::max(1, (6 * d.nmax + 255) / 256);
+    hipLaunchKernelGGL(compose_kernel, dim3(cg), dim3(256), 0, h->stream, d, h->meta, h->x[o], h->P[o], h->x[c], h->P[c], h->d_pose);
+    HIPCHK(h, hipGetLastError());
+    if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
+    return RVIO_OK;
+}
+int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return augment_compose_dev(h, do_augment);
+}
+
+// ------------------------------------------------------------------ T1..T6
+static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int b) {
+    const DevCfg& d = h->dc;
+    PyrDev& p = h->pyr[b];
+    HIPCHK(h, hipMemcpy2DAsync((void*)p.img[0], d.W, d_img, stride, d.W, d.H, hipMemcpyDeviceToDevice, h->stream));
+    for (int l = 1; l < d.levels; ++l)
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, p.img[l - 1], p.w[l - 1], p.h[l - 1],
+                           p.w[l - 1], (uint8_t*)p.img[l], p.w[l], p.h[l]);
+    for (int l = 0; l < d.levels; ++l)
+        hipLaunchKernelGGL(scharr_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, p.img[l], p.w[l], p.h[l], p.w[l],
+                           (short*)p.dxy[l]);
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
+// everything after Tracker.cc:246; status/tracked already on the device
+static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2, h->t.status, d_imu, m,
+                       h->rng, h->cand_scratch, h->d_info);
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->t, d_cand, n_cand);
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
+int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
+    int rc = build_pyramid_dev(h, d_img, stride, nb);
+    if (rc != RVIO_OK) return rc;
+    hipLaunchKernelGGL(klt_kernel, dim3(h->dc.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+                       h->t.tracked, h->t.status);
+    rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
+    h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
+    return rc;
+}
+
+int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
+    if (!h || !img || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nc = std::min(n_cand, h->dc.F);
+    HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
+    return rvio_hip_track_dev(h, h->d_img, h->dc.W, h->d_imu, m, h->d_cand, nc);
+}
+
+// direct-track mode: the caller supplies the KLT result
+int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
+                          const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
+    if (!h || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nc = std::min(n_cand, h->dc.F);
+    if (n_pts > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_in_xy, tracked_xy, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_in_st, status, n_pts, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);
+    return post_klt_dev(h, h->d_imu, m, h->d_cand, nc);
+}
+
+int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const DevCfg& d = h->dc;
+    int nf = 0;
+    HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_feat) *n_feat = nf;
+    if (nf > 0) {
+        if (types) HIPCHK(h, hipMemcpyAsync(types, h->t.types, nf, hipMemcpyDeviceToHost, h->stream));
+        if (len) HIPCHK(h, hipMemcpyAsync(len, h->t.len, sizeof(int) * nf, hipMemcpyDeviceToHost, h->stream));
+        if (meas) HIPCHK(h, hipMemcpyAsync(meas, h->t.meas, sizeof(float) * 2 * d.max_len * nf, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const DevCfg& d = h->dc;
+    int np = 0;
+    HIPCHK(h, hipMemcpyAsync(&np, h->t.n_pts, sizeof np, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n) *n = np;
+    if (np > 0) {
+        if (xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.feats, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, h->stream));
+        if (hist_len) {
+            std::vector<int> slot(np), hl(d.F);
+            HIPCHK(h, hipMemcpyAsync(slot.data(), h->t.slot, sizeof(int) * np, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(hl.data(), h->t.hist_len, sizeof(int) * d.F, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (int i = 0; i < np; ++i) hist_len[i] = hl[slot[i]];
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+// ------------------------------------------------------------------ whole frame (System.cc:253-367)
+static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
+    h->img_count++;
+    int rc = propagate_dev(h, d_imu, m);
+    if (rc != RVIO_OK) return rc;
+    if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
+        rc = rvio_hip_update_tracked(h);
+        if (rc != RVIO_OK) return rc;
+    }
+    return augment_compose_dev(h, h->img_count > 1);      // System.cc:280
+}
+int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    int rc = rvio_hip_track_dev(h, d_img, stride, d_imu, m, d_cand, n_cand);
+    if (rc != RVIO_OK) return rc;
+    return frame_tail_dev(h, d_imu, m);
+}
+// direct-track variant of the whole frame (host inputs)
+int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
+                          const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
+    int rc = rvio_hip_track_points(h, tracked_xy, status, n_pts, imu, m, cand_xy, n_cand);
+    if (rc != RVIO_OK) return rc;
+    return frame_tail_dev(h, h->d_imu, m);
+}
+
+int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
+    if (!h || !info) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    FilterMeta m;
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    info->n_clones = m.n_clones; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
+    info->reserved[0] = m.err;
+    return RVIO_OK;
+}
+int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    double buf[8];
+    HIPCHK(h, hipMemcpyAsync(buf, h->d_pose, sizeof buf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (p) for (int i = 0; i < 3; ++i) p[i] = buf[i];
+    if (q) for (int i = 0; i < 4; ++i) q[i] = buf[3 + i];
+    return RVIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Loader + thin ctypes wrapper of librvio_hip.so (the C-ABI of include/rvio_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing, cannot be loaded, or no
+GPU is present, every entry point raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librvio_hip.so")
+
+# every symbol include/rvio_hip.h declares (tests/test_abi.py checks the export list)
+SYMBOLS = [
+    "rvio_config_euroc", "rvio_hip_create", "rvio_hip_destroy", "rvio_hip_last_error", "rvio_hip_abi_version",
+    "rvio_hip_stream", "rvio_hip_sync", "rvio_hip_set_state", "rvio_hip_get_state", "rvio_hip_initialize",
+    "rvio_hip_propagate", "rvio_hip_update", "rvio_hip_augment_compose", "rvio_hip_track", "rvio_hip_track_dev",
+    "rvio_hip_track_points", "rvio_hip_get_tracks", "rvio_hip_get_tracker_points", "rvio_hip_update_tracked",
+    "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
+    "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
+]
+
+_LIB = None
+dp, fp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_ubyte)
+
+
+class RvioHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree HIP library; fail loudly when it is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvioHipError("librvio_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(no CPU fallback exists for the product path)")
+        L = C.CDLL(LIB_PATH)
+        L.rvio_hip_last_error.restype = C.c_char_p
+        L.rvio_hip_last_error.argtypes = [C.c_void_p]
+        L.rvio_hip_stream.restype = C.c_void_p
+        L.rvio_hip_stream.argtypes = [C.c_void_p]
+        L.rvio_hip_destroy.argtypes = [C.c_void_p]
+        L.rvio_hip_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class RvioHip:
+    """One filter instance on one GPU (mirrors the System-owned stage objects, System.h:89-92)."""
+
+    def __init__(self, cfg, device=0):
+        self.L = load()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.L.rvio_hip_create(C.byref(cfg), int(device), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.rvio_hip_last_error(self.h).decode() if self.h else ""
+            if self.h:
+                self.L.rvio_hip_destroy(self.h)
+                self.h = C.c_void_p()
+            raise RvioHipError("rvio_hip_create failed: rc=%d %s" % (rc, msg))
+        self.nmax = cfg.max_track_len - 1
+        self.Fu = abi.fu(cfg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rvio_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RvioHipError("%s failed: rc=%d %s" % (what, rc, self.L.rvio_hip_last_error(self.h).decode()))
+
+    def sync(self):
+        self._ck(self.L.rvio_hip_sync(self.h), "sync")
+
+    def stream(self):
+        return self.L.rvio_hip_stream(self.h)
+
+    # ---- state
+    def set_state(self, x, P):
+        x = np.ascontiguousarray(x, float)
+        Pf = np.asfortranarray(P, dtype=float)
+        self._ck(self.L.rvio_hip_set_state(self.h, _p(x, dp), len(x), Pf.ctypes.data_as(dp), P.shape[0]), "set_state")
+
+    def get_state(self):
+        xb = np.zeros(26 + 7 * (self.nmax + 1))
+        Pb = np.zeros((24 + 6 * (self.nmax + 1)) ** 2)
+        xd, d = C.c_int(0), C.c_int(0)
+        self._ck(self.L.rvio_hip_get_state(self.h, _p(xb, dp), C.byref(xd), _p(Pb, dp), C.byref(d)), "get_state")
+        return xb[: xd.value].copy(), Pb[: d.value ** 2].reshape(d.value, d.value, order="F").copy()
+
+    def initialize(self, w, a, n_imu):
+        w = np.ascontiguousarray(w, float)
+        a = np.ascontiguousarray(a, float)
+        self._ck(self.L.rvio_hip_initialize(self.h, _p(w, dp), _p(a, dp), int(n_imu)), "initialize")
+
+    # ---- stages
+    def propagate(self, imu):
+        imu = np.ascontiguousarray(imu)
+        self._ck(self.L.rvio_hip_propagate(self.h, imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu)), "propagate")
+
+    def update(self, types, lens, meas):
+        tr = abi.make_tracks(types, lens, meas)
+        self._ck(self.L.rvio_hip_update(self.h, C.byref(tr)), "update")
+
+    def update_tracked(self):
+        self._ck(self.L.rvio_hip_update_tracked(self.h), "update_tracked")
+
+    def update_local(self, types, lens, meas, rank, world):
+        """returns (device pointer, n_doubles) of this rank's [A|b] block"""
+        tr = abi.make_tracks(types, lens, meas)
+        ptr, n = dp(), C.c_int(0)
+        self._ck(self.L.rvio_hip_update_local(self.h, C.byref(tr), rank, world, C.byref(ptr), C.byref(n)), "update_local")
+        return C.cast(ptr, C.c_void_p).value, n.value
+
+    def update_global(self, d_blocks_ptr, world):
+        self._ck(self.L.rvio_hip_update_global(self.h, C.c_void_p(d_blocks_ptr), world), "update_global")
+
+    def update_diag(self):
+        nf = C.c_int32(0)
+        acc, gam, ndof, pf = np.zeros(self.Fu, np.int32), np.zeros(self.Fu), np.zeros(self.Fu, np.int32), np.zeros((self.Fu, 3))
+        self._ck(self.L.rvio_hip_get_update_diag(self.h, C.byref(nf), _p(acc, ip), _p(gam, dp), _p(ndof, ip), _p(pf, dp)), "update_diag")
+        n = nf.value
+        return dict(accepted=acc[:n], gamma=gam[:n], ndof=ndof[:n], pfinv=pf[:n])
+
+    def augment_compose(self, do_augment=True):
+        self._ck(self.L.rvio_hip_augment_compose(self.h, int(do_augment)), "augment_compose")
+
+    # ---- front end
+    def track(self, img, imu, cand):
+        img = np.ascontiguousarray(img, np.uint8)
+        imu = np.ascontiguousarray(imu)
+        cand = np.ascontiguousarray(cand, np.float32)
+        self._ck(self.L.rvio_hip_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
+                                       _p(cand, fp), len(cand)), "track")
+
+    def track_points(self, tracked, status, imu, cand):
+        tracked = np.ascontiguousarray(tracked, np.float32)
+        status = np.ascontiguousarray(status, np.uint8)
+        imu = np.ascontiguousarray(imu)
+        cand = np.ascontiguousarray(cand, np.float32)
+        self._ck(self.L.rvio_hip_track_points(self.h, _p(tracked, fp), _p(status, up), len(status),
+                                              imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu), _p(cand, fp), len(cand)), "track_points")
+
+    def frame_points(self, tracked, status, imu, cand):
+        tracked = np.ascontiguousarray(tracked, np.float32)
+        status = np.ascontiguousarray(status, np.uint8)
+        imu = np.ascontiguousarray(imu)
+        cand = np.ascontiguousarray(cand, np.float32)
+        self._ck(self.L.rvio_hip_frame_points(self.h, _p(tracked, fp), _p(status, up), len(status),
+                                              imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu), _p(cand, fp), len(cand)), "frame_points")
+
+    def frame_dev(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand):
+        self._ck(self.L.rvio_hip_frame_dev(self.h, C.c_void_p(d_img_ptr), int(stride), C.c_void_p(d_imu_ptr), int(m),
+                                           C.c_void_p(d_cand_ptr), int(n_cand)), "frame_dev")
+
+    def track_dev(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand):
+        self._ck(self.L.rvio_hip_track_dev(self.h, C.c_void_p(d_img_ptr), int(stride), C.c_void_p(d_imu_ptr), int(m),
+                                           C.c_void_p(d_cand_ptr), int(n_cand)), "track_dev")
+
+    def get_tracks(self):
+        ML = self.cfg.max_track_len
+        types, lens, meas = np.zeros(self.Fu, np.uint8), np.zeros(self.Fu, np.int32), np.zeros((self.Fu, ML, 2), np.float32)
+        n = C.c_int32(0)
+        self._ck(self.L.rvio_hip_get_tracks(self.h, C.byref(n), _p(types, up), _p(lens, ip), _p(meas, fp)), "get_tracks")
+        return types[: n.value].copy(), lens[: n.value].copy(), meas[: n.value].copy()
+
+    def get_points(self):
+        F = self.cfg.n_features
+        xy, hl = np.zeros((F, 2), np.float32), np.zeros(F, np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.rvio_hip_get_tracker_points(self.h, C.byref(n), _p(xy, fp), _p(hl, ip)), "get_tracker_points")
+        return xy[: n.value].copy(), hl[: n.value].copy()
+
+    def frame_info(self):
+        info = abi.rvio_frame_info()
+        self._ck(self.L.rvio_hip_get_frame_info(self.h, C.byref(info)), "get_frame_info")
+        return info.asdict()
+
+    def pose(self):
+        p, q = np.zeros(3), np.zeros(4)
+        self._ck(self.L.rvio_hip_get_pose(self.h, _p(p, dp), _p(q, dp)), "get_pose")
+        return p, q

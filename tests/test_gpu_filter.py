@@ -1,0 +1,129 @@
+"""GPU parity: the HIP filter stages (propagate, update, augment+compose) against the CPU
+oracle on identical inputs, through the C-ABI.  Tolerance: per-state |delta| <= 1e-6 is the
+north-star bar (BASELINE.json); the tests assert 1e-9 on states and 1e-12 + 1e-9*|P| on P."""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+X_TOL = 1e-9
+
+
+def p_close(Pa, Pb):
+    scale = np.max(np.abs(Pb))
+    return float(np.max(np.abs(Pa - Pb))) <= 1e-9 * scale + 1e-15
+
+
+@pytest.fixture(scope="module")
+def recB():
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=30)
+    return cfg, seq, recs
+
+
+@pytest.fixture(scope="module")
+def hipB(gpu_required, recB):
+    from rvio_amd import hip
+    h = hip.RvioHip(recB[0])
+    yield h
+    h.close()
+
+
+def test_set_get_state_roundtrip(hipB, recB):
+    r = recB[2][-1]
+    hipB.set_state(r["x0"], r["P0"])
+    x, P = hipB.get_state()
+    assert np.array_equal(x, r["x0"]) and np.array_equal(P, r["P0"])
+
+
+@pytest.mark.parametrize("fi", [0, 1, 3, 9, 15, 29])
+def test_propagate_parity(hipB, recB, fi):
+    r = recB[2][fi]
+    hipB.set_state(r["x0"], r["P0"])
+    hipB.propagate(r["inp"]["imu"])
+    x, P = hipB.get_state()
+    assert S.state_delta(x, r["x1"]) <= X_TOL
+    assert p_close(P, r["P1"])
+    assert np.allclose(P, P.T, rtol=0, atol=1e-18 + 1e-14 * np.max(np.abs(P)))
+
+
+@pytest.mark.parametrize("fi", [5, 9, 12, 15, 20, 29])
+def test_update_parity(hipB, recB, fi):
+    r = recB[2][fi]
+    assert r["did_update"]
+    hipB.set_state(r["x1"], r["P1"])
+    hipB.update(r["types"], r["lens"], r["meas"])
+    x, P = hipB.get_state()
+    dg = hipB.update_diag()
+    od = r["diag"]
+    assert np.array_equal(dg["accepted"], od["accepted"]), (dg["gamma"], od["gamma"])
+    assert np.array_equal(dg["ndof"][od["accepted"] > 0], od["ndof"][od["accepted"] > 0])
+    assert np.allclose(dg["gamma"], od["gamma"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(dg["pfinv"], od["pfinv"], rtol=1e-8, atol=1e-10)
+    assert S.state_delta(x, r["x2"]) <= X_TOL
+    assert p_close(P, r["P2"])
+
+
+@pytest.mark.parametrize("fi", [0, 1, 2, 5, 12, 20])
+def test_augment_compose_parity(hipB, recB, fi):
+    r = recB[2][fi]
+    hipB.set_state(r["x2"], r["P2"])
+    hipB.augment_compose(r["do_augment"])
+    x, P = hipB.get_state()
+    assert len(x) == len(r["x3"])
+    assert S.state_delta(x, r["x3"]) <= 1e-12
+    assert p_close(P, r["P3"])
+    p, q = hipB.pose()
+    assert np.max(np.abs(p - r["pose_p"])) <= 1e-12
+
+
+def test_update_full_load(hipB, recB):
+    """ceil(F/2)=100 features, half at max track length: the BASELINE '200 feat / 10 clone' load."""
+    cfg, seq, recs = recB
+    r = recs[-1]
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    xo, Po, od = O.update(cfg, r["x1"], r["P1"], types, lens, meas)
+    assert od["n_good"] > 50
+    hipB.set_state(r["x1"], r["P1"])
+    hipB.update(types, lens, meas)
+    x, P = hipB.get_state()
+    dg = hipB.update_diag()
+    assert np.array_equal(dg["accepted"], od["accepted"])
+    assert S.state_delta(x, xo) <= X_TOL
+    assert p_close(P, Po)
+
+
+def test_update_passthrough_when_too_few(hipB, recB):
+    cfg, seq, recs = recB
+    r = recs[-1]
+    types, lens, meas = r["types"][:2], r["lens"][:2], r["meas"][:2]
+    hipB.set_state(r["x1"], r["P1"])
+    hipB.update(types, lens, meas)
+    x, P = hipB.get_state()
+    assert np.array_equal(x, r["x1"]) and np.array_equal(P, r["P1"])
+    assert hipB.frame_info()["updated"] == 0
+
+
+def test_sequence_free_running(hipB, recB):
+    """whole MonoVIO body (direct-track mode) for 30 frames without resets."""
+    cfg, seq, recs = recB
+    from rvio_amd import hip
+    h = hip.RvioHip(cfg)
+    w, a, n = seq.init_from_static(38)
+    h.initialize(w, a, n)
+    worst = 0.0
+    for r in recs:
+        inp = r["inp"]
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        x, P = h.get_state()
+        info = h.frame_info()
+        assert info["n_clones"] == (len(r["x3"]) - 26) // 7
+        worst = max(worst, S.state_delta(x, r["x3"]))
+        pts, hl = h.get_points()
+        assert np.array_equal(pts, r["pts"]) and np.array_equal(hl, r["hist_len"])
+    h.close()
+    assert worst <= 1e-6, worst
