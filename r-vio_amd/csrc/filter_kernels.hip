@@ -46,7 +46,7 @@ __device__ __forceinline__ double phi9_entry(int r, int c, double dt, const m33&
     }
 }
 
-__global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, const FilterMeta* meta, double* x, double* P,
+__global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* meta, double* x, double* P,
                                                         const rvio_imu* imu, int m) {
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, const Filter
     const int tid = threadIdx.x;
     const int n = meta->n_clones;
     const int ld = cfg.dmax;
+    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }   // per-frame update statistics
     for (int e = tid; e < 576; e += 256) {
         int i = e % 24, j = e / 24;
         Pl[i][j] = P[i + (size_t)j * ld];
@@ -560,7 +561,8 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, FilterMeta* 
         Ab[e] = acc;
         const int p = e / ldh, q = e % ldh;
         // every tableau entry of row p is (re)written here: stale values never survive a frame
-        Aug[(size_t)p * lda + q] = (q < c6) ? ((p == q) ? s2 : 0.0) : 0.0;
+        // (slot ldh-1 holds b and is written only by the q == c6 thread: no write race while n < nmax)
+        if (q != ldh - 1) Aug[(size_t)p * lda + q] = (q < c6) ? ((p == q) ? s2 : 0.0) : 0.0;
         Aug[(size_t)p * lda + ldh + q] = (q < c6 && p == q) ? 1.0 : 0.0;
         if (q == c6) Aug[(size_t)p * lda + ldh - 1] = acc;
     }
