@@ -204,6 +204,11 @@ int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world);
 int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma,
                              int32_t* ndof, double* pfinv /* n_feat x 3 */);
 
+/* pyramid level of the most recent image (u8 w*h, int16 (dx,dy) w*h*2) and the raw KLT output
+ * (vFeatsTracked + its undistorted-normalised form) of the last track() call */
+int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy);
+int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy);
+
 #ifdef __cplusplus
 }
 #endif

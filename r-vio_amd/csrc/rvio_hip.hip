@@ -604,3 +604,29 @@ int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ diagnostics for parity tests
+extern "C" {
+// pyramid level `level` of the most recent image: u8 image (w*h) and int16 (dx,dy) derivative (w*h*2)
+int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy) {
+    if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const PyrDev& p = h->pyr[h->pyr_cur];
+    if (w) *w = p.w[level];
+    if (hgt) *hgt = p.h[level];
+    const size_t n = (size_t)p.w[level] * p.h[level];
+    if (img) HIPCHK(h, hipMemcpyAsync(img, p.img[level], n, hipMemcpyDeviceToHost, h->stream));
+    if (dxy) HIPCHK(h, hipMemcpyAsync(dxy, p.dxy[level], n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+// raw vFeatsTracked of the last track() call (n entries = mnFeatsToTrack that entered the call)
+int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
+    if (!h || n < 0 || n > h->dc.F) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    if (n > 0 && un_xy) HIPCHK(h, hipMemcpyAsync(un_xy, h->t.un2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+}

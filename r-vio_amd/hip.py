@@ -20,6 +20,7 @@ SYMBOLS = [
     "rvio_hip_track_points", "rvio_hip_get_tracks", "rvio_hip_get_tracker_points", "rvio_hip_update_tracked",
     "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
+    "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked",
 ]
 
 _LIB = None
@@ -185,6 +186,20 @@ class RvioHip:
         n = C.c_int32(0)
         self._ck(self.L.rvio_hip_get_tracker_points(self.h, C.byref(n), _p(xy, fp), _p(hl, ip)), "get_tracker_points")
         return xy[: n.value].copy(), hl[: n.value].copy()
+
+    def debug_pyramid(self, level):
+        w, hh = C.c_int32(0), C.c_int32(0)
+        self._ck(self.L.rvio_hip_debug_pyramid(self.h, level, C.byref(w), C.byref(hh), None, None), "debug_pyramid")
+        img = np.zeros((hh.value, w.value), np.uint8)
+        dxy = np.zeros((hh.value, w.value, 2), np.int16)
+        self._ck(self.L.rvio_hip_debug_pyramid(self.h, level, C.byref(w), C.byref(hh), _p(img, up),
+                                               dxy.ctypes.data_as(C.POINTER(C.c_int16))), "debug_pyramid")
+        return img, dxy
+
+    def debug_tracked(self, n):
+        xy, un = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32)
+        self._ck(self.L.rvio_hip_debug_tracked(self.h, n, _p(xy, fp), _p(un, fp)), "debug_tracked")
+        return xy, un
 
     def frame_info(self):
         info = abi.rvio_frame_info()

@@ -1,0 +1,113 @@
+"""GPU parity of the visual front end (pyramid, Scharr, KLT, undistort, RANSAC, book-keeping)
+against the CPU oracle on rendered synthetic frames.  Integer/fixed-point + float32 arithmetic
+with order-free sums: the bar is BIT-EXACT positions, flags and track tables."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq = rv.synth.SynthSequence(cfg, duration=8.0)
+    ks = list(range(60, 60 + 14))
+    imgs = [seq.render(k) for k in ks]
+    return cfg, seq, ks, imgs
+
+
+def test_pyramid_and_scharr_bit_exact(gpu_required, frames):
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = frames
+    h = hip.RvioHip(cfg)
+    xy, vis = seq.project(ks[0])
+    cand, _ = seq.candidates(ks[0], xy, vis)
+    h.track(imgs[0], seq.imu_between(ks[0]), cand)
+    ref = imgs[0]
+    for lv in range(4):
+        img, dxy = h.debug_pyramid(lv)
+        assert np.array_equal(img, ref), lv
+        assert np.array_equal(dxy, O.scharr(ref)), lv
+        ref = O.pyr_down(ref)
+    h.close()
+
+
+def test_klt_bit_exact(gpu_required, frames):
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = frames
+    h = hip.RvioHip(cfg)
+    xy, vis = seq.project(ks[0], noise=False)
+    cand, _ = seq.candidates(ks[0], xy, vis)
+    h.track(imgs[0], seq.imu_between(ks[0]), cand)
+    pts0, _ = h.get_points()
+    assert len(pts0) == cfg.n_features
+    h.track(imgs[1], seq.imu_between(ks[1]), cand)
+    got, _ = h.debug_tracked(len(pts0))
+    want, st = O.klt(imgs[0], imgs[1], pts0)
+    assert st.sum() > 150
+    assert np.array_equal(got, want)
+    # border / textureless / far-off points exercise the early-outs
+    h.close()
+
+
+def test_tracker_sequence_bit_exact(gpu_required, frames):
+    """Tracker::track over 14 rendered frames: identical feature lists, histories and update tracks."""
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = frames
+    h = hip.RvioHip(cfg)
+    t = O.Tracker(cfg)
+    n_upd = 0
+    for k, img in zip(ks, imgs):
+        xy, vis = seq.project(k, noise=False)
+        cand, _ = seq.candidates(k, xy, vis)
+        imu = seq.imu_between(k)
+        oi = t.track(img, imu, cand)
+        h.track(img, imu, cand)
+        gi = h.frame_info()
+        for key in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "ransac_winner", "n_tracked_out", "n_feat_update"):
+            assert gi[key] == oi[key], (k, key, gi, oi)
+        pa, ha = h.get_points()
+        pb, hb = t.get_points()
+        assert np.array_equal(pa, pb) and np.array_equal(ha, hb), k
+        ta, la, ma = h.get_tracks()
+        tb, lb, mb = t.get_tracks()
+        assert np.array_equal(ta, tb) and np.array_equal(la, lb), k
+        for f in range(len(la)):
+            assert np.array_equal(ma[f, : la[f]], mb[f, : lb[f]]), (k, f)
+        n_upd += len(la)
+    assert n_upd > 0
+    h.close()
+
+
+def test_whole_frame_with_images(gpu_required, frames):
+    """System::MonoVIO body on images: HIP vs oracle states within 1e-6 over the sequence."""
+    from rvio_amd import hip
+    import scenarios as S
+    cfg, seq, ks, imgs = frames
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    import torch
+    worst = 0.0
+    for k, img in zip(ks, imgs):
+        xy, vis = seq.project(k, noise=False)
+        cand, _ = seq.candidates(k, xy, vis)
+        imu = seq.imu_between(k)
+        s.frame(imu, cand, img=img)
+        d_img = torch.from_numpy(img).cuda()
+        d_imu = torch.from_numpy(imu.view(np.uint8)).cuda()
+        d_cand = torch.from_numpy(cand).cuda()
+        torch.cuda.synchronize()
+        h.frame_dev(d_img.data_ptr(), img.shape[1], d_imu.data_ptr(), len(imu), d_cand.data_ptr(), len(cand))
+        h.sync()
+        xa, Pa = h.get_state()
+        xb, Pb = s.get_state()
+        worst = max(worst, S.state_delta(xa, xb))
+    h.close()
+    assert worst <= 1e-6, worst
