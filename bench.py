@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — camera frames/s of the MI355X-native R-VIO hot path (BASELINE.json metric).
+
+A "step" is one pass of the per-frame hot path (System::MonoVIO timed body, System.cc:253-367:
+KLT track + RANSAC + book-keeping -> IMU propagate -> MSCKF update -> augment/compose) over one
+synthetic EuRoC-shaped 752x480 frame with its ~10 IMU samples and its detector corner list, all
+resident in HBM before the timed region.  N=1 workload = BASELINE.json configs[1] (cfg B: 200
+features, 10-clone window).  N>1: the feature-sharded updater — every rank runs the
+replicated front end + propagate, builds the Jacobians / nullspace / gate / compression of its
+feature shard, and the per-rank information blocks [A|b] are exchanged with ONE all-gather (RCCL)
+per frame; the same frames are processed by the whole group => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from pkgload import load_pkg  # noqa: E402
+
+rv = load_pkg()
+abi, synth = rv.abi, rv.synth
+
+K0 = 38  # last stationary frame of the synthetic sequence (t = 1.9 s)
+
+
+def build_inputs(cfg, n_frames, seed=0):
+    """Render the sequence on the host (untimed): frames, IMU batches, detector corner lists."""
+    seq = synth.SynthSequence(cfg, duration=(K0 + n_frames + 3) / 20.0, seed=seed)
+    F = cfg.n_features
+    imgs = np.zeros((n_frames, cfg.height, cfg.width), np.uint8)
+    imus, cands = [], []
+    mmax = 0
+    for i in range(n_frames):
+        k = K0 + 1 + i
+        imgs[i] = seq.render(k)
+        xy, vis = seq.project(k, noise=False)
+        cand, _ = seq.candidates(k, xy, vis)
+        imu = seq.imu_between(k)
+        imus.append(imu)
+        cands.append(cand)
+        mmax = max(mmax, len(imu))
+    imu_arr = np.zeros((n_frames, mmax), dtype=abi.IMU_DTYPE)
+    imu_cnt = np.zeros(n_frames, np.int32)
+    cand_arr = np.zeros((n_frames, F, 2), np.float32)
+    cand_cnt = np.zeros(n_frames, np.int32)
+    for i in range(n_frames):
+        imu_arr[i, : len(imus[i])] = imus[i]
+        imu_cnt[i] = len(imus[i])
+        cand_arr[i, : len(cands[i])] = cands[i]
+        cand_cnt[i] = len(cands[i])
+    return seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt
+
+
+class DeviceArray:
+    """__cuda_array_interface__ view of a raw device pointer (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="B", choices=list(abi.BASELINE_CONFIGS))
+    ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the same sequence timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rvio_amd import hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = abi.config_named(args.config, enable_equalizer=0)
+    K, W = args.steps, args.warmup
+    n_frames = 1 + W + K   # first image (seed) + warmup + timed
+    seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt = build_inputs(cfg, n_frames)
+
+    h = hip.RvioHip(cfg, device=local_rank)
+    stream = torch.cuda.ExternalStream(h.stream(), device=torch.device("cuda", local_rank))
+    d_imgs = torch.from_numpy(imgs).cuda()
+    d_imu = torch.from_numpy(imu_arr.view(np.uint8).reshape(n_frames, -1)).cuda()
+    d_cand = torch.from_numpy(cand_arr).cuda()
+    torch.cuda.synchronize()
+    img_stride_b = cfg.width * cfg.height
+    imu_stride_b = d_imu.shape[1]
+    cand_stride_b = cfg.n_features * 2 * 4
+    p_img, p_imu, p_cand = d_imgs.data_ptr(), d_imu.data_ptr(), d_cand.data_ptr()
+
+    wi, ai, ni = seq.init_from_static(K0)
+    h.initialize(wi, ai, ni)
+
+    gathered = None
+    if world > 1:
+        nblk = (6 * (cfg.max_track_len - 1) + 1) ** 2
+        gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda")
+
+    def frame(i):
+        if world == 1:
+            h.frame_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
+        else:
+            h.track_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
+            h.frame_tail_sharded(p_imu + i * imu_stride_b, int(imu_cnt[i]), rank, world, gathered, dist, DeviceArray, torch)
+
+    for i in range(1 + W):
+        frame(i)
+    h.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record()
+    for i in range(1 + W, n_frames):
+        frame(i)
+    with torch.cuda.stream(stream):
+        ev1.record()
+    h.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gpu_ms = ev0.elapsed_time(ev1)
+    info = h.frame_info()
+    x_gpu, P_gpu = h.get_state()
+
+    out = {
+        "metric": "camera frames/sec (KLT+RANSAC track, IMU propagate, MSCKF update, augment/compose), 200 feat / 10-clone window",
+        "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f64 (filter) / u8+i32+f32 (KLT)", "data": "synthetic",
+        "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer off"
+                               % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1),
+                   "parallelism": "1 process/GPU; feature-sharded updater + 1 all-gather/frame" if world > 1 else "single GPU"},
+        "gpu_ms_per_step_events": gpu_ms / K,
+        "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_latency:
+            out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
+                                    img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni))
+        if not args.no_cpu:
+            out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
+            if xs_cpu is not None and "x_at_cpu_frames" in out:
+                out["max_state_delta_vs_cpu"] = float(np.max(np.abs(_qfix(out.pop("x_at_cpu_frames")) - _qfix(xs_cpu))))
+        out.pop("x_at_cpu_frames", None)
+    h.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _qfix(x):
+    x = np.array(x, float)
+    for i in [0, 10] + list(range(26, len(x), 7)):
+        if x[i + 3] < 0:
+            x[i:i + 4] *= -1
+    return x
+
+
+def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, k0, wi, ai, ni):
+    """Second, untimed-for-throughput pass on a fresh handle: per-stage device latencies with HIP events on the
+    handle's stream (p50 EKF-update ms of the metric), the dominant kernel's roofline, and the state after
+    `cpu_frames` frames for the parity figure."""
+    from rvio_amd import hip
+    h = hip.RvioHip(cfg)
+    st = torch.cuda.ExternalStream(h.stream())
+    h.initialize(wi, ai, ni)
+    n = len(imgs)
+    L = h.L
+    import ctypes as C
+    names = ["track", "propagate", "update", "augment_compose"]
+    lat = {k: [] for k in names}
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    x_at = None
+    ncpu = min(120, n)
+    for i in range(n):
+        m, nc = int(imu_cnt[i]), int(cand_cnt[i])
+        with torch.cuda.stream(st):
+            evs[0].record()
+        h.track_dev(p_img + i * isb, cfg.width, p_imu + i * msb, m, p_cand + i * csb, nc)
+        with torch.cuda.stream(st):
+            evs[1].record()
+        did_update = h.frame_tail_staged(p_imu + i * msb, m, evs, st, torch)
+        h.sync()
+        if i > 20:
+            lat["track"].append(evs[0].elapsed_time(evs[1]))
+            lat["propagate"].append(evs[1].elapsed_time(evs[2]))
+            if did_update:
+                lat["update"].append(evs[2].elapsed_time(evs[3]))
+            lat["augment_compose"].append(evs[3].elapsed_time(evs[4]))
+        if i == ncpu - 1:
+            x_at, _ = h.get_state()
+    res = {"latency_ms_p50": {k: float(np.median(v)) for k, v in lat.items() if v},
+           "latency_ms_p95": {k: float(np.percentile(v, 95)) for k, v in lat.items() if v},
+           "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
+           "x_at_cpu_frames": x_at}
+    # ---- roofline of the dominant kernel (klt_kernel, HBM/L2 bound): algorithmic bytes per launch
+    # B_klt = per tracked feature, per level: 16x16 template (u8 + 2 x int16 gradient)
+    # + 16x16 search-window read per iteration.  Measured here: the track stage's device time per launch.
+    F = cfg.n_features
+    it_l = 10
+    alg_bytes = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16
+    t_track = np.median(lat["track"]) * 1e-3
+    res["roofline"] = {"bound": "hbm", "kernel": "track stage (pyr_down x3 + scharr x4 + klt_kernel + ransac + bookkeep)",
+                       "achieved": (alg_bytes + cfg.width * cfg.height * 1.656) / t_track / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": (alg_bytes + cfg.width * cfg.height * 1.656) / t_track / 1e9 / 8000.0, "traffic": None,
+                       "note": "single 752x480 stream is launch/latency bound (SURVEY.md 8d): 3.67 MB algorithmic per frame"}
+    h.close()
+    return res
+
+
+def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):
+    """The CPU oracle (oracle/liborc.so, -O3, 1 core) on the first n frames of the same sequence."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, wi, ai, ni)
+    s.set_state(x0, P0)
+    tms = []
+    t0 = time.perf_counter()
+    for i in range(n):
+        info, t, pp, pq = s.frame(imu_arr[i, : imu_cnt[i]], cand_arr[i, : cand_cnt[i]], img=imgs[i])
+        tms.append(t)
+    el = time.perf_counter() - t0
+    tms = np.array(tms)[20:]
+    xs, _ = s.get_state()
+    return ({"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
+             "sample": "first %d frames of the same synthetic sequence, oracle/liborc.so (g++ -O3, single thread); "
+                       "p50 ms: track %.3f propagate %.3f update %.3f augment+compose %.3f"
+                       % (n, *np.median(tms, axis=0))}, xs)
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,12 @@ int rvio_hip_update_tracked(rvio_hip* h);
  * enqueued on the handle's stream with no host synchronisation. */
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
                        const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+/* For callers that sequence the frame themselves (per-stage timing, the sharded updater):
+ * frame_plan advances nImageCountAfterInit and reports MonoVIO's two data-independent
+ * branches (System.cc:266 `nCloneStates > mnMinCloneStates`, System.cc:280
+ * `nImageCountAfterInit > 1`); propagate_dev is rvio_hip_propagate on device-resident IMU. */
+int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment);
+int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m);
 /* same, direct-track mode, host inputs */
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand);

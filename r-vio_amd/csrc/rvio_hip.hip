@@ -558,6 +558,21 @@ int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* his
 }
 
 // ------------------------------------------------------------------ whole frame (System.cc:253-367)
+// Pieces for callers that sequence the frame themselves (staged timing, sharded updater):
+// frame_plan advances nImageCountAfterInit and reports MonoVIO's two data-independent branches.
+int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment) {
+    if (!h) return RVIO_ERR_INVALID;
+    h->img_count++;
+    if (do_update) *do_update = (h->n_clones_host > h->cfg.min_track_len - 1) ? 1 : 0;   // System.cc:266
+    if (do_augment) *do_augment = (h->img_count > 1) ? 1 : 0;                            // System.cc:280
+    return RVIO_OK;
+}
+int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
+    if (!h || !d_imu || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return propagate_dev(h, d_imu, m);
+}
+
 static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
     h->img_count++;
     int rc = propagate_dev(h, d_imu, m);

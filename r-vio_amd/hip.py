@@ -20,7 +20,7 @@ SYMBOLS = [
     "rvio_hip_track_points", "rvio_hip_get_tracks", "rvio_hip_get_tracker_points", "rvio_hip_update_tracked",
     "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
-    "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked",
+    "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
 ]
 
 _LIB = None
@@ -172,6 +172,48 @@ class RvioHip:
     def track_dev(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand):
         self._ck(self.L.rvio_hip_track_dev(self.h, C.c_void_p(d_img_ptr), int(stride), C.c_void_p(d_imu_ptr), int(m),
                                            C.c_void_p(d_cand_ptr), int(n_cand)), "track_dev")
+
+    def frame_plan(self):
+        du, da = C.c_int(0), C.c_int(0)
+        self._ck(self.L.rvio_hip_frame_plan(self.h, C.byref(du), C.byref(da)), "frame_plan")
+        return bool(du.value), bool(da.value)
+
+    def propagate_dev(self, d_imu_ptr, m):
+        self._ck(self.L.rvio_hip_propagate_dev(self.h, C.c_void_p(d_imu_ptr), int(m)), "propagate_dev")
+
+    def update_local_tracked(self, rank, world):
+        """stage A of the sharded updater on the tracker's device-resident tracks"""
+        ptr, n = dp(), C.c_int(0)
+        self._ck(self.L.rvio_hip_update_local(self.h, None, rank, world, C.byref(ptr), C.byref(n)), "update_local")
+        return C.cast(ptr, C.c_void_p).value, n.value
+
+    def frame_tail_staged(self, d_imu_ptr, m, evs, stream, torch):
+        """propagate -> [update] -> augment/compose with events evs[2..4] recorded between the stages"""
+        do_update, do_augment = self.frame_plan()
+        self.propagate_dev(d_imu_ptr, m)
+        with torch.cuda.stream(stream):
+            evs[2].record()
+        if do_update:
+            self.update_tracked()
+        with torch.cuda.stream(stream):
+            evs[3].record()
+        self.augment_compose(do_augment)
+        with torch.cuda.stream(stream):
+            evs[4].record()
+        return do_update
+
+    def frame_tail_sharded(self, d_imu_ptr, m, rank, world, gathered, dist, DeviceArray, torch):
+        """Feature-sharded frame tail: local [A|b] block -> ONE all-gather -> replicated EKF update."""
+        do_update, do_augment = self.frame_plan()
+        self.propagate_dev(d_imu_ptr, m)
+        if do_update:
+            ptr, n = self.update_local_tracked(rank, world)
+            self.sync()                                   # block ready (handle stream) before the collective's stream reads it
+            local = torch.as_tensor(DeviceArray(ptr, n), device="cuda")
+            dist.all_gather_into_tensor(gathered, local)
+            torch.cuda.current_stream().synchronize()     # gathered blocks visible before the handle stream consumes them
+            self.update_global(gathered.data_ptr(), world)
+        self.augment_compose(do_augment)
 
     def get_tracks(self):
         ML = self.cfg.max_track_len

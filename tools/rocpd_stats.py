@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max (us).
+usage: tools/rocpd_stats.py results.db [out.md]"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+rows = cur.execute("select %s, start, end from kernels" % name_col).fetchall()
+agg = {}
+for name, s, e in rows:
+    name = re.sub(r"\(.*", "", name)
+    a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
+    d = (e - s) / 1e3
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+tot = sum(a[1] for a in agg.values())
+lines = ["| kernel | calls | total us | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append("| %s | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % (name, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / tot))
+txt = "\n".join(lines)
+print(txt)
+if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(txt + "\n")
