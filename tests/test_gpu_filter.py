@@ -127,3 +127,38 @@ def test_sequence_free_running(hipB, recB):
         assert np.array_equal(pts, r["pts"]) and np.array_equal(hl, r["hist_len"])
     h.close()
     assert worst <= 1e-6, worst
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_updater_fake_shards_on_one_gpu(hipB, recB, world):
+    """SURVEY.md 8e 'fake shard' mode: the `world` shards run one after the other on one GPU, their [A|b]
+    blocks are concatenated (what the all-gather would deliver) and the global stage is applied."""
+    import torch
+    cfg, seq, recs = recB
+    r = recs[-1]
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    xo, Po, od = O.update(cfg, r["x1"], r["P1"], types, lens, meas)
+    hipB.set_state(r["x1"], r["P1"])
+
+    class DA:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    blocks = []
+    for rk in range(world):
+        ptr, n = hipB.update_local(types, lens, meas, rk, world)
+        hipB.sync()
+        blocks.append(torch.as_tensor(DA(ptr, n), device="cuda").clone())
+    allb = torch.cat(blocks).contiguous()
+    torch.cuda.synchronize()
+    # block of rank k equals the oracle's block (information form is order-insensitive up to rounding)
+    nb = blocks[0].numel()
+    ob = O.update_local(cfg, r["x1"], r["P1"], types, lens, meas, 1, world)
+    gb = blocks[1].cpu().numpy()
+    ldh = 6 * (cfg.max_track_len - 1) + 1
+    assert nb == ldh * ldh
+    assert np.allclose(gb[: ldh * (ldh - 1)], ob[: ldh * (ldh - 1)], rtol=1e-9, atol=1e-9 * np.max(np.abs(ob)))
+    assert gb[ldh * (ldh - 1)] == ob[-2] and gb[ldh * (ldh - 1) + 1] == ob[-1]
+    hipB.update_global(allb.data_ptr(), world)
+    x, P = hipB.get_state()
+    assert S.state_delta(x, xo) <= X_TOL
+    assert p_close(P, Po)

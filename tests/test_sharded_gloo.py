@@ -1,0 +1,68 @@
+"""N>1 path on CPU: world_size-2 (and 4) gloo groups run the feature-sharded updater protocol
+ — rank r builds the information block [A|b] of features f % world == r, ONE all-gather
+exchanges the blocks, every rank runs the identical global stage.  The compute legs here are the CPU
+oracle's mirrors of rvio_hip_update_local/_global (tests only); what is under test is the protocol:
+partition, payload layout, gather order, replica determinism."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    import scenarios as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=30)
+    r = recs[-1]
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    blk = torch.from_numpy(O.update_local(cfg, r["x1"], r["P1"], types, lens, meas, rank, world))
+    gathered = [torch.zeros_like(blk) for _ in range(world)]
+    dist.all_gather(gathered, blk)                       # the ONE collective of the frame
+    blocks = np.stack([g.numpy() for g in gathered])
+    x, P, info = O.update_global(cfg, r["x1"], r["P1"], blocks)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, P=P, good=info["n_good"], rows=info["n_rows"], own=blk.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_update_gloo(world, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    import scenarios as S
+    cfg = O.abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=30)
+    r = recs[-1]
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    xo, Po, d = O.update(cfg, r["x1"], r["P1"], types, lens, meas)        # unsharded reference-form update
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    for k in range(1, world):                                                # replicas are bit-identical
+        assert np.array_equal(res[0]["x"], res[k]["x"]) and np.array_equal(res[0]["P"], res[k]["P"])
+    assert int(res[0]["good"]) == d["n_good"] and int(res[0]["rows"]) == d["n_rows"]
+    assert S.state_delta(res[0]["x"], xo) < 1e-9
+    assert np.max(np.abs(res[0]["P"] - Po)) < 1e-9 * np.max(np.abs(Po))
+    # every feature is owned by exactly one rank: per-rank accepted counts add up
+    assert sum(int(res[k]["own"][-2]) for k in range(world)) == d["n_good"]
