@@ -3,14 +3,20 @@
 //
 //   propagate_kernel     PreIntegrator::propagate          PreIntegrator.cc:51-194
 //   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455
-//   gram_kernel/gram_reduce_kernel   measurement compression (Updater.cc:469-536)
-//                        in information form [A|b] = Hw^T [Hw | r]   
-//   gemm_f64_kernel      FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM used for
-//                        every dense covariance product of Updater.cc:540-619
-//   gj_kernel            (sigma^2 I + A Pcc)^-1 by Gauss-Jordan with partial pivoting
-//   inject_kernel        state injection                   Updater.cc:546-613
-//   symm_out_kernel      P = .5 (P + P^T)                  Updater.cc:619
-//   augment_kernel / compose_kernel   System.cc:279-365
+//   gram_kernel / gram_reduce_kernel / block_sum_kernel
+//                        measurement compression (Updater.cc:469-536) in information
+//                        form [A|b] = Hw^T [Hw | r]   
+//   gemm_f64_kernel      FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
+//   solve_kernel         W = T^-1, y = W b by Gauss-Jordan (partial pivoting, one barrier
+//                        per column), then dx = Pc y and state injection  (Updater.cc:540-613)
+//   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG)
+//   final_kernel         P+ = sym( P1 - P1c G^T + s2 G U^T )   (Joseph form, Updater.cc:615-619)
+//   augcomp_kernel       augmentation/slide + composition, fused  (System.cc:279-365)
+//
+// Design rules learnt from the first profile (profiles/r01_a): every kernel front-loads its
+// global reads in one batch (a dependent global load after a kernel boundary costs 1-2 us),
+// n_clones is a kernel argument (data-independent, mirrored on the host), wave reductions use
+// DPP, serial chains are hoisted out of barrier-separated loops.
 #include "rvio_dev.h"
 #include "../../include/rvio_hip.h"
 
@@ -18,125 +24,155 @@ __device__ const double kChi2Dev[500] = {
 #include "chi2_table.inc"
 };
 
-// =============================================================== P1 propagate
-// One workgroup, 256 threads.  Only rows 9..17 of Phi = I + dt F differ from the
-// identity (PreIntegrator.cc:123-132), so Phi P Phi^T touches 9 rows then 9
-// columns of the 24x24 IMU block; the scalar state integration is evaluated
-// redundantly by every lane (uniform control flow, no broadcasts).
-__device__ __forceinline__ double phi9_entry(int r, int c, double dt, const m33& wx, const m33& RkTvx, const m33& RkT,
-                                             const m33& Rk, const m33& gx, const m33& vx, double nG) {
-    const int br = r / 3, i = r % 3, bc = c / 3, j = c % 3;
-    const double id = (i == j) ? 1.0 : 0.0;
-    if (br == 0) {          // theta_k rows (F rows 9..11)
-        if (bc == 3) return id - dt * wx.m[3 * i + j];
-        if (bc == 6) return -dt * id;
-        return 0.0;
-    } else if (br == 1) {   // p_k rows (12..14)
-        if (bc == 3) return -dt * RkTvx.m[3 * i + j];
-        if (bc == 4) return id;
-        if (bc == 5) return dt * RkT.m[3 * i + j];
-        return 0.0;
-    } else {                // v rows (15..17)
-        if (bc == 2) return -dt * nG * Rk.m[3 * i + j];
-        if (bc == 3) return -dt * nG * gx.m[3 * i + j];
-        if (bc == 5) return id - dt * wx.m[3 * i + j];
-        if (bc == 6) return -dt * vx.m[3 * i + j];
-        if (bc == 7) return -dt * id;
-        return 0.0;
-    }
-}
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* meta, double* x, double* P,
+// =============================================================== P1 propagate
+// One workgroup, 256 threads.
+//  phase A  lane s <-> IMU sample s: everything that depends on the sample alone (trig, dR, f1..f4)
+//  phase B  the short serial chain Rk <- dR Rk, dp, dv, pk, vk, gk (reference order)
+//  phase C  Phi rows 9..17 (the only non-identity rows of Phi = I + dt F, PreIntegrator.cc:123-132)
+//           for all samples at once
+//  phase D  per sample: rows 9..17 of (Phi P), Psi <- Phi Psi, columns 9..17 of (Phi P) Phi^T + Q
+#define PROP_CH 16
+struct PropSample {      // per-sample scratch in LDS
+    double dR[9], up[3], uv[3], w[3], dt, Dt, small;
+    double Rk[9], vk[3], gk[3];   // PRE-step values used by F (PreIntegrator.cc:123-131)
+};
+
+__global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* meta, int n, double* x, double* P,
                                                         const rvio_imu* imu, int m) {
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
-    __shared__ double Phi9[9][25];
+    __shared__ double Phi9[PROP_CH][9][25];
+    __shared__ double vxs[PROP_CH][9];
+    __shared__ PropSample sm[PROP_CH];
+    __shared__ double xs[26];
     const int tid = threadIdx.x;
-    const int n = meta->n_clones;
     const int ld = cfg.dmax;
-    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }   // per-frame update statistics
+    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }
     for (int e = tid; e < 576; e += 256) {
         int i = e % 24, j = e / 24;
         Pl[i][j] = P[i + (size_t)j * ld];
         Psi[i][j] = (i == j) ? 1.0 : 0.0;
     }
-    d3 gk = ld3(x + 7);
-    const q4 qk0 = ldq(x + 10);
-    d3 pk = ld3(x + 14), vk = ld3(x + 17);
-    const d3 bg = ld3(x + 20), ba = ld3(x + 23);
-    const d3 gR = gk, vR = vk;
-    m33 Rk = q2r(qk0), RkT = tr33(Rk);
+    if (tid < 26) xs[tid] = x[tid];
+    __syncthreads();
+    const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
+    const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
+    m33 Rk = q2r(ldq(xs + 10)), RkT = tr33(Rk);
+    d3 pk = ld3(xs + 14), vk = vR, gk = gR;
     d3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
     const m33 I = eye33();
     const double nG = cfg.gravity;
     double Dt = 0;
     const int r9 = tid / 24, c9 = tid % 24;  // valid for tid < 216
-    __syncthreads();
-    for (int s = 0; s < m; ++s) {
-        const d3 wm = mk3(imu[s].w[0], imu[s].w[1], imu[s].w[2]);
-        const d3 am = mk3(imu[s].a[0], imu[s].a[1], imu[s].a[2]);
-        const double dt = imu[s].dt;
-        Dt += dt;
-        const d3 w = sub3(wm, bg), a = sub3(am, ba);
-        const double w1 = nrm3(w);
-        const bool small = w1 < cfg.small_angle;
-        const double wdt = w1 * dt, wdt2 = wdt * wdt;
-        const double cw = cos(wdt), sw = sin(wdt);
-        const m33 wx = skew33(w), wx2 = mul33(wx, wx), vx = skew33(vk);
-        const m33 RkTvx = mul33(RkT, vx), gx = skew33(gk);
-        if (tid < 216) Phi9[r9][c9] = phi9_entry(r9, c9, dt, wx, RkTvx, RkT, Rk, gx, vx, nG);
-        __syncthreads();
-        double accP = 0, accS = 0;
-        if (tid < 216) {
-#pragma unroll 8
-            for (int k = 0; k < 24; ++k) { double f = Phi9[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
-        }
-        __syncthreads();
-        if (tid < 216) { Pl[9 + r9][c9] = accP; Psi[9 + r9][c9] = accS; }
-        __syncthreads();
-        // P' = (Phi P) Phi^T: only columns 9..17 change; thread (i = c9, r = r9) -> P'[i][9+r]
-        double accC = 0;
-        if (tid < 216) {
-#pragma unroll 8
-            for (int k = 0; k < 24; ++k) accC += Pl[c9][k] * Phi9[r9][k];
-            // Q = dt G Sigma G^T  (PreIntegrator.cc:135-140), nonzero blocks only
-            const int i = c9, j = 9 + r9;
-            const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
-            if (bi == 3 && bj == 3) accC += (ii == jj) ? dt * cfg.sg2 : 0.0;
-            else if (bi == 3 && bj == 5) accC += dt * cfg.sg2 * vx.m[3 * jj + ii];
-            else if (bi == 5 && bj == 3) accC += dt * cfg.sg2 * vx.m[3 * ii + jj];
-            else if (bi == 5 && bj == 5) {
-                double q = ((dt * vx.m[3 * ii]) * cfg.sg2) * vx.m[3 * jj] + ((dt * vx.m[3 * ii + 1]) * cfg.sg2) * vx.m[3 * jj + 1] +
-                           ((dt * vx.m[3 * ii + 2]) * cfg.sg2) * vx.m[3 * jj + 2];
-                if (ii == jj) q += dt * cfg.sa2;
-                accC += q;
+    for (int s0 = 0; s0 < m; s0 += PROP_CH) {
+        const int mc = (m - s0 < PROP_CH) ? (m - s0) : PROP_CH;
+        // ---- phase A
+        if (tid < mc) {
+            const rvio_imu u = imu[s0 + tid];
+            const d3 w = sub3(mk3(u.w[0], u.w[1], u.w[2]), bg), a = sub3(mk3(u.a[0], u.a[1], u.a[2]), ba);
+            const double dt = u.dt, w1 = nrm3(w);
+            const bool small = w1 < cfg.small_angle;
+            const double wdt = w1 * dt, wdt2 = wdt * wdt;
+            const double cw = cos(wdt), sw = sin(wdt);
+            const m33 wx = skew33(w), wx2 = mul33(wx, wx);
+            m33 dR; double f1, f2, f3, f4;
+            if (small) {
+                dR = add33(sub33(I, scl33(dt, wx)), scl33(dt * dt / 2, wx2));
+                f1 = -(dt * dt * dt) / 3; f2 = (dt * dt * dt * dt) / 8; f3 = -(dt * dt) / 2; f4 = (dt * dt * dt) / 6;
+            } else {
+                const double w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
+                dR = add33(sub33(I, scl33(sw / w1, wx)), scl33((1 - cw) / w2, wx2));
+                f1 = (wdt * cw - sw) / w3;
+                f2 = .5 * (wdt2 - 2 * cw - 2 * wdt * sw + 2) / w4;
+                f3 = (cw - 1) / w2;
+                f4 = (wdt - sw) / w3;
             }
+            PropSample& q = sm[tid];
+            for (int k = 0; k < 9; ++k) q.dR[k] = dR.m[k];
+            st3(q.up, mv33(add33(add33(scl33(.5 * dt * dt, I), scl33(f1, wx)), scl33(f2, wx2)), a));
+            st3(q.uv, mv33(add33(add33(scl33(dt, I), scl33(f3, wx)), scl33(f4, wx2)), a));
+            st3(q.w, w); q.dt = dt;
         }
         __syncthreads();
-        if (tid < 216) Pl[c9][9 + r9] = accC;
-        if (tid >= 216 && tid < 219) Pl[18 + tid - 216][18 + tid - 216] += dt * cfg.swg2;
-        if (tid >= 219 && tid < 222) Pl[21 + tid - 219][21 + tid - 219] += dt * cfg.swa2;
-        // state (PreIntegrator.cc:145-178)
-        m33 dR; double f1, f2, f3, f4;
-        if (small) {
-            dR = add33(sub33(I, scl33(dt, wx)), scl33(dt * dt / 2, wx2));
-            f1 = -(dt * dt * dt) / 3; f2 = (dt * dt * dt * dt) / 8; f3 = -(dt * dt) / 2; f4 = (dt * dt * dt) / 6;
-        } else {
-            const double w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
-            dR = add33(sub33(I, scl33(sw / w1, wx)), scl33((1 - cw) / w2, wx2));
-            f1 = (wdt * cw - sw) / w3;
-            f2 = .5 * (wdt2 - 2 * cw - 2 * wdt * sw + 2) / w4;
-            f3 = (cw - 1) / w2;
-            f4 = (wdt - sw) / w3;
+        // ---- phase B (every thread runs the same short chain: no broadcast needed)
+        for (int s = 0; s < mc; ++s) {
+            PropSample& q = sm[s];
+            if (tid == 0) { for (int k = 0; k < 9; ++k) q.Rk[k] = Rk.m[k]; st3(q.vk, vk); st3(q.gk, gk); }
+            const double dt = q.dt;
+            Dt += dt;
+            Rk = mul33(ldm33(q.dR), Rk); RkT = tr33(Rk);
+            dp = add3(dp, scl3(dt, dv));
+            dp = add3(dp, mv33(RkT, ld3(q.up)));
+            dv = add3(dv, mv33(RkT, ld3(q.uv)));
+            pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
+            vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
+            gk = unit3(mv33(Rk, gR));
         }
-        Rk = mul33(dR, Rk); RkT = tr33(Rk);
-        dp = add3(dp, scl3(dt, dv));
-        dp = add3(dp, mv33(mul33(RkT, add33(add33(scl33(.5 * dt * dt, I), scl33(f1, wx)), scl33(f2, wx2))), a));
-        dv = add3(dv, mv33(mul33(RkT, add33(add33(scl33(dt, I), scl33(f3, wx)), scl33(f4, wx2))), a));
-        pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
-        vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
-        gk = unit3(mv33(Rk, gR));
         __syncthreads();
+        // ---- phase C: Phi9[s][r][c] for all samples of the chunk
+        for (int e = tid; e < mc * 216; e += 256) {
+            const int s = e / 216, rc = e % 216, r = rc / 24, c = rc % 24;
+            const PropSample& q = sm[s];
+            const int br = r / 3, i = r % 3, bc = c / 3, j = c % 3;
+            const double id = (i == j) ? 1.0 : 0.0, dt = q.dt;
+            double v = 0.0;
+            if (br == 0) {            // theta_k rows
+                if (bc == 3) v = id - dt * skew33(ld3(q.w)).m[3 * i + j];
+                else if (bc == 6) v = -dt * id;
+            } else if (br == 1) {     // p_k rows:  -Rk^T [v]x | I | Rk^T
+                if (bc == 3) {
+                    const m33 vx = skew33(ld3(q.vk));
+                    v = -dt * (q.Rk[i] * vx.m[j] + q.Rk[3 + i] * vx.m[3 + j] + q.Rk[6 + i] * vx.m[6 + j]);
+                } else if (bc == 4) v = id;
+                else if (bc == 5) v = dt * q.Rk[3 * j + i];
+            } else {                  // v rows
+                if (bc == 2) v = -dt * nG * q.Rk[3 * i + j];
+                else if (bc == 3) v = -dt * nG * skew33(ld3(q.gk)).m[3 * i + j];
+                else if (bc == 5) v = id - dt * skew33(ld3(q.w)).m[3 * i + j];
+                else if (bc == 6) v = -dt * skew33(ld3(q.vk)).m[3 * i + j];
+                else if (bc == 7) v = -dt * id;
+            }
+            Phi9[s][r][c] = v;
+            if (rc < 9) vxs[s][rc] = skew33(ld3(q.vk)).m[rc];
+        }
+        __syncthreads();
+        // ---- phase D
+        for (int s = 0; s < mc; ++s) {
+            const double dt = sm[s].dt;
+            double accP = 0, accS = 0;
+            if (tid < 216) {
+#pragma unroll 8
+                for (int k = 0; k < 24; ++k) { const double f = Phi9[s][r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
+            }
+            __syncthreads();
+            if (tid < 216) { Pl[9 + r9][c9] = accP; Psi[9 + r9][c9] = accS; }
+            __syncthreads();
+            double accC = 0;
+            if (tid < 216) {
+#pragma unroll 8
+                for (int k = 0; k < 24; ++k) accC += Pl[c9][k] * Phi9[s][r9][k];
+                // Q = dt G Sigma G^T (PreIntegrator.cc:135-140), non-zero blocks only
+                const int i = c9, j = 9 + r9;
+                const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
+                const double* vx = vxs[s];
+                if (bi == 3 && bj == 3) accC += (ii == jj) ? dt * cfg.sg2 : 0.0;
+                else if (bi == 3 && bj == 5) accC += dt * cfg.sg2 * vx[3 * jj + ii];
+                else if (bi == 5 && bj == 3) accC += dt * cfg.sg2 * vx[3 * ii + jj];
+                else if (bi == 5 && bj == 5) {
+                    double q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] +
+                               ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
+                    if (ii == jj) q += dt * cfg.sa2;
+                    accC += q;
+                }
+            }
+            __syncthreads();
+            if (tid < 216) Pl[c9][9 + r9] = accC;
+            if (tid >= 216 && tid < 219) Pl[18 + tid - 216][18 + tid - 216] += dt * cfg.swg2;
+            if (tid >= 219 && tid < 222) Pl[21 + tid - 219][21 + tid - 219] += dt * cfg.swa2;
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         stq(x + 10, r2q(Rk));
@@ -166,40 +202,29 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
 
 // =============================================================== U1..U5 per feature
 // One workgroup per feature slot.  Dynamic LDS (doubles):
-//   pose[(L-1)*24]  RI(9) tI(3) Rc(9) tc(3) per track phase
-//   hrr[L*6] hf[2L*3] lr[(L-1)*18] vh[3*2L] misc[16]
-//   Hx[2L][ldh]   ([Hx | r], row-major)   Tm[rho][ldh]   S[(rho+1)][rho+1]
-struct FeatLds {
-    double *pose, *hrr, *hf, *lr, *vh, *misc, *Hx, *Tm, *S;
-};
+//   xcl[7*nmax] pose[(L-1)*24] hrr[L*6] hf[2L*3] lr[(L-1)*18] vh[3*2L] misc[16]
+//   Hx[2L][ldh]  ([Hx | r], row-major)   Tm[rho][ldh]   S[(rho+1)][rho+1]
 __host__ __device__ inline size_t feat_lds_doubles(int max_len, int ldh, bool tm_in_lds) {
     const int L = max_len, M2 = 2 * L, rho = 2 * L - 2;
-    size_t n = (size_t)(L - 1) * 24 + L * 6 + M2 * 3 + (L - 1) * 18 + 3 * M2 + 16;
+    size_t n = (size_t)7 * (L - 1) + (size_t)(L - 1) * 24 + L * 6 + M2 * 3 + (L - 1) * 18 + 3 * M2 + 16;
     n += (size_t)M2 * ldh;
     if (tm_in_lds) n += (size_t)rho * ldh;
     n += (size_t)(rho + 1) * (rho + 1);
     return n;
 }
 
-__global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const double* x, const double* P,
+__global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
                                   double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global) {
     extern __shared__ __align__(16) double lds[];
     const int tid = threadIdx.x, T = blockDim.x, f = blockIdx.x;
-    const int n = meta->n_clones, c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
-    const int n_feat = *n_feat_ptr;
-    if (f >= n_feat || (f % shard_world) != shard_rank) {
-        if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
-        return;
-    }
-    const unsigned char type = types[f];
-    const int L = lens[f];
-    const float* mz = meas + (size_t)f * cfg.max_len * 2;
+    const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     // carve LDS
     const int ML = cfg.max_len, M2max = 2 * ML, rhomax = 2 * ML - 2;
     double* p = lds;
+    double* xcl = p;  p += 7 * (ML - 1);
     double* pose = p; p += (size_t)(ML - 1) * 24;
     double* hrr = p;  p += ML * 6;
     double* hf = p;   p += M2max * 3;
@@ -210,16 +235,29 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
     double* Tm;
     if (tm_global) Tm = tm_global + (size_t)f * rhomax * ldh; else { Tm = p; p += (size_t)rhomax * ldh; }
     double* S = p;
+    // ---- one batch of global reads: feature header, its observations, the clone poses
+    const int n_feat = *n_feat_ptr;
+    const unsigned char type = types[f];
+    const int L = lens[f];
+    const float* mz = meas + (size_t)f * cfg.max_len * 2;
+    float mxv = 0, myv = 0;
     const int lane = tid & 63;
+    if (lane < ML) { mxv = mz[2 * lane]; myv = mz[2 * lane + 1]; }
+    for (int e = tid; e < 7 * n; e += T) xcl[e] = x[26 + e];
+    if (f >= n_feat || (f % shard_world) != shard_rank) {
+        if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
+        return;
+    }
     const bool wave0 = tid < 64;
     const int nPh = L - 1;
     const double sig = cfg.sigma_im, sig2 = sig * sig;
     const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
     const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
+    __syncthreads();
 
-    // ---- U1 relative-pose chain (Updater.cc:114-141): sequential, lane 0 writes
+    // ---- U1 relative-pose chain (Updater.cc:114-141): serial, every lane of wave 0 runs it, lane 0 writes
     if (wave0) {
-        const double* rel = (type == '1') ? (x + 26 + 7 * n - 7 * nPh) : (x + 26);
+        const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
         q4 qI = ldq(rel);
         d3 tI = scl3(-1.0, mv33(q2r(qI), ld3(rel + 4)));
         for (int i = 0; i < nPh; ++i) {
@@ -245,21 +283,21 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
     // ---- U2 inverse-depth LM triangulation (Updater.cc:143-269): lane i <-> observation i
     double phi = 0, psi = 0, rho = 0;
     bool valid = true;
+    const float fx0 = __shfl(mxv, 0, 64), fy0 = __shfl(myv, 0, 64);
     if (wave0) {
-        const float fx0 = mz[0], fy0 = mz[1];
         phi = atan2((double)fy0, sqrt((double)fx0 * (double)fx0 + 1));
         psi = atan2((double)fx0, 1.0);
         if (fabs(phi) > .5 * 3.14 || fabs(psi) > .5 * 3.14) valid = false;
         const bool act = lane < L;
-        float mx = 0, my = 0;
+        const float mx = mxv, my = myv;
         m33 Rc = eye33(); d3 tc = mk3(0, 0, 0);
-        if (act) { mx = mz[2 * lane]; my = mz[2 * lane + 1]; }
         if (act && lane > 0) { Rc = ldm33(pose + (lane - 1) * 24 + 12); tc = ld3(pose + (lane - 1) * 24 + 21); }
         const double ri = 1. / sig2;
         double lambda = 0.01, lastCost = INFINITY;
         if (valid) {
             for (int it = 0; it < 10; ++it) {
-                const double sph = sin(phi), cph = cos(phi), sps = sin(psi), cps = cos(psi);
+                double sph, cph, sps, cps;
+                sincos(phi, &sph, &cph); sincos(psi, &sps, &cps);
                 const d3 ep = mk3(cph * sps, sph, cph * cps);
                 const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
                 double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0, cost = 0;
@@ -327,7 +365,8 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
     const int M2 = 2 * Lu;
     const int nStartCol = (type == '1') ? 6 * (n - (Lu - 1)) : 0;
     const int cLo = nStartCol, cHi = nStartCol + 6 * (Lu - 1);   // non-zero column range of this feature
-    const double sph = sin(phi), cph = cos(phi), sps = sin(psi), cps = cos(psi);
+    double sph, cph, sps, cps;
+    sincos(phi, &sph, &cph); sincos(psi, &sps, &cps);
     const d3 ep = mk3(cph * sps, sph, cph * cps);
     const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
     for (int e = tid; e < M2 * ldh; e += T) Hx[e] = 0.0;
@@ -339,7 +378,8 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
         const double iz = 1 / h.z, iz2 = h.z * h.z;
         const double Hp0[3] = {iz, 0, -h.x / iz2}, Hp1[3] = {0, iz, -h.y / iz2};
         const float px = (float)(h.x / h.z), py = (float)(h.y / h.z);
-        const float ex = mz[2 * i] - px, ey = mz[2 * i + 1] - py;  // float32 residual (Updater.cc:307-308,338-339)
+        // T >= 64 > Lu: the loop body runs once with i == tid == lane, so (mxv, myv) is observation i
+        const float ex = mxv - px, ey = myv - py;  // float32 residual (Updater.cc:307-308,338-339)
         Hx[(size_t)(2 * i) * ldh + c6] = (double)ex;
         Hx[(size_t)(2 * i + 1) * ldh + c6] = (double)ey;
         double HR0[3], HR1[3];
@@ -372,10 +412,15 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { o[a * 6 + b] = left.m[3 * a + b]; o[a * 6 + 3 + b] = right.m[3 * a + b]; }
     }
     __syncthreads();
-    for (int i = 1; i < Lu; ++i) {
-        const double* hr = hrr + i * 6;
-        for (int e = tid; e < i * 12; e += T) {
-            const int j = e / 12, a = (e % 12) / 6, b = e % 6;
+    {   // all (i, j<i) 2x6 blocks, flattened over the workgroup
+        const int nitems = (Lu * (Lu - 1) / 2) * 12;
+        for (int e = tid; e < nitems; e += T) {
+            const int pr = e / 12, ab = e % 12, a = ab / 6, b = ab % 6;
+            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)pr)) * 0.5f);
+            while (i * (i - 1) / 2 > pr) --i;
+            while ((i + 1) * i / 2 <= pr) ++i;
+            const int j = pr - i * (i - 1) / 2;
+            const double* hr = hrr + i * 6;
             const double* l = lr + j * 18;
             Hx[(size_t)(2 * i + a) * ldh + nStartCol + 6 * j + b] = hr[3 * a] * l[b] + hr[3 * a + 1] * l[6 + b] + hr[3 * a + 2] * l[12 + b];
         }
@@ -390,17 +435,19 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
         if (lane < M2) { h0 = hf[lane * 3]; h1 = hf[lane * 3 + 1]; h2 = hf[lane * 3 + 2]; }
         if (sqrt(wave_sum(h2 * h2)) < 1e-4) N = 2;   // rank-deficient Hf (Updater.cc:374-378)
         double hc[3] = {h0, h1, h2};
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             double v = 0, beta = 0;
             if (k < N) {
                 const double xk = (lane >= k && lane < M2) ? hc[k] : 0.0;
                 const double s = wave_sum(xk * xk);
-                const double akk = __shfl(hc[k], k, 64);
+                const double akk = readlane_f64(hc[k], k);
                 if (s > 0) {
                     const double alpha = (akk >= 0) ? -sqrt(s) : sqrt(s);
                     v = (lane == k) ? (akk - alpha) : xk;
                     const double vtv = s - akk * akk + (akk - alpha) * (akk - alpha);
                     beta = 2.0 / vtv;
+#pragma unroll
                     for (int c = k + 1; c < 3; ++c) {
                         const double wdot = wave_sum(v * hc[c]);
                         hc[c] -= beta * wdot * v;
@@ -472,9 +519,10 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
     // Cholesky of S with the residual appended as an extra row: its entries become y = L^-1 r,
     // gamma = |r^T S^-1 r| = y^T y.  (reference: colPivHouseholderQr().solve, Updater.cc:420)
     for (int k = 0; k < rr; ++k) {
-        if (tid == 0) { double dkk = S[k * lds_s + k]; S[k * lds_s + k] = sqrt(dkk > 0 ? dkk : 1e-300); }
+        const double dkk = S[k * lds_s + k];
+        const double lkk = sqrt(dkk > 0 ? dkk : 1e-300);
         __syncthreads();
-        for (int i = k + 1 + tid; i <= rr; i += T) S[i * lds_s + k] /= S[k * lds_s + k];
+        for (int i = k + tid; i <= rr; i += T) S[i * lds_s + k] = (i == k) ? lkk : S[i * lds_s + k] / lkk;
         __syncthreads();
         for (int i = k + 1 + tid; i <= rr; i += T) {
             const double lik = S[i * lds_s + k];
@@ -504,33 +552,33 @@ __global__ void feat_build_kernel(DevCfg cfg, const FilterMeta* meta, const doub
 // partial[g][p][q] = sum over the rows of feature group g of H[row][p] * H[row][q],
 // q = 0..c6 (column c6 is the residual -> b).  grid = (groups, ceil(c6/16)), 256 threads.
 #define GRAM_FG 4
-__global__ __launch_bounds__(256) void gram_kernel(DevCfg cfg, const FilterMeta* meta, const double* Hstack, const int* nrows,
-                                                   double* partial) {
-    const int n = meta->n_clones, c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max;
+__global__ __launch_bounds__(256) void gram_kernel(DevCfg cfg, int n, const double* Hstack, const int* nrows, double* partial) {
+    const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max;
     const int g = blockIdx.x, p0 = blockIdx.y * 16;
     if (p0 >= c6) return;
     const int f0 = g * GRAM_FG;
     const int ncol = c6 + 1;
+    int nr[GRAM_FG];
+#pragma unroll
+    for (int ff = 0; ff < GRAM_FG; ++ff) nr[ff] = (f0 + ff < cfg.Fu) ? nrows[f0 + ff] : 0;
     double* out = partial + (size_t)g * cfg.ldh * cfg.ldh;
     for (int e = threadIdx.x; e < 16 * ncol; e += 256) {
         const int p = p0 + e / ncol, q = e % ncol;
         if (p >= c6) continue;
         double acc = 0;
+#pragma unroll
         for (int ff = 0; ff < GRAM_FG; ++ff) {
-            const int f = f0 + ff;
-            if (f >= cfg.Fu) break;
-            const int nr = nrows[f];
-            const double* H = Hstack + (size_t)f * rhomax * ldh;
-            for (int r = 0; r < nr; ++r) acc += H[(size_t)r * ldh + p] * H[(size_t)r * ldh + q];
+            const double* H = Hstack + (size_t)(f0 + ff) * rhomax * ldh;
+            for (int r = 0; r < nr[ff]; ++r) acc += H[(size_t)r * ldh + p] * H[(size_t)r * ldh + q];
         }
         out[(size_t)p * ldh + q] = acc;
     }
 }
 
 // block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
-__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, const FilterMeta* meta, const double* partial, int n_groups,
+__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
                                                           const int* nrows, double* block) {
-    const int n = meta->n_clones, c6 = 6 * n, ldh = cfg.ldh;
+    const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
@@ -538,170 +586,167 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, const Filt
         if (q <= c6) for (int g = 0; g < n_groups; ++g) acc += partial[(size_t)g * ldh * ldh + e];
         block[e] = acc;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
         int good = 0, rows = 0;
-        for (int f = 0; f < cfg.Fu; ++f) { if (nrows[f] > 0) { good++; rows += nrows[f]; } }
-        block[(size_t)cfg.ldh * (cfg.ldh - 1)] = (double)good;
-        block[(size_t)cfg.ldh * (cfg.ldh - 1) + 1] = (double)rows;
+        for (int f = threadIdx.x; f < cfg.Fu; f += 64) { const int r = nrows[f]; if (r > 0) { good++; rows += r; } }
+        good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows);
+        if (threadIdx.x == 0) {
+            block[(size_t)cfg.ldh * (cfg.ldh - 1)] = (double)good;
+            block[(size_t)cfg.ldh * (cfg.ldh - 1) + 1] = (double)rows;
+        }
     }
 }
 
-// Sum `world` gathered blocks in rank order -> Ab (c6 x ldh), set meta counters, build
-// the Gauss-Jordan tableau Aug (c6 x 2*ldh, row-major) at FIXED column offsets so that no
-// pointer depends on n_clones:  cols [0,c6) = s2 I + A Pcc,  col ldh-1 = b,  cols [ldh, ldh+c6) = I.
-// The product A*Pcc is added by gemm_f64_kernel afterwards.
-__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, FilterMeta* meta, const double* blocks, int world, size_t block_stride,
-                                                        double* Ab, double* Aug) {
-    const int n = meta->n_clones, c6 = 6 * n, ldh = cfg.ldh, lda = 2 * ldh;
-    const double s2 = cfg.sigma_im * cfg.sigma_im;
+// world > 1: sum the gathered blocks in rank order -> Ab (same layout as a block, counts included)
+__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const double* blocks, int world, size_t block_stride, double* Ab) {
+    const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         double acc = 0;
         for (int w = 0; w < world; ++w) acc += blocks[(size_t)w * block_stride + e];
         Ab[e] = acc;
-        const int p = e / ldh, q = e % ldh;
-        // every tableau entry of row p is (re)written here: stale values never survive a frame
-        // (slot ldh-1 holds b and is written only by the q == c6 thread: no write race while n < nmax)
-        if (q != ldh - 1) Aug[(size_t)p * lda + q] = (q < c6) ? ((p == q) ? s2 : 0.0) : 0.0;
-        Aug[(size_t)p * lda + ldh + q] = (q < c6 && p == q) ? 1.0 : 0.0;
-        if (q == c6) Aug[(size_t)p * lda + ldh - 1] = acc;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double good = 0, rows = 0;
-        for (int w = 0; w < world; ++w) { good += blocks[(size_t)w * block_stride + (size_t)ldh * (ldh - 1)]; rows += blocks[(size_t)w * block_stride + (size_t)ldh * (ldh - 1) + 1]; }
-        meta->n_good = (int)good; meta->n_rows = (int)rows;
-        meta->updated = ((int)good > 2) ? 1 : 0;    // Updater.cc:460
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        const size_t t = (size_t)ldh * (ldh - 1) + threadIdx.x;
+        double acc = 0;
+        for (int w = 0; w < world; ++w) acc += blocks[(size_t)w * block_stride + t];
+        Ab[t] = acc;
     }
 }
 
-// =============================================================== FP64 MFMA GEMM
-// Cout = alpha * A(MxK) * B(KxN) + beta * Cin, arbitrary element strides (handles
-// transposes and the column-major P without copies).  One workgroup = 4 waves = a
-// 32x32 output tile, each wave one 16x16 tile with v_mfma_f64_16x16x4_f64:
+// =============================================================== FP64 MFMA GEMM:  T = s2 I + A Pcc
+// One workgroup = 4 waves = a 32x32 output tile, each wave one 16x16 tile with v_mfma_f64_16x16x4_f64:
 //   A operand lane l : A[i = l&15][k = l>>4]      B operand lane l : B[k = l>>4][j = l&15]
 //   C/D      lane l : 4 values, row = (l>>4) + 4*r, col = l&15.
-// dims[] (device): M,N,K are read from meta at run time so shapes follow n_clones.
-typedef double d4 __attribute__((ext_vector_type(4)));
-struct GemmArgs {
-    const double* A; long sar, sac;
-    const double* B; long sbr, sbc;
-    const double* Cin; long scr, scc;
-    double* Cout; long sor, soc;
-    double alpha, beta;
-    int mode;   // 0: M=d,N=c6,K=c6   1: M=d,N=d,K=c6   2: M=c6,N=c6,K=c6
-    int need_update;  // 1: skip when meta->updated == 0
-};
-__global__ __launch_bounds__(256) void gemm_f64_kernel(const FilterMeta* meta, GemmArgs g) {
-    if (g.need_update && !meta->updated) return;
-    const int n = meta->n_clones, c6 = 6 * n, d = 24 + c6;
-    const int M = (g.mode == 2) ? c6 : d, N = (g.mode == 1) ? d : c6, K = c6;
+// A = Ab (row-major, ld = ldh), B = Pcc = P[24:,24:] (column-major, ld = dmax), T row-major ld = ldh.
+__global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const double* Ab, const double* P, double* Tm) {
+    const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
-    if (i0 >= M || j0 >= N) return;
+    if (i0 >= c6 || j0 >= c6) return;
     const int li = lane & 15, lk = lane >> 4;
     const int ai = i0 + li, bj = j0 + li;
-    const bool aok = ai < M, bok = bj < N;
-    const double* ap = g.A + (long)ai * g.sar;
-    const double* bp = g.B + (long)bj * g.sbc;
+    const bool aok = ai < c6, bok = bj < c6;
+    const double* ap = Ab + (size_t)ai * ldh;
+    const double* bp = P + 24 + (size_t)(24 + bj) * ld;
     d4 acc = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int k0 = 0; k0 < c6; k0 += 16) {
         double a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + 4 * u + lk;
-            a[u] = (aok && k < K) ? ap[(long)k * g.sac] : 0.0;
-            b[u] = (bok && k < K) ? bp[(long)k * g.sbr] : 0.0;
+            a[u] = (aok && k < c6) ? ap[k] : 0.0;
+            b[u] = (bok && k < c6) ? bp[k] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
     const int col = j0 + li;
-    if (col < N) {
+    if (col < c6) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = i0 + lk + 4 * r;
-            if (row < M) {
-                double v = g.alpha * acc[r];
-                if (g.beta != 0.0) v += g.beta * g.Cin[(long)row * g.scr + (long)col * g.scc];
-                g.Cout[(long)row * g.sor + (long)col * g.soc] = v;
-            }
+            if (row < c6) Tm[(size_t)row * ldh + col] = acc[r] + ((row == col) ? s2 : 0.0);
         }
     }
 }
 
-// =============================================================== Gauss-Jordan
-// In-place reduction of the tableau [T | b | I] (c6 x 2*ldh, fixed offsets, see block_sum_kernel)
-// to [I | T^-1 b | T^-1] with partial pivoting.  One workgroup (1024 threads); staged in LDS when it fits.
-__global__ __launch_bounds__(1024) void gj_kernel(DevCfg cfg, FilterMeta* meta, double* AugG, int use_lds) {
-    extern __shared__ __align__(16) double gl[];
-    __shared__ double red_v[16];
-    __shared__ int red_i[16];
-    __shared__ double s_piv;
-    __shared__ int s_prow;
-    if (!meta->updated) return;
-    const int n = meta->n_clones, c6 = 6 * n, lda = 2 * cfg.ldh, ncol = 2 * cfg.ldh;
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
-    double* M = AugG;
-    int ldm = lda;
-    if (use_lds) {
-        ldm = ncol | 1;   // odd stride: conflict-free column walks
-        for (int e = tid; e < c6 * ncol; e += T) { int r = e / ncol, c = e % ncol; gl[(size_t)r * ldm + c] = AugG[(size_t)r * lda + c]; }
-        M = gl;
-        __syncthreads();
+// =============================================================== solve: W = T^-1, y = W b, dx, x+
+// One workgroup of 1024 threads.  Tableau M = [T | b | I]  (c6 x NC, NC = 2 c6 + 1) in LDS (or in
+// global scratch when it does not fit).  Gauss-Jordan with partial pivoting, NO row swaps and
+// deferred pivot scaling: step k picks the unused row p with max |M[i][k]|, every other row i does
+// M[i][j] -= (M[i][k]/piv) M[p][j] for the still-active columns.  Every wave re-derives p itself from
+// LDS, so ONE barrier per column suffices.  Solution row k is row p_k of the tableau times 1/piv_k.
+template <bool USE_LDS>
+__device__ __forceinline__ void solve_body(const DevCfg& cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
+                                           const double* x, const double* P, double* Wout, double* x_out, double* Mg, double* sh) {
+    __shared__ int s_prow[6 * RVIO_MAX_LEN];
+    __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
+    __shared__ double s_y[6 * RVIO_MAX_LEN];
+    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = T >> 6;
+    const int NC = 2 * c6 + 1;
+    const int ldm = USE_LDS ? (NC | 1) : (2 * ldh);
+    double* M = USE_LDS ? sh : Mg;
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += T) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += T) x_out[i] = x[i];
+        return;
     }
-    for (int k = 0; k < c6; ++k) {
-        // pivot search over rows k..c6-1 of column k
-        double best = -1.0; int bi = k;
-        for (int i = k + tid; i < c6; i += T) { double v = fabs(M[(size_t)i * ldm + k]); if (v > best) { best = v; bi = i; } }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            double ov = __shfl_xor(best, off, 64); int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wv] = best; red_i[wv] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double b = red_v[0]; int ib = red_i[0];
-            for (int w = 1; w < (T >> 6); ++w) if (red_v[w] > b || (red_v[w] == b && red_i[w] < ib)) { b = red_v[w]; ib = red_i[w]; }
-            s_prow = ib;
-            if (!(b > 0)) meta->err |= 1;
-        }
-        __syncthreads();
-        const int pr = s_prow;
-        if (pr != k) for (int c = tid; c < ncol; c += T) { double t0 = M[(size_t)k * ldm + c]; M[(size_t)k * ldm + c] = M[(size_t)pr * ldm + c]; M[(size_t)pr * ldm + c] = t0; }
-        __syncthreads();
-        const double ipiv = 1.0 / M[(size_t)k * ldm + k];
-        // eliminate column k from every other row; columns <= k of the left block are already final
-        const int nc = ncol - (k + 1);
-        for (int e = tid; e < c6 * nc; e += T) {
-            const int i = e / nc, c = k + 1 + e % nc;
-            if (i == k) continue;
-            const double fct = M[(size_t)i * ldm + k] * ipiv;
-            M[(size_t)i * ldm + c] -= fct * M[(size_t)k * ldm + c];
-        }
-        __syncthreads();
-        // scale the pivot row, clear column k
-        for (int c = k + 1 + tid; c < ncol; c += T) M[(size_t)k * ldm + c] *= ipiv;
-        for (int i = tid; i < c6; i += T) M[(size_t)i * ldm + k] = (i == k) ? 1.0 : 0.0;
-        __syncthreads();
-    }
-    if (use_lds) for (int e = tid; e < c6 * ncol; e += T) { int r = e / ncol, c = e % ncol; AugG[(size_t)r * lda + c] = gl[(size_t)r * ldm + c]; }
-}
-
-// =============================================================== U9 state injection
-// dx = Pc * y  (y = W b = last tableau column), then Updater.cc:546-613.  Writes x_out.
-__global__ __launch_bounds__(256) void inject_kernel(DevCfg cfg, const FilterMeta* meta, const double* x, const double* P,
-                                                     const double* Aug, double* x_out) {
-    __shared__ double dx[24 + 6 * RVIO_MAX_LEN];
-    const int n = meta->n_clones, c6 = 6 * n, d = 24 + c6, ld = cfg.dmax, lda = 2 * cfg.ldh, xd = 26 + 7 * n;
-    const int tid = threadIdx.x;
-    if (!meta->updated) { for (int i = tid; i < xd; i += 256) x_out[i] = x[i]; return; }
-    for (int i = tid; i < d; i += 256) {
-        double acc = 0;
-        for (int k = 0; k < c6; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * Aug[(size_t)k * lda + cfg.ldh - 1];
-        dx[i] = acc;
+    for (int e = tid; e < c6 * NC; e += T) {
+        const int r = e / NC, c = e % NC;
+        double v;
+        if (c < c6) v = Tg[(size_t)r * ldh + c];
+        else if (c == c6) v = Ab[(size_t)r * ldh + c6];
+        else v = (c - c6 - 1 == r) ? 1.0 : 0.0;
+        M[(size_t)r * ldm + c] = v;
     }
     __syncthreads();
+    unsigned long long used0 = 0, used1 = 0, used2 = 0;   // rows already chosen as pivots (uniform per wave)
+    for (int k = 0; k < c6; ++k) {
+        // pivot search: lane <-> row (rows lane, lane+64, lane+128)
+        double best = -1.0; int bi = 0;
+        for (int i = lane, q = 0; i < c6; i += 64, ++q) {
+            const unsigned long long um = (q == 0) ? used0 : (q == 1 ? used1 : used2);
+            if (!((um >> lane) & 1ull)) { const double v = fabs(M[(size_t)i * ldm + k]); if (v > best) { best = v; bi = i; } }
+        }
+        // wave arg-max: 4 DPP row-rotate steps (16-lane rows), then the 4 row winners through readlane
+#define ARGMAX_STEP(CTRL)                                                                             \
+        {                                                                                             \
+            const double ov = dpp_f64<CTRL>(best);                                                    \
+            const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, 0xf, 0xf, false);                \
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }                         \
+        }
+        ARGMAX_STEP(0x128) ARGMAX_STEP(0x124) ARGMAX_STEP(0x122) ARGMAX_STEP(0x121)
+#undef ARGMAX_STEP
+        {
+            double b0 = readlane_f64(best, 0); int i0 = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+            for (int rw = 16; rw < 64; rw += 16) {
+                const double ov = readlane_f64(best, rw); const int oi = __builtin_amdgcn_readlane(bi, rw);
+                if (ov > b0 || (ov == b0 && oi < i0)) { b0 = ov; i0 = oi; }
+            }
+            best = b0; bi = i0;
+        }
+        const int pr = bi;
+        if (pr < 64) used0 |= 1ull << pr; else if (pr < 128) used1 |= 1ull << (pr - 64); else used2 |= 1ull << (pr - 128);
+        const double piv = M[(size_t)pr * ldm + k];
+        const double ipiv = 1.0 / piv;
+        if (tid == 0) { s_prow[k] = pr; s_ipiv[k] = ipiv; if (!(best > 0)) meta->err |= 1; }
+        // eliminate: wave w owns rows w, w+NW, ...; lanes own the active columns j > k
+        const int j0 = k + 1 + lane;
+        double prv[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) { const int j = j0 + 64 * u; prv[u] = (j < NC) ? M[(size_t)pr * ldm + j] : 0.0; }
+        for (int i = wv; i < c6; i += NW) {
+            if (i == pr) continue;
+            const double f = M[(size_t)i * ldm + k] * ipiv;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const int j = j0 + 64 * u; if (j < NC) M[(size_t)i * ldm + j] -= f * prv[u]; }
+        }
+        __syncthreads();
+    }
+    // unscramble: solution row k = tableau row prow[k] * ipiv[k]
+    for (int e = tid; e < c6 * c6; e += T) {
+        const int k = e / c6, j = e % c6;
+        Wout[(size_t)k * ldh + j] = M[(size_t)s_prow[k] * ldm + c6 + 1 + j] * s_ipiv[k];
+    }
+    for (int k = tid; k < c6; k += T) s_y[k] = M[(size_t)s_prow[k] * ldm + c6] * s_ipiv[k];
+    __syncthreads();
+    // dx = K r = Pc y   (Updater.cc:544)
+    for (int i = tid; i < d; i += T) {
+        double acc = 0;
+        for (int k = 0; k < c6; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
+        s_dx[i] = acc;
+    }
+    __syncthreads();
+    // state injection (Updater.cc:546-613)
+    const double* dx = s_dx;
     if (tid == 0) {
         stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
         for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
@@ -709,77 +754,198 @@ __global__ __launch_bounds__(256) void inject_kernel(DevCfg cfg, const FilterMet
         stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
         for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
     }
-    for (int p = tid - 1; p >= 0 && p < n; p += 255) {
+    for (int p = tid - 64; p >= 0 && p < n; p += T - 64) {
         stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
         for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
     }
 }
+__global__ __launch_bounds__(1024) void solve_kernel_lds(DevCfg cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
+                                                         const double* x, const double* P, double* Wout, double* x_out) {
+    extern __shared__ __align__(16) double sh[];
+    solve_body<true>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, nullptr, sh);
+}
+__global__ __launch_bounds__(1024) void solve_kernel_glb(DevCfg cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
+                                                         const double* x, const double* P, double* Wout, double* x_out, double* Mg) {
+    solve_body<false>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, Mg, nullptr);
+}
 
-// P_out = .5 (Pt + Pt^T) if updated else P_in   (Updater.cc:619 / :621-627)
-__global__ __launch_bounds__(256) void symm_out_kernel(DevCfg cfg, const FilterMeta* meta, const double* Pt, const double* Pin, double* Pout) {
-    const int n = meta->n_clones, d = 24 + 6 * n, ld = cfg.dmax;
-    const bool upd = meta->updated;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < d * d; e += gridDim.x * 256) {
-        const int i = e % d, j = e / d;
-        Pout[(size_t)i + (size_t)j * ld] = upd ? .5 * (Pt[(size_t)i + (size_t)j * ld] + Pt[(size_t)j + (size_t)i * ld]) : Pin[(size_t)i + (size_t)j * ld];
+// =============================================================== U = Pc W, G = U A, P1 = P - G Pc^T
+// One workgroup (4 waves) per 16-row strip of the d rows.  K H = [0 | G];  (I - K H) P = P1.
+// LDS: Us[16][c6p], Gs[16][c6p] (row-major, c6p = c6 rounded up to 16, +1 pad).
+__global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double* P, const double* W, const double* Ab,
+                                                 double* U, double* G, double* P1) {
+    extern __shared__ __align__(16) double sh[];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
+    const int lds = c6t * 16 + 1;
+    double* Us = sh; double* Gs = sh + 16 * lds;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int i0 = blockIdx.x * 16;
+    if (i0 >= d) return;
+    const int ai = i0 + li;
+    const bool aok = ai < d;
+    // U strip: A = Pc[i][k] = P[i + (24+k) ld], B = W[k][j] (row-major ldh)
+    for (int jt = wave; jt < c6t; jt += 4) {
+        const int bj = jt * 16 + li; const bool bok = bj < c6;
+        d4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < c6; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk;
+                a[u] = (aok && k < c6) ? P[(size_t)ai + (size_t)(24 + k) * ld] : 0.0;
+                b[u] = (bok && k < c6) ? W[(size_t)k * ldh + bj] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            Us[row * lds + jt * 16 + li] = acc[r];
+            if (i0 + row < d && bj < c6) U[(size_t)(i0 + row) * ldh + bj] = acc[r];
+        }
+    }
+    __syncthreads();
+    // G strip: A = Us[i][k], B = A[k][j] (Ab row-major; A is symmetric)
+    for (int jt = wave; jt < c6t; jt += 4) {
+        const int bj = jt * 16 + li; const bool bok = bj < c6;
+        d4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < c6; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk;
+                a[u] = (k < c6) ? Us[li * lds + k] : 0.0;
+                b[u] = (bok && k < c6) ? Ab[(size_t)k * ldh + bj] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            Gs[row * lds + jt * 16 + li] = acc[r];
+            if (i0 + row < d && bj < c6) G[(size_t)(i0 + row) * ldh + bj] = acc[r];
+        }
+    }
+    __syncthreads();
+    // P1 strip = P - G Pc^T: A = Gs[i][k], B[k][j] = Pc[j][k] = P[j + (24+k) ld]
+    for (int jt = wave; jt < dt; jt += 4) {
+        const int bj = jt * 16 + li; const bool bok = bj < d;
+        d4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < c6; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk;
+                a[u] = (k < c6) ? Gs[li * lds + k] : 0.0;
+                b[u] = (bok && k < c6) ? P[(size_t)bj + (size_t)(24 + k) * ld] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + lk + 4 * r;
+            if (row < d && bj < d) P1[(size_t)row + (size_t)bj * ld] = P[(size_t)row + (size_t)bj * ld] - acc[r];
+        }
     }
 }
 
-// =============================================================== S1 augmentation / slide
-// System.cc:279-323.  J P J^T with J = [I; rows 9..14] is a pure gather: out[a][b] = P[src(a)][src(b)].
+// =============================================================== Joseph form, final: P+ = sym(X),
+//   X = P1 - P1c G^T + s2 G U^T   =  (I-KH) P (I-KH)^T + s2 K K^T      (Updater.cc:615-619)
+// One wave per unordered 16x16 tile pair (I <= J): computes X_IJ and X_JI, writes .5 (X_IJ + X_JI^T) to both.
+__device__ __forceinline__ d4 final_tile(const double* P1, const double* G, const double* U, int d, int c6, int ld, int ldh, double s2,
+                                         int i0, int j0, int li, int lk) {
+    const int ai = i0 + li, bj = j0 + li;
+    const bool aok = ai < d, bok = bj < d;
+    d4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < c6; k0 += 16) {
+        double a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const bool kok = k < c6;
+            a1[u] = (aok && kok) ? P1[(size_t)ai + (size_t)(24 + k) * ld] : 0.0;   // P1c[i][k]
+            b1[u] = (bok && kok) ? G[(size_t)bj * ldh + k] : 0.0;                  // G[j][k]
+            a2[u] = (aok && kok) ? G[(size_t)ai * ldh + k] : 0.0;                  // G[i][k]
+            b2[u] = (bok && kok) ? U[(size_t)bj * ldh + k] : 0.0;                  // U[j][k]
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[u], b2[u], acc2, 0, 0, 0);
+        }
+    }
+    d4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r;
+        const double p1 = (row < d && bj < d) ? P1[(size_t)row + (size_t)bj * ld] : 0.0;
+        out[r] = p1 - acc[r] + s2 * acc2[r];
+    }
+    return out;
+}
+__global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const double* P1, const double* G, const double* U, double* Pout) {
+    __shared__ double tl[4][16][17];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    const int nt = (d + 15) / 16, npair = nt * (nt + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= npair) return;
+    int I = 0, rem = pr;
+    while (rem >= nt - I) { rem -= nt - I; ++I; }
+    const int J = I + rem;
+    const d4 xij = final_tile(P1, G, U, d, c6, ld, ldh, s2, I * 16, J * 16, li, lk);
+    d4 xji = xij;
+    if (I != J) xji = final_tile(P1, G, U, d, c6, ld, ldh, s2, J * 16, I * 16, li, lk);
+    // transpose X_JI through LDS (wave-private 16x16 tile)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tl[wave][lk + 4 * r][li] = xji[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = lk + 4 * r, row = I * 16 + rr, col = J * 16 + li;
+        const double v = .5 * (xij[r] + tl[wave][li][rr]);     // X_JI[col_local][row_local]
+        if (row < d && col < d) {
+            Pout[(size_t)row + (size_t)col * ld] = v;
+            if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+        }
+    }
+}
+
+// =============================================================== S1 + S2 fused: augmentation/slide + composition
+// System.cc:279-365.  J P J^T with J = [I; rows 9..14] is a gather (out[a][b] = P[src(a)][src(b)]); composition
+// multiplies the first 24 rows/columns by Vk.  Out-of-place (reads cur, writes cur^1).
+// block 0: the 24x24 corner Vk P11 Vk^T (symmetrised) + the state vector; other blocks: one clone column per thread.
 __device__ __forceinline__ int aug_src(int a, int n, int nmax, int do_aug) {
     if (a < 24 || !do_aug) return a;
     const int cb = (a - 24) / 6, off = (a - 24) % 6;
     if (n < nmax) return (cb < n) ? a : 9 + off;
     return (cb < nmax - 1) ? a + 6 : 9 + off;
 }
-__global__ __launch_bounds__(256) void augment_kernel(DevCfg cfg, const FilterMeta* meta, const double* x, const double* P,
-                                                      double* x_out, double* P_out, int do_aug) {
-    const int n = meta->n_clones, nmax = cfg.nmax, ld = cfg.dmax;
-    const int n2 = do_aug ? ((n < nmax) ? n + 1 : nmax) : n;
-    const int d2 = 24 + 6 * n2;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < d2 * d2; e += gridDim.x * 256) {
-        const int i = e % d2, j = e / d2;
-        P_out[(size_t)i + (size_t)j * ld] = P[(size_t)aug_src(i, n, nmax, do_aug) + (size_t)aug_src(j, n, nmax, do_aug) * ld];
-    }
-    if (blockIdx.x == 0) {
-        const int xd2 = 26 + 7 * n2;
-        for (int i = threadIdx.x; i < xd2; i += 256) {
-            int src = i;
-            if (do_aug && i >= 26) {
-                const int cb = (i - 26) / 7, off = (i - 26) % 7;
-                if (n < nmax) src = (cb < n) ? i : 10 + off;
-                else src = (cb < nmax - 1) ? i + 7 : 10 + off;
-            }
-            x_out[i] = x[src];
-        }
-    }
-}
-// meta update after augmentation (separate tiny kernel keeps augment_kernel race-free)
-__global__ void meta_after_augment_kernel(DevCfg cfg, FilterMeta* meta, int do_aug) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (do_aug && meta->n_clones < cfg.nmax) meta->n_clones += 1;
-    }
-}
-
-// =============================================================== S2 composition
-// System.cc:325-365.  Reads (x_in,P_in) written by augment_kernel, writes (x_out,P_out).
-// block 0: the 24x24 corner Vk P11 Vk^T (symmetrised); other blocks: rows<24 x clone columns.
-__global__ __launch_bounds__(256) void compose_kernel(DevCfg cfg, const FilterMeta* meta, const double* x, const double* P,
+__global__ __launch_bounds__(256) void augcomp_kernel(DevCfg cfg, int n, int do_aug, const double* x, const double* P,
                                                       double* x_out, double* P_out, double* pose_out) {
     __shared__ double Vk[24][25];
     __shared__ double P11[24][25];
     __shared__ double Tm[24][25];
-    const int n = meta->n_clones, d = 24 + 6 * n, ld = cfg.dmax, xd = 26 + 7 * n;
+    __shared__ double xs[26];
+    const int nmax = cfg.nmax, ld = cfg.dmax;
+    const int n2 = do_aug ? ((n < nmax) ? n + 1 : nmax) : n;
+    const int d2 = 24 + 6 * n2, xd2 = 26 + 7 * n2;
     const int tid = threadIdx.x;
-    const q4 qG = ldq(x), qk = ldq(x + 10);
-    const d3 pG = ld3(x + 4), pk = ld3(x + 14);
-    const m33 RG = q2r(qG), Rk = q2r(qk);
-    const d3 gk = unit3(mv33(Rk, ld3(x + 7)));
-    const q4 qkG = qmul(qk, qG);
-    const d3 pkG = mv33(Rk, sub3(pG, pk));
+    if (tid < 26) xs[tid] = x[tid];
+    if (blockIdx.x == 0) for (int e = tid; e < 576; e += 256) P11[e % 24][e / 24] = P[(size_t)(e % 24) + (size_t)(e / 24) * ld];
     for (int e = tid; e < 576; e += 256) Vk[e / 24][e % 24] = 0.0;
     __syncthreads();
+    const q4 qG = ldq(xs), qk = ldq(xs + 10);
+    const d3 pG = ld3(xs + 4), pk = ld3(xs + 14);
+    const m33 RG = q2r(qG), Rk = q2r(qk);
+    const d3 gk = unit3(mv33(Rk, ld3(xs + 7)));
+    const q4 qkG = qmul(qk, qG);
+    const d3 pkG = mv33(Rk, sub3(pG, pk));
     if (tid < 9) {
         const int i = tid / 3, j = tid % 3;
         const m33 spx = skew33(pkG), sgx = skew33(gk);
@@ -790,42 +956,52 @@ __global__ __launch_bounds__(256) void compose_kernel(DevCfg cfg, const FilterMe
     }
     __syncthreads();
     if (blockIdx.x == 0) {
-        for (int e = tid; e < 576; e += 256) P11[e % 24][e / 24] = P[(size_t)(e % 24) + (size_t)(e / 24) * ld];
-        __syncthreads();
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Vk[i][k] * P11[k][j]; Tm[i][j] = a; }
         __syncthreads();
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Tm[i][k] * Vk[j][k]; P11[i][j] = a; }
         __syncthreads();
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; P_out[(size_t)i + (size_t)j * ld] = .5 * (P11[i][j] + P11[j][i]); }
-        // state (System.cc:360-365) + pose line (System.cc:371-374)
-        for (int i = tid; i < xd; i += 256) {
-            double v = x[i];
+        // state: augmentation (System.cc:282-287,303-306) then composition (System.cc:360-365)
+        for (int i = tid; i < xd2; i += 256) {
+            double v;
             if (i < 4) v = (&qkG.x)[i];
             else if (i < 7) v = (&pkG.x)[i - 4];
             else if (i < 10) v = (&gk.x)[i - 7];
             else if (i < 13) v = 0.0;
             else if (i == 13) v = 1.0;
             else if (i < 17) v = 0.0;
+            else if (i < 26) v = xs[i];
+            else {
+                int src = i;
+                if (do_aug) {
+                    const int cb = (i - 26) / 7, off = (i - 26) % 7;
+                    if (n < nmax) src = (cb < n) ? i : 10 + off;
+                    else src = (cb < nmax - 1) ? i + 7 : 10 + off;
+                }
+                v = (src < 26) ? xs[src] : x[src];
+            }
             x_out[i] = v;
         }
-        if (tid == 0) {
+        if (tid == 0) {   // pose line (System.cc:371-374)
             const d3 pGk = mv33(tr33(RG), sub3(pk, pG));
             st3(pose_out, pGk); stq(pose_out + 3, qkG);
         }
     } else {
-        // columns c >= 24: out[0:24, c] = Vk * P[0:24, c]; mirror; lower-right block copied
-        const int c6 = 6 * n;
+        const int c6 = 6 * n2;
         for (int c = (blockIdx.x - 1) * 256 + tid; c < c6; c += (gridDim.x - 1) * 256) {
+            const int sc = aug_src(24 + c, n, nmax, do_aug);
             double col[24];
-            const double* pc = P + (size_t)(24 + c) * ld;
+            const double* pc = P + (size_t)sc * ld;
+#pragma unroll
             for (int k = 0; k < 24; ++k) col[k] = pc[k];
             for (int i = 0; i < 24; ++i) {
                 double a = 0;
+#pragma unroll
                 for (int k = 0; k < 24; ++k) a += Vk[i][k] * col[k];
                 P_out[(size_t)i + (size_t)(24 + c) * ld] = a;
                 P_out[(size_t)(24 + c) + (size_t)i * ld] = a;
             }
-            for (int r = 24; r < d; ++r) P_out[(size_t)r + (size_t)(24 + c) * ld] = pc[r];
+            for (int r = 24; r < d2; ++r) P_out[(size_t)r + (size_t)(24 + c) * ld] = pc[aug_src(r, n, nmax, do_aug)];
         }
     }
 }

@@ -1,10 +1,11 @@
 // frontend_kernels.hip — hand-written gfx950 kernels for the visual front end of the
-// R-VIO hot path.  Compiled with -ffp-contract=off: the
+// R-VIO hot path.  Compiled with FP contraction off: the
 // KLT arithmetic (integer fixed-point + float32) is bit-identical to oracle/frontend.cpp.
 //
-//   pyr_down_kernel   cv::pyrDown inside calcOpticalFlowPyrLK        (Tracker.cc:244)
-//   scharr_kernel     calcSharrDeriv (int16 dx,dy)                   (Tracker.cc:244)
-//   klt_kernel        LKTrackerInvoker, all pyramid levels, one wave per feature
+//   pyr_level_kernel  one launch per pyramid level: Scharr derivative of level l (calcSharrDeriv),
+//                     cv::pyrDown l -> l+1, and (level 0) the copy of the frame into the pyramid
+//   klt_kernel        LKTrackerInvoker, all levels, one wave per feature, template and search
+//                     windows staged in LDS (Tracker.cc:244)
 //   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
 //   bookkeep_kernel   track book-keeping + FindNewer + refill        (Tracker.cc:271-393, FeatureDetector.cc:78-150)
 #include "rvio_dev.h"
@@ -16,53 +17,58 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
     return i;
 }
+// single reflection: valid (and identical to reflect101) whenever -n < i < 2n-1
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
-// ------------------------------------------------------------------ pyramid
-// [1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (v+128)>>8.  One thread per output pixel.
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, int w, int h, int stride,
-                                                       uint8_t* __restrict__ dst, int dw, int dh) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    int xs[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, w);
-    int rows[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const uint8_t* s = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
-        rows[k] = s[xs[2]] * 6 + (s[xs[1]] + s[xs[3]]) * 4 + s[xs[0]] + s[xs[4]];
-    }
-    const int v = rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6;
-    dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
-}
-
-// un-normalised 3x3 Scharr, reflect-101 neighbours, int16 interleaved (dx, dy)
-__global__ __launch_bounds__(256) void scharr_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, short* __restrict__ dxy) {
+// ------------------------------------------------------------------ pyramid level
+// thread (x,y) of level l:  dxy[y][x] = un-normalised 3x3 Scharr (reflect-101 neighbours, int16 (dx,dy));
+// copy_dst[y][x] = src[y][x] (level 0 only);  if (x,y) lies in level l+1: pyrDown pixel
+// ([1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (v+128)>>8).
+__global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restrict__ src, int w, int h, int stride,
+                                                        uint8_t* __restrict__ copy_dst, short* __restrict__ dxy,
+                                                        uint8_t* __restrict__ down, int dw, int dh) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
     const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
     const uint8_t *r0 = src + (size_t)ym * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yp * stride;
-    const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
-    const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
-    dxy[((size_t)y * w + x) * 2] = (short)(t0p - t0m);
-    dxy[((size_t)y * w + x) * 2 + 1] = (short)((t1p + t1m) * 3 + t1c * 10);
+    const int a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b1 = r1[x], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
+    const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
+    const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
+    ((int*)dxy)[(size_t)y * w + x] = ((t0p - t0m) & 0xffff) | (((t1p + t1m) * 3 + t1c * 10) << 16);
+    if (copy_dst) copy_dst[(size_t)y * w + x] = (uint8_t)b1;
+    if (down && x < dw && y < dh) {
+        int xs[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, w);
+        int rows[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t* s = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
+            rows[k] = s[xs[2]] * 6 + (s[xs[1]] + s[xs[3]]) * 4 + s[xs[0]] + s[xs[4]];
+        }
+        const int v = rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6;
+        down[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+    }
 }
 
 // ------------------------------------------------------------------ KLT
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
-__device__ __forceinline__ int pixI(const uint8_t* img, int w, int h, int x, int y) { return img[(size_t)reflect101(y, h) * w + reflect101(x, w)]; }
-__device__ __forceinline__ int derI(const short* d, int w, int h, int x, int y, int c) {
-    return (x < 0 || y < 0 || x >= w || y >= h) ? 0 : d[((size_t)y * w + x) * 2 + c];
-}
 
-// One wave per feature; lane l owns window pixels p = l + 64 q (q < 4, p < 225).  The template
-// patch (I, Ix, Iy) lives in registers; the 64-bit integer sums are order-free (see oracle).
+// One wave per feature; lane l owns window pixels p = l + 64 q (q < 4, p < 225).
+//   Ip  16x16 u8   prev-image patch  (window + 1 for the bilinear taps)      staged once per level
+//   dIp 16x16 i32  packed (dx | dy<<16) Scharr patch                         staged once per level
+//   Jr  32x32 u8   next-image search region around the current estimate      restaged only if the window leaves it
+// The template (I, Ix, Iy) lives in registers; 64-bit integer sums make the result order-free.
+#define KLT_JR 32
 __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int levels, const int* n_pts_ptr,
                                                  const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status) {
+    __shared__ uint8_t Ip[16 * 16];
+    __shared__ int dIp[16 * 16];
+    __shared__ uint8_t Jr[KLT_JR * KLT_JR];
     const int f = blockIdx.x, lane = threadIdx.x;
-    if (f >= *n_pts_ptr) return;
     const float px = pts[2 * f], py = pts[2 * f + 1];
+    if (f >= *n_pts_ptr) return;
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2 = 0.01 * 0.01;
     float nx = 0, ny = 0;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
 #pragma unroll
     for (int q = 0; q < 4; ++q) { int p = lane + 64 * q; wx_[q] = p % 15; wy_[q] = p / 15; }
     for (int level = levels - 1; level >= 0; --level) {
-        const uint8_t* I = prev.img[level]; const short* dI = prev.dxy[level]; const uint8_t* J = next.img[level];
+        const uint8_t* I = prev.img[level]; const int* dI = (const int*)prev.dxy[level]; const uint8_t* J = next.img[level];
         const int w = prev.w[level], h = prev.h[level];
         const float sc = (float)(1. / (1 << level));
         float ppx = px * sc, ppy = py * sc;
@@ -84,16 +90,44 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
         int iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
         int iw10 = (int)rintf((1.f - a) * b * (1 << 14));
         int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+        // ---- stage the 16x16 template source (image: reflect-101, derivative: zero outside) and the J region
+        float npx = nx - 7.f, npy = ny - 7.f;
+        int jx0 = (int)floorf(npx) - 8, jy0 = (int)floorf(npy) - 8;
+        __syncthreads();   // previous level's LDS readers are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q, X = ipx + (e & 15), Y = ipy + (e >> 4);
+            Ip[e] = I[(size_t)reflect1(Y, h) * w + reflect1(X, w)];
+            dIp[e] = (X < 0 || Y < 0 || X >= w || Y >= h) ? 0 : dI[(size_t)Y * w + X];
+        }
+        // (only when the first window is inside the image: otherwise iteration 0 bails out before reading, and
+        //  a garbage estimate must never reach the reflect loops)
+        if (jx0 + 8 >= -15 && jx0 + 8 < w && jy0 + 8 >= -15 && jy0 + 8 < h) {
+            const int r = lane >> 1, c0 = (lane & 1) * 16;
+            const uint8_t* jrow = J + (size_t)reflect101(jy0 + r, h) * w;
+            unsigned pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect101(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
+                pk[g] = v;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ((unsigned*)Jr)[(r * KLT_JR + c0) / 4 + g] = pk[g];
+        }
+        __syncthreads();
         int Iw[4], Ixw[4], Iyw[4];
         long long s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             Iw[q] = 0; Ixw[q] = 0; Iyw[q] = 0;
             if (lane + 64 * q < 225) {
-                const int X = ipx + wx_[q], Y = ipy + wy_[q];
-                const int ival = descale(pixI(I, w, h, X, Y) * iw00 + pixI(I, w, h, X + 1, Y) * iw01 + pixI(I, w, h, X, Y + 1) * iw10 + pixI(I, w, h, X + 1, Y + 1) * iw11, 14 - 5);
-                const int ixv = descale(derI(dI, w, h, X, Y, 0) * iw00 + derI(dI, w, h, X + 1, Y, 0) * iw01 + derI(dI, w, h, X, Y + 1, 0) * iw10 + derI(dI, w, h, X + 1, Y + 1, 0) * iw11, 14);
-                const int iyv = descale(derI(dI, w, h, X, Y, 1) * iw00 + derI(dI, w, h, X + 1, Y, 1) * iw01 + derI(dI, w, h, X, Y + 1, 1) * iw10 + derI(dI, w, h, X + 1, Y + 1, 1) * iw11, 14);
+                const int o = wy_[q] * 16 + wx_[q];
+                const int ival = descale(Ip[o] * iw00 + Ip[o + 1] * iw01 + Ip[o + 16] * iw10 + Ip[o + 17] * iw11, 14 - 5);
+                const int d00 = dIp[o], d01 = dIp[o + 1], d10 = dIp[o + 16], d11 = dIp[o + 17];
+                const int ixv = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 + (short)(d11 & 0xffff) * iw11, 14);
+                const int iyv = descale((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 + (d11 >> 16) * iw11, 14);
                 Iw[q] = (short)ival; Ixw[q] = (short)ixv; Iyw[q] = (short)iyv;
                 s11 += (long long)Ixw[q] * Ixw[q]; s12 += (long long)Ixw[q] * Iyw[q]; s22 += (long long)Iyw[q] * Iyw[q];
             }
@@ -104,11 +138,28 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * 15 * 15);
         if (minEig < 1e-3f || D < 1.1920929e-07f) { if (level == 0) st = 0; continue; }
         D = 1.f / D;
-        float npx = nx - 7.f, npy = ny - 7.f;
         float pdx = 0, pdy = 0;
         for (int j = 0; j < 30; ++j) {
             const int inx = (int)floorf(npx), iny = (int)floorf(npy);
             if (inx < -15 || inx >= w || iny < -15 || iny >= h) { if (level == 0) st = 0; break; }
+            int ox = inx - jx0, oy = iny - jy0;
+            if (ox < 0 || ox > KLT_JR - 17 || oy < 0 || oy > KLT_JR - 17) {   // window left the staged region: restage around it
+                jx0 = inx - 8; jy0 = iny - 8; ox = 8; oy = 8;
+                __syncthreads();
+                const int r = lane >> 1, c0 = (lane & 1) * 16;
+                const uint8_t* jrow = J + (size_t)reflect101(jy0 + r, h) * w;
+                unsigned pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned v = 0;
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect101(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
+                    pk[g] = v;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ((unsigned*)Jr)[(r * KLT_JR + c0) / 4 + g] = pk[g];
+                __syncthreads();
+            }
             a = npx - inx; b = npy - iny;
             iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));
             iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
@@ -118,8 +169,8 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (lane + 64 * q < 225) {
-                    const int X = inx + wx_[q], Y = iny + wy_[q];
-                    const int diff = descale(pixI(J, w, h, X, Y) * iw00 + pixI(J, w, h, X + 1, Y) * iw01 + pixI(J, w, h, X, Y + 1) * iw10 + pixI(J, w, h, X + 1, Y + 1) * iw11, 14 - 5) - Iw[q];
+                    const int o = (oy + wy_[q]) * KLT_JR + ox + wx_[q];
+                    const int diff = descale(Jr[o] * iw00 + Jr[o + 1] * iw01 + Jr[o + KLT_JR] * iw10 + Jr[o + KLT_JR + 1] * iw11, 14 - 5) - Iw[q];
                     sb1 += (long long)diff * Ixw[q]; sb2 += (long long)diff * Iyw[q];
                 }
             }
@@ -186,16 +237,29 @@ __device__ int rng_next(int* st) {
     return out;
 }
 
+// wave-inclusive scan of one int per lane with DPP row shifts + row broadcasts (no LDS round trips)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v += t;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v += t;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v += t;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v += t;   // row_shr:8
+    // carry the totals of the previous rows (lane 15, 31, 47)
+    const int lane = threadIdx.x & 63;
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    v += (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+    return v;
+}
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
 __device__ int block_exscan(int v, int* total, int* s_w) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    const int inc = wave_incl_scan(v);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
     int base = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; tot += s_w[w]; }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int s = s_w[w]; if (w < wv) base += s; tot += s; }
     __syncthreads();
     *total = tot;
     return base + inc - v;
@@ -213,15 +277,34 @@ __device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  /
 
 // UndistortAndNormalize of the tracked points + Ransac::FindInliers.  One workgroup, 256 threads.
 // un1: previous-frame normalised coords (mPoints1ForRansac, z = 1), un2: output for this frame.
+// Dynamic LDS: cand[F] ints + used[F] bytes.
 __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
-                                                     unsigned char* status, const rvio_imu* imu, int m, int* rng, int* cand_scratch,
+                                                     unsigned char* status, const rvio_imu* imu, int m, int* rng,
                                                      rvio_frame_info* info) {
+    extern __shared__ __align__(16) unsigned char dsh[];
     __shared__ int s_w[4];
     __shared__ int pairs[16][2];
     __shared__ double hyp[16][9];
+    __shared__ double dRs[RVIO_MAX_IMU][9];
     __shared__ int cnt[16];
+    __shared__ int s_rng[36];
     __shared__ int s_winner, s_newout;
+    int* cand = (int*)dsh;
+    unsigned char* used = dsh + sizeof(int) * cfg.F;
     const int tid = threadIdx.x, N = *n_pts_ptr;
+    // one batch of global reads: RNG state, IMU samples (-> per-sample delta rotations), the points
+    if (tid < 35) s_rng[tid] = rng[tid];
+    if (tid >= 64 && tid < 64 + m) {   // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal): per-sample dR
+        const int s = tid - 64;
+        const m33 I = eye33();
+        const d3 wm = mk3(imu[s].w[0], imu[s].w[1], imu[s].w[2]);
+        const double dt = imu[s].dt, w1 = nrm3(wm), wdt = w1 * dt;
+        const m33 wx = skew33(wm), wx2 = mul33(wx, wx);
+        m33 dR;
+        if (w1 < cfg.small_angle) dR = add33(sub33(I, scl33(dt, wx)), scl33(.5 * dt * dt, wx2));
+        else dR = add33(sub33(I, scl33(sin(wdt) / w1, wx)), scl33((1 - cos(wdt)) / (w1 * w1), wx2));
+        for (int k = 0; k < 9; ++k) dRs[s][k] = dR.m[k];
+    }
     for (int i = tid; i < N; i += 256) undistort_pt(cfg, tracked[2 * i], tracked[2 * i + 1], &un2[2 * i], &un2[2 * i + 1]);
     // ordered compaction of candidate indices (status != 0)
     int nc = 0;
@@ -230,39 +313,29 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
         const int fl = (i < N && status[i]) ? 1 : 0;
         int tot;
         const int pos = block_exscan(fl, &tot, s_w);
-        if (fl) cand_scratch[nc + pos] = i;
+        if (fl) cand[nc + pos] = i;
         nc += tot;
     }
     if (tid < 16) cnt[tid] = 0;
+    for (int i = tid; i < nc; i += 256) used[i] = 0;
     if (tid == 0) { s_winner = 0; s_newout = 0; info->n_tracked_in = N; info->n_klt_ok = nc; info->n_ransac_inliers = 0; info->ransac_winner = 0; }
     __syncthreads();
     if (nc < 32) return;   // Ransac.cc:201-205; 17..31 would spin forever in the reference
-    if (tid == 0) {        // SetPointPair, Ransac.cc:50-83 — serial by construction (rand() stream)
-        // "used" marks live in status-independent scratch: reuse cand_scratch[N..2N) as the -1 table
-        int* used = cand_scratch + N;
-        for (int i = 0; i < nc; ++i) used[i] = 0;
+    if (tid == 0) {        // SetPointPair, Ransac.cc:50-83 — serial by construction (rand() stream), all in LDS
         for (int it = 0; it < 16; ++it) {
             int a, b;
-            do { a = rng_next(rng) % nc; } while (used[a]);
-            do { b = rng_next(rng) % nc; } while (used[b] || a == b);
-            pairs[it][0] = cand_scratch[a]; pairs[it][1] = cand_scratch[b];
+            do { a = rng_next(s_rng) % nc; } while (used[a]);
+            do { b = rng_next(s_rng) % nc; } while (used[b] || a == b);
+            pairs[it][0] = cand[a]; pairs[it][1] = cand[b];
             used[a] = 1; used[b] = 1;
         }
+        for (int k = 0; k < 35; ++k) rng[k] = s_rng[k];
     }
     __syncthreads();
     if (tid < 16) {
-        // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal)
-        const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci), I = eye33();
-        m33 R = I;
-        for (int s = 0; s < m; ++s) {
-            const d3 wm = mk3(imu[s].w[0], imu[s].w[1], imu[s].w[2]);
-            const double dt = imu[s].dt, w1 = nrm3(wm), wdt = w1 * dt;
-            const m33 wx = skew33(wm), wx2 = mul33(wx, wx);
-            m33 dR;
-            if (w1 < cfg.small_angle) dR = add33(sub33(I, scl33(dt, wx)), scl33(.5 * dt * dt, wx2));
-            else dR = add33(sub33(I, scl33(sin(wdt) / w1, wx)), scl33((1 - cos(wdt)) / (w1 * w1), wx2));
-            R = mul33(dR, R);
-        }
+        const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
+        m33 R = eye33();
+        for (int s = 0; s < m; ++s) R = mul33(ldm33(dRs[s]), R);
         R = mul33(mul33(Rci, R), Ric);
         // SetRansacModel, Ransac.cc:86-117
         const int ia = pairs[tid][0], ib = pairs[tid][1];
@@ -282,7 +355,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
     for (int base = 0; base < nc; base += 256) {
         const int k = base + tid;
         d3 p1 = mk3(0, 0, 1), p2 = mk3(0, 0, 1);
-        if (k < nc) { const int idx = cand_scratch[k]; p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0); p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0); }
+        if (k < nc) { const int idx = cand[k]; p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0); p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0); }
         for (int it = 0; it < 16; ++it) {
             m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[it][q];
             const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
@@ -300,7 +373,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
     {
         m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[s_winner][q];
         for (int k = tid; k < nc; k += 256) {
-            const int idx = cand_scratch[k];
+            const int idx = cand[k];
             const d3 p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0), p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0);
             const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
             if (dist > cfg.inlier_thr || isnan(dist)) { status[idx] = 0; atomicAdd(&s_newout, 1); }
@@ -313,34 +386,43 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // ------------------------------------------------------------------ T6 book-keeping + refill
 // One workgroup, 256 threads.  Track histories are per-slot arrays hist[F][max_len] (float2) with
 // lengths hist_len[F]; which free slot a new feature takes is storage only and never reaches an output.
+// Dynamic LDS: tfs[F] float2 (new feature order), cds[F] float2 (candidates), cid_t[F] / cid_c[F] short (grid cell
+// of each tracked point / candidate, -1 = outside), cellp[4][F] float2 (per-wave ChessGrid cell).
 __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand) {
+    extern __shared__ __align__(16) unsigned char dsh[];
     __shared__ int s_w[4];
-    __shared__ int s_nmeas;
-    const int tid = threadIdx.x, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
+    float2* tfs = (float2*)dsh;
+    float2* cds = tfs + F;
+    short* cid_t = (short*)(cds + F);
+    short* cid_c = cid_t + F;
+    float2* cellp = (float2*)(dsh + (((size_t)20 * F + 7) & ~(size_t)7));        // 8-byte aligned
     const int N = *t.n_pts;
+    const int first = *t.first;
     float2* hist = (float2*)t.hist;
     float2* meas = (float2*)t.meas;
     const float2* tr2 = (const float2*)t.tracked;
     const float2* un2 = (const float2*)t.un2;
     float2* feats = (float2*)t.feats;
     float2* un1 = (float2*)t.un1;
-    float2* tf = (float2*)t.tmp_feats;
     float2* tu = (float2*)t.tmp_un;
+    const int nc = n_cand < F ? n_cand : F;
+    for (int c = tid; c < nc; c += 256) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
     int nMeas = 0;
-    if (*t.first) {
+    if (first) {
         // first image, Tracker.cc:204-234: seed every slot with a detector corner
-        const int n0 = n_cand < F ? n_cand : F;
+        __syncthreads();
+        const int n0 = nc;
         for (int i = tid; i < F; i += 256) {
             if (i < n0) {
                 float ux, uy;
-                undistort_pt(cfg, cand[2 * i], cand[2 * i + 1], &ux, &uy);
-                feats[i] = make_float2(cand[2 * i], cand[2 * i + 1]);
+                undistort_pt(cfg, cds[i].x, cds[i].y, &ux, &uy);
+                feats[i] = cds[i];
                 un1[i] = make_float2(ux, uy);
                 hist[(size_t)i * ML] = make_float2(ux, uy);
                 t.hist_len[i] = 1; t.slot[i] = i;
             } else t.hist_len[i] = 0;
         }
-        __syncthreads();
         if (tid == 0) {
             *t.n_pts = n0; *t.n_feat = 0;
             if (n0 > 0) *t.first = 0;
@@ -371,7 +453,8 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
         const int i = base + tid;
         const bool trk = (i < N) && t.status[i];
         int slot = 0, hl = 0, full = 0;
-        if (trk) { slot = t.slot[i]; hl = t.hist_len[slot]; full = (hl == ML) ? 1 : 0; }
+        float2 pt = make_float2(0, 0), pu = make_float2(0, 0);
+        if (trk) { slot = t.slot[i]; hl = t.hist_len[slot]; full = (hl == ML) ? 1 : 0; pt = tr2[i]; pu = un2[i]; }
         int tot2, totT;
         const int pos2 = nMeas + block_exscan(full, &tot2, s_w);
         const int posT = nIn + block_exscan(trk ? 1 : 0, &totT, s_w);
@@ -387,9 +470,9 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
                 for (int k = 0; k + shift < hl; ++k) hs[k] = hs[k + shift];
                 hl -= shift;
             }
-            hs[hl] = un2[i];
+            hs[hl] = pu;
             t.hist_len[slot] = hl + 1;
-            tf[posT] = tr2[i]; tu[posT] = un2[i]; t.tmp_slot[posT] = slot;
+            tfs[posT] = pt; tu[posT] = pu; t.tmp_slot[posT] = slot;
         }
         nMeas = (nMeas + tot2 < Fu) ? nMeas + tot2 : Fu;
         nIn += totT;
@@ -397,37 +480,65 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
     __syncthreads();
     // ---- refill (Tracker.cc:344-387) through FindNewer/ChessGrid (FeatureDetector.cc:78-150)
     int nNew = 0;
-    if (nIn < F && n_cand > 0) {
+    if (nIn < F && nc > 0) {
         const int cells = cfg.grid_cols * cfg.grid_rows;
         const float W = (float)cfg.W, H = (float)cfg.H, offX = cfg.off_x, offY = cfg.off_y;
-        const int nc = n_cand < F ? n_cand : F;
-        for (int c = tid; c < nc; c += 256) t.cand_acc[c] = 0;
-        __syncthreads();
-        // thread <-> grid cell: gather the cell's tracked points, then walk the candidates in order
-        for (int cell = tid; cell < cells; cell += 256) {
-            float2* cp = (float2*)t.cell_pts + (size_t)cell * (2 * F);
-            int cn = 0;
-            for (int i = 0; i < nIn; ++i) {
-                const float2 p = tf[i];
-                if (p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY)) continue;
+        // grid cell of every tracked point and candidate (-1: outside / too close to a block edge)
+        for (int i = tid; i < nIn; i += 256) {
+            const float2 p = tfs[i];
+            int cell = -1;
+            if (!(p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY))) {
                 const int col = (int)floorf((p.x - offX) / cfg.block_x), row = (int)floorf((p.y - offY) / cfg.block_y);
-                if (row * cfg.grid_cols + col == cell) cp[cn++] = p;
+                cell = row * cfg.grid_cols + col;
             }
-            for (int c = 0; c < nc; ++c) {
-                const float2 p = make_float2(cand[2 * c], cand[2 * c + 1]);
-                if (p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY)) continue;
+            cid_t[i] = (short)cell;
+        }
+        for (int c = tid; c < nc; c += 256) {
+            const float2 p = cds[c];
+            int cell = -1;
+            if (!(p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY))) {
                 const int col = (int)floorf((p.x - offX) / cfg.block_x), row = (int)floorf((p.y - offY) / cfg.block_y);
-                if (row * cfg.grid_cols + col != cell) continue;
                 const float xl = col * cfg.block_x + offX, xr = xl + cfg.block_x, yt = row * cfg.block_y + offY, yb = yt + cfg.block_y;
-                if (fabsf(p.x - xl) < cfg.min_dist || fabsf(p.x - xr) < cfg.min_dist || fabsf(p.y - yt) < cfg.min_dist || fabsf(p.y - yb) < cfg.min_dist) continue;
-                if (!((double)(float)cn < .75 * (double)cfg.max_per_block)) continue;
-                bool ok = true;
-                for (int q = 0; q < cn; ++q) {
-                    const float dx = p.x - cp[q].x, dy = p.y - cp[q].y;
-                    const double dist = sqrt((double)dx * dx + (double)dy * dy);
-                    if (!(dist > (double)cfg.min_dist)) { ok = false; break; }
+                if (!(fabsf(p.x - xl) < cfg.min_dist || fabsf(p.x - xr) < cfg.min_dist || fabsf(p.y - yt) < cfg.min_dist || fabsf(p.y - yb) < cfg.min_dist))
+                    cell = row * cfg.grid_cols + col;
+            }
+            cid_c[c] = (short)cell;
+            t.cand_acc[c] = 0;
+        }
+        __syncthreads();
+        // one wave per grid cell: gather the cell's tracked points, then walk its candidates in detector order
+        float2* cp = cellp + (size_t)wv * F;
+        for (int cell = wv; cell < cells; cell += 4) {
+            int cn = 0;
+            for (int base = 0; base < nIn; base += 64) {
+                const int i = base + lane;
+                const bool in = (i < nIn) && (cid_t[i] == cell);
+                const unsigned long long bal = __ballot(in);
+                if (in) cp[cn + __popcll(bal & ((1ull << lane) - 1ull))] = tfs[i];
+                cn += __popcll(bal);
+            }
+            for (int base = 0; base < nc; base += 64) {
+                const int c = base + lane;
+                unsigned long long bal = __ballot((c < nc) && (cid_c[c] == cell));
+                while (bal) {
+                    const int bit = __ffsll((long long)bal) - 1;
+                    bal &= bal - 1ull;
+                    const int cc = base + bit;
+                    if (!((double)(float)cn < .75 * (double)cfg.max_per_block)) continue;
+                    const float2 p = cds[cc];
+                    bool close = false;
+                    for (int q0 = 0; q0 < cn; q0 += 64) {
+                        const int q = q0 + lane;
+                        bool cl = false;
+                        if (q < cn) {
+                            const float dx = p.x - cp[q].x, dy = p.y - cp[q].y;
+                            const double dist = sqrt((double)dx * dx + (double)dy * dy);
+                            cl = !(dist > (double)cfg.min_dist);
+                        }
+                        if (__ballot(cl)) { close = true; break; }
+                    }
+                    if (!close) { if (lane == 0) { cp[cn] = p; t.cand_acc[cc] = 1; } cn++; }
                 }
-                if (ok) { cp[cn++] = p; t.cand_acc[c] = 1; }
             }
         }
         __syncthreads();
@@ -438,7 +549,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
             const int ac = (c < nc) ? t.cand_acc[c] : 0;
             int tot;
             const int k = nNew + block_exscan(ac, &tot, s_w);
-            if (ac && k < room) { tf[nIn + k] = make_float2(cand[2 * c], cand[2 * c + 1]); }
+            if (ac && k < room) tfs[nIn + k] = cds[c];
             nNew = (nNew + tot < room) ? nNew + tot : room;
         }
         __syncthreads();
@@ -450,7 +561,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
             const int k = nFree + block_exscan(fr, &tot, s_w);
             if (fr && k < nNew) {
                 float ux, uy;
-                const float2 p = tf[nIn + k];
+                const float2 p = tfs[nIn + k];
                 undistort_pt(cfg, p.x, p.y, &ux, &uy);
                 tu[nIn + k] = make_float2(ux, uy);
                 t.tmp_slot[nIn + k] = s;
@@ -462,7 +573,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
     }
     __syncthreads();
     const int nOut = nIn + nNew;
-    for (int i = tid; i < nOut; i += 256) { feats[i] = tf[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
+    for (int i = tid; i < nOut; i += 256) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
     if (tid == 0) {
         *t.n_pts = nOut; *t.n_feat = nMeas;
         t.info->n_tracked_out = nOut; t.info->n_feat_update = nMeas;

@@ -31,12 +31,12 @@ struct rvio_hip {
     int img_count = 0;      // host mirror of nImageCountAfterInit (data-independent)
     int n_clones_host = 0;  // host mirror of nCloneStates (data-independent)
     // update scratch
-    double *Hstack = nullptr, *partial = nullptr, *block = nullptr, *Ab = nullptr, *Aug = nullptr, *U = nullptr, *G = nullptr,
-           *Pt1 = nullptr, *Pt2 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
+    double *Hstack = nullptr, *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
+           *Pt1 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
     int *nrows = nullptr, *acc = nullptr, *ndof = nullptr;
     int n_groups = 0, feat_threads = 64;
-    size_t feat_lds = 0, gj_lds = 0;
-    int gj_use_lds = 0;
+    size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
+    int solve_use_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
@@ -165,9 +165,9 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
     DALLOC(h, h->block, ldh * ldh);
     DALLOC(h, h->Ab, ldh * ldh);
-    DALLOC(h, h->Aug, ldh * 2 * ldh);
+    DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
-    DALLOC(h, h->Pt1, PP); DALLOC(h, h->Pt2, PP);
+    DALLOC(h, h->Pt1, PP);
     DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
     DALLOC(h, h->nrows, d.Fu); DALLOC(h, h->acc, d.Fu); DALLOC(h, h->ndof, d.Fu);
     DALLOC(h, h->d_imu, RVIO_MAX_IMU);
@@ -206,12 +206,17 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     }
     if (h->feat_lds > 160 * 1024) { h->err = "per-feature LDS footprint exceeds 160 KiB"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
+    HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
-        const size_t ncol = 2 * ldh, ldm = ncol | 1;
-        h->gj_lds = (size_t)(d.ldh - 1) * ldm * sizeof(double);
-        h->gj_use_lds = h->gj_lds <= 150 * 1024;
-        if (!h->gj_use_lds) h->gj_lds = 0;
-        HIPCHK(h, hipFuncSetAttribute((const void*)gj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gj_lds));
+        const size_t c6m = ldh - 1, NC = 2 * c6m + 1, ldm = NC | 1;
+        h->solve_lds = c6m * ldm * sizeof(double);
+        h->solve_use_lds = h->solve_lds <= 150 * 1024;
+        if (h->solve_use_lds) HIPCHK(h, hipFuncSetAttribute((const void*)solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+        else { h->solve_lds = 0; DALLOC(h, h->Mg, ldh * 2 * ldh); }
+        const size_t c6t = (c6m + 15) / 16;
+        h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
+        HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
@@ -257,7 +262,7 @@ int rvio_hip_get_state(rvio_hip* h, double* x, int* xdim, double* P, int* d) {
     FilterMeta m;
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int n = m.n_clones, dd = 24 + 6 * n, xd = 26 + 7 * n;
+    const int n = h->n_clones_host, dd = 24 + 6 * n, xd = 26 + 7 * n;
     if (xdim) *xdim = xd;
     if (d) *d = dd;
     if (x) HIPCHK(h, hipMemcpyAsync(x, h->x[h->cur], sizeof(double) * xd, hipMemcpyDeviceToHost, h->stream));
@@ -310,7 +315,7 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 
 // ------------------------------------------------------------------ P1
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
-    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->x[h->cur], h->P[h->cur], d_imu, m);
+    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -344,47 +349,39 @@ static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
 
 static int update_local_dev(rvio_hip* h, int rank, int world) {
     const DevCfg& d = h->dc;
-    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, h->meta, h->x[h->cur], h->P[h->cur],
+    const int n = h->n_clones_host;
+    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global);
-    hipLaunchKernelGGL(gram_kernel, dim3(h->n_groups, (d.ldh - 1 + 15) / 16), dim3(256), 0, h->stream, d, h->meta, h->Hstack, h->nrows, h->partial);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (d.ldh * d.ldh + 255) / 256))), dim3(256), 0, h->stream, d, h->meta,
+    hipLaunchKernelGGL(gram_kernel, dim3(h->n_groups, (6 * n + 15) / 16), dim3(256), 0, h->stream, d, n, h->Hstack, h->nrows, h->partial);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256))), dim3(256), 0, h->stream, d, n,
                        h->partial, h->n_groups, h->nrows, h->block);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
 
-static void gemm(rvio_hip* h, int mode, int need_update, double alpha, const double* A, long sar, long sac, const double* B, long sbr, long sbc,
-                 double beta, const double* Cin, long scr, long scc, double* Cout, long sor, long soc) {
-    GemmArgs g;
-    g.A = A; g.sar = sar; g.sac = sac; g.B = B; g.sbr = sbr; g.sbc = sbc;
-    g.Cin = Cin; g.scr = scr; g.scc = scc; g.Cout = Cout; g.sor = sor; g.soc = soc;
-    g.alpha = alpha; g.beta = beta; g.mode = mode; g.need_update = need_update;
-    const int tiles = (h->dc.dmax + 31) / 32;
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3(tiles, tiles), dim3(256), 0, h->stream, h->meta, g);
-}
-
 static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     const DevCfg& d = h->dc;
-    const long ld = d.dmax, ldh = d.ldh, lda = 2 * ldh;
-    const double s2 = d.sigma_im * d.sigma_im;
+    const int n = h->n_clones_host, c6 = 6 * n, dd = 24 + c6;
+    const long ldh = d.ldh;
     double* Pc = h->P[h->cur];
     double* Pn = h->P[h->cur ^ 1];
-    const int eg = std::max(1, std::min(64, (int)((ldh * ldh + 255) / 256)));
-    hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, h->meta, d_blocks, world, (size_t)(ldh * ldh), h->Ab, h->Aug);
-    // T = s2 I + A Pcc                      (c6 x c6 x c6)
-    gemm(h, 2, 1, 1.0, h->Ab, ldh, 1, Pc + 24 + 24 * ld, 1, ld, 1.0, h->Aug, lda, 1, h->Aug, lda, 1);
-    hipLaunchKernelGGL(gj_kernel, dim3(1), dim3(1024), h->gj_lds, h->stream, d, h->meta, h->Aug, h->gj_use_lds);
-    hipLaunchKernelGGL(inject_kernel, dim3(1), dim3(256), 0, h->stream, d, h->meta, h->x[h->cur], Pc, h->Aug, h->x[h->cur ^ 1]);
-    // U = Pc W, G = U A  (K H = [0 | G]),  Joseph form (Updater.cc:615-619) in the information parametrisation:
-    //   P+ = (I-KH) P (I-KH)^T + s2 K K^T,  (I-KH)P = P - G Pc^T,  s2 K K^T = s2 G U^T
-    gemm(h, 0, 1, 1.0, Pc + 24 * ld, 1, ld, h->Aug + ldh, lda, 1, 0.0, nullptr, 0, 0, h->U, ldh, 1);
-    gemm(h, 0, 1, 1.0, h->U, ldh, 1, h->Ab, ldh, 1, 0.0, nullptr, 0, 0, h->G, ldh, 1);
-    gemm(h, 1, 1, -1.0, h->G, ldh, 1, Pc + 24 * ld, ld, 1, 1.0, Pc, 1, ld, h->Pt1, 1, ld);
-    gemm(h, 1, 1, -1.0, h->Pt1 + 24 * ld, 1, ld, h->G, 1, ldh, 1.0, h->Pt1, 1, ld, h->Pt2, 1, ld);
-    gemm(h, 1, 1, s2, h->G, ldh, 1, h->U, 1, ldh, 1.0, h->Pt2, 1, ld, h->Pt2, 1, ld);
-    const int sg = std::max(1, std::min(256, (int)((ld * ld + 255) / 256)));
-    hipLaunchKernelGGL(symm_out_kernel, dim3(sg), dim3(256), 0, h->stream, d, h->meta, h->Pt2, Pc, Pn);
+    const double* Ab = d_blocks;
+    if (world > 1) {   // sum the gathered [A|b] blocks in rank order
+        const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
+        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, n, d_blocks, world, (size_t)(ldh * ldh), h->Ab);
+        Ab = h->Ab;
+    }
+    const int tt = (c6 + 31) / 32;
+    hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf);
+    if (h->solve_use_lds)
+        hipLaunchKernelGGL(solve_kernel_lds, dim3(1), dim3(1024), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
+    else
+        hipLaunchKernelGGL(solve_kernel_glb, dim3(1), dim3(1024), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1], h->Mg);
+    // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
+    hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+    const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn);
     HIPCHK(h, hipGetLastError());
     h->cur ^= 1;
     return RVIO_OK;
@@ -440,12 +437,10 @@ int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, do
 static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const DevCfg& d = h->dc;
     const int c = h->cur, o = c ^ 1;
-    const int ag = std::max(1, std::min(256, (d.dmax * d.dmax + 255) / 256));
-    hipLaunchKernelGGL(augment_kernel, dim3(ag), dim3(256), 0, h->stream, d, h->meta, h->x[c], h->P[c], h->x[o], h->P[o], do_augment);
-    hipLaunchKernelGGL(meta_after_augment_kernel, dim3(1), dim3(64), 0, h->stream, d, h->meta, do_augment);
     const int cg = 1 + std::max(1, (6 * d.nmax + 255) / 256);
-    hipLaunchKernelGGL(compose_kernel, dim3(cg), dim3(256), 0, h->stream, d, h->meta, h->x[o], h->P[o], h->x[c], h->P[c], h->d_pose);
+    hipLaunchKernelGGL(augcomp_kernel, dim3(cg), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose);
     HIPCHK(h, hipGetLastError());
+    h->cur = o;
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
     return RVIO_OK;
 }
@@ -459,22 +454,23 @@ int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
 static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int b) {
     const DevCfg& d = h->dc;
     PyrDev& p = h->pyr[b];
-    HIPCHK(h, hipMemcpy2DAsync((void*)p.img[0], d.W, d_img, stride, d.W, d.H, hipMemcpyDeviceToDevice, h->stream));
-    for (int l = 1; l < d.levels; ++l)
-        hipLaunchKernelGGL(pyr_down_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, p.img[l - 1], p.w[l - 1], p.h[l - 1],
-                           p.w[l - 1], (uint8_t*)p.img[l], p.w[l], p.h[l]);
-    for (int l = 0; l < d.levels; ++l)
-        hipLaunchKernelGGL(scharr_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, p.img[l], p.w[l], p.h[l], p.w[l],
-                           (short*)p.dxy[l]);
+    // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
+    for (int l = 0; l < d.levels; ++l) {
+        const bool last = (l + 1 == d.levels);
+        const uint8_t* src = (l == 0) ? d_img : p.img[l];
+        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, src, p.w[l], p.h[l],
+                           (l == 0) ? stride : p.w[l], (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
+                           last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1]);
+    }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
 
 // everything after Tracker.cc:246; status/tracked already on the device
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2, h->t.status, d_imu, m,
-                       h->rng, h->cand_scratch, h->d_info);
-    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->t, d_cand, n_cand);
+    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), (size_t)5 * h->dc.F + 16, h->stream, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
+                       h->t.status, d_imu, m, h->rng, h->d_info);
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->stream, h->dc, h->t, d_cand, n_cand);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -603,7 +599,7 @@ int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    info->n_clones = m.n_clones; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
+    info->n_clones = h->n_clones_host; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
     info->reserved[0] = m.err;
     return RVIO_OK;
 }
