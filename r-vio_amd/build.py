@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librvio_hip.so")
-SOURCES = ["rvio_hip.hip", "filter_kernels.hip", "frontend_kernels.hip", "rvio_dev.h", "frontend_dev.h",
+SOURCES = ["rvio_hip.hip", "filter_kernels.hip", "filter_kernels2.hip", "solve4.hip", "frontend_kernels.hip", "rvio_dev.h", "frontend_dev.h",
            "chi2_table.inc", os.path.join("..", "..", "include", "rvio_hip.h")]
 
 
@@ -26,8 +26,8 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           os.path.join(CSRC, "rvio_hip.hip"), "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + \
+          os.environ.get("RVIO_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, "rvio_hip.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
     const double nG = cfg.gravity;
     double Dt = 0;
     const int r9 = tid / 24, c9 = tid % 24;  // valid for tid < 216
+    DBG_T(0);
     for (int s0 = 0; s0 < m; s0 += PROP_CH) {
         const int mc = (m - s0 < PROP_CH) ? (m - s0) : PROP_CH;
         // ---- phase A
+        DBG_T(1);
         if (tid < mc) {
             const rvio_imu u = imu[s0 + tid];
             const d3 w = sub3(mk3(u.w[0], u.w[1], u.w[2]), bg), a = sub3(mk3(u.a[0], u.a[1], u.a[2]), ba);
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
             st3(q.w, w); q.dt = dt;
         }
         __syncthreads();
+        DBG_T(2);
         // ---- phase B (every thread runs the same short chain: no broadcast needed)
         for (int s = 0; s < mc; ++s) {
             PropSample& q = sm[s];
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
             gk = unit3(mv33(Rk, gR));
         }
         __syncthreads();
+        DBG_T(3);
         // ---- phase C: Phi9[s][r][c] for all samples of the chunk
         for (int e = tid; e < mc * 216; e += 256) {
             const int s = e / 216, rc = e % 216, r = rc / 24, c = rc % 24;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
             if (rc < 9) vxs[s][rc] = skew33(ld3(q.vk)).m[rc];
         }
         __syncthreads();
+        DBG_T(4);
         // ---- phase D
         for (int s = 0; s < mc; ++s) {
             const double dt = sm[s].dt;
@@ -174,16 +179,19 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
             __syncthreads();
         }
     }
+    DBG_T(5);
     if (tid == 0) {
         stq(x + 10, r2q(Rk));
         st3(x + 14, pk);
         st3(x + 17, vk);
     }
+    DBG_T(6);
     // P11 back (symmetrised, PreIntegrator.cc:192); P22 is untouched and already symmetric
     for (int e = tid; e < 576; e += 256) {
         int i = e % 24, j = e / 24;
         P[i + (size_t)j * ld] = .5 * (Pl[i][j] + Pl[j][i]);
     }
+    DBG_T(7);
     // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191): one thread per clone column
     for (int c = tid; c < 6 * n; c += 256) {
         double col[24];
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* 
             P[(24 + c) + (size_t)i * ld] = acc;
         }
     }
+    DBG_T(8);
 }
 
 // =============================================================== U1..U5 per feature
@@ -253,32 +262,53 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
     const double sig = cfg.sigma_im, sig2 = sig * sig;
     const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
     const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
+    DBG_T(30);
     __syncthreads();
+    DBG_T(31);
 
-    // ---- U1 relative-pose chain (Updater.cc:114-141): serial, every lane of wave 0 runs it, lane 0 writes
+    // ---- U1 relative-pose chain (Updater.cc:114-141).  R(q_i) for every clone in parallel (lane <-> clone), the chain
+    // R_I(i) = R(q_i) R_I(i-1), t_I(i) = R(q_i) (t_I(i-1) - p_i) as a short serial product of 3x3 matrices, then the
+    // camera-frame poses in parallel again.  The reference carries the chain as normalised quaternions and passes
+    // R_c through RotToQuat/QuatToRot; both are the same rotations up to O(1e-16).
     if (wave0) {
         const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
-        q4 qI = ldq(rel);
-        d3 tI = scl3(-1.0, mv33(q2r(qI), ld3(rel + 4)));
+        if (lane < nPh) {
+            const m33 Rl = q2r(ldq(rel + 7 * lane));
+            double* o = pose + lane * 24 + 12;          // park R(q_i) in the Rc slot until the chain has consumed it
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = Rl.m[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        m33 RI = ldm33(pose + 12);
+        d3 tI = scl3(-1.0, mv33(RI, ld3(rel + 4)));
         for (int i = 0; i < nPh; ++i) {
             if (i > 0) {
-                q4 qi = ldq(rel + 7 * i);
-                tI = mv33(q2r(qi), sub3(tI, ld3(rel + 7 * i + 4)));
-                qI = qmul(qi, qI);
+                const m33 Ri = ldm33(pose + i * 24 + 12);
+                tI = mv33(Ri, sub3(tI, ld3(rel + 7 * i + 4)));
+                RI = mul33(Ri, RI);
             }
-            m33 RI = q2r(qI);
-            m33 RcRaw = mul33(mul33(Rci, RI), Ric);
-            q4 qC = r2q(RcRaw);
-            m33 Rc = q2r(qC);
-            d3 tC = add3(add3(mv33(mul33(Rci, RI), tic), mv33(Rci, tI)), tci);
             if (lane == 0) {
                 double* o = pose + i * 24;
-                for (int k = 0; k < 9; ++k) { o[k] = RI.m[k]; o[12 + k] = Rc.m[k]; }
-                st3(o + 9, tI); st3(o + 21, tC);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) o[k] = RI.m[k];
+                st3(o + 9, tI);
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nPh) {
+            double* o = pose + lane * 24;
+            const m33 RIl = ldm33(o);
+            const d3 tIl = ld3(o + 9);
+            const m33 RciRI = mul33(Rci, RIl);
+            const m33 Rc = mul33(RciRI, Ric);
+            const d3 tC = add3(add3(mv33(RciRI, tic), mv33(Rci, tIl)), tci);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[12 + k] = Rc.m[k];
+            st3(o + 21, tC);
         }
     }
     __syncthreads();
+    DBG_T(32);
 
     // ---- U2 inverse-depth LM triangulation (Updater.cc:143-269): lane i <-> observation i
     double phi = 0, psi = 0, rho = 0;
@@ -337,12 +367,13 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                 g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2);
                 if (cost <= lastCost) {
                     // damped normal equations, SPD 3x3: Cholesky solve (reference: colPivHouseholderQr, Updater.cc:239)
+                    // L D L^T (square-root free): 3 reciprocals instead of 3 sqrt + 9 divisions
                     const double a00 = c00 + lambda * c00, a11 = c11 + lambda * c11, a22 = c22 + lambda * c22;
-                    const double l00 = sqrt(a00), l10 = c01 / l00, l20 = c02 / l00;
-                    const double l11 = sqrt(a11 - l10 * l10), l21 = (c12 - l20 * l10) / l11;
-                    const double l22 = sqrt(a22 - l20 * l20 - l21 * l21);
-                    const double y0 = g0 / l00, y1 = (g1 - l10 * y0) / l11, y2 = (g2 - l20 * y0 - l21 * y1) / l22;
-                    const double d2 = y2 / l22, d1 = (y1 - l21 * d2) / l11, d0 = (y0 - l10 * d1 - l20 * d2) / l00;
+                    const double i0 = 1.0 / a00, l10 = c01 * i0, l20 = c02 * i0;
+                    const double dd1 = a11 - l10 * c01, i1 = 1.0 / dd1, l21 = (c12 - l20 * c01) * i1;
+                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = 1.0 / dd2;
+                    const double z0 = g0, z1 = g1 - l10 * z0, z2 = g2 - l20 * z0 - l21 * z1;
+                    const double d2 = z2 * i2, d1 = z1 * i1 - l21 * d2, d0 = z0 * i0 - l10 * d1 - l20 * d2;
                     phi += d0; psi += d1; rho += d2;
                     if (fabs(lastCost - cost) < 1e-6 && d2 < 1e-6) break;
                     lambda *= .1; lastCost = cost;
@@ -353,6 +384,7 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         if (lane == 0) { misc[0] = phi; misc[1] = psi; misc[2] = rho; misc[3] = valid ? 1.0 : 0.0; }
     }
     __syncthreads();
+    DBG_T(33);
     phi = misc[0]; psi = misc[1]; rho = misc[2]; valid = misc[3] != 0.0;
     if (tid == 0) { pfinv_out[3 * f] = phi; pfinv_out[3 * f + 1] = psi; pfinv_out[3 * f + 2] = rho; }
     if (!valid) {
@@ -412,6 +444,7 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { o[a * 6 + b] = left.m[3 * a + b]; o[a * 6 + 3 + b] = right.m[3 * a + b]; }
     }
     __syncthreads();
+    DBG_T(34);
     {   // all (i, j<i) 2x6 blocks, flattened over the workgroup
         const int nitems = (Lu * (Lu - 1) / 2) * 12;
         for (int e = tid; e < nitems; e += T) {
@@ -435,6 +468,7 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         if (lane < M2) { h0 = hf[lane * 3]; h1 = hf[lane * 3 + 1]; h2 = hf[lane * 3 + 2]; }
         if (sqrt(wave_sum(h2 * h2)) < 1e-4) N = 2;   // rank-deficient Hf (Updater.cc:374-378)
         double hc[3] = {h0, h1, h2};
+        double vv[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             double v = 0, beta = 0;
@@ -455,89 +489,126 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                 }
             }
             if (lane < M2max) vh[k * M2max + lane] = v;
-            if (lane == 0) misc[4 + k] = beta;
+            vv[k] = v; bb[k] = beta;
         }
-        if (lane == 0) misc[7] = (double)N;
+        // compact WY:  H0 H1 H2 = I - V T V^T  (T upper triangular), so the sweep H2 H1 H0 X = X - V T^T (V^T X)
+        const double d01 = wave_sum(vv[0] * vv[1]), d02 = wave_sum(vv[0] * vv[2]), d12 = wave_sum(vv[1] * vv[2]);
+        if (lane == 0) {
+            const double T00 = bb[0], T11 = bb[1], T22 = bb[2];
+            const double T01 = -bb[1] * T00 * d01;
+            const double T02 = -bb[2] * (T00 * d02 + T01 * d12), T12 = -bb[2] * T11 * d12;
+            misc[7] = (double)N;
+            misc[9] = T00; misc[10] = T01; misc[11] = T02; misc[12] = T11; misc[13] = T12; misc[14] = T22;
+        }
     }
     __syncthreads();
+    DBG_T(35);
     N = (int)misc[7];
     {
         const int nact = (cHi - cLo) + 1;   // active columns + the residual column
+        const double T00 = misc[9], T01 = misc[10], T02 = misc[11], T11 = misc[12], T12 = misc[13], T22 = misc[14];
+        const double *v0 = vh, *v1 = vh + M2max, *v2 = vh + 2 * M2max;
         for (int e = tid; e < nact; e += T) {
             const int c = (e < cHi - cLo) ? (cLo + e) : c6;
-            for (int k = 0; k < N; ++k) {
-                const double beta = misc[4 + k];
-                const double* v = vh + k * M2max;
-                double wdot = 0;
-                for (int i = k; i < M2; ++i) wdot += v[i] * Hx[(size_t)i * ldh + c];
-                wdot *= beta;
-                for (int i = k; i < M2; ++i) Hx[(size_t)i * ldh + c] -= wdot * v[i];
-            }
+            double w0 = 0, w1 = 0, w2 = 0;
+            for (int i = 0; i < M2; ++i) { const double hv = Hx[(size_t)i * ldh + c]; w0 += v0[i] * hv; w1 += v1[i] * hv; w2 += v2[i] * hv; }
+            const double u0 = T00 * w0, u1 = T01 * w0 + T11 * w1, u2 = T02 * w0 + T12 * w1 + T22 * w2;
+            for (int i = 0; i < M2; ++i) Hx[(size_t)i * ldh + c] -= v0[i] * u0 + v1[i] * u1 + v2[i] * u2;
         }
     }
     __syncthreads();
+    DBG_T(36);
     // ---- U5 Mahalanobis gate (Updater.cc:404-422) on rows N..M2-1
     const int rr = M2 - N;             // nDOF
     const double* Hn = Hx + (size_t)N * ldh;
     const int wa = cHi - cLo;          // active width
-    // Tm = Hn * Pcc restricted to the active clone range; Pcc[k][c] read as its mirror (coalesced)
-    for (int e = tid; e < wa; e += T) {
-        const int c = cLo + e;
-        const double* pcol = P + (size_t)(24 + c) + (size_t)(24 + cLo) * ld;   // P[(24+c),(24+cLo+k)]
-        for (int i0 = 0; i0 < rr; i0 += 20) {
-            double acc[20];
+    // Tm = Hn * Pcc restricted to the active clone range, on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+    //   A[i][k] = Hn[i][cLo+k] (LDS),  B[k][j] = Pcc[cLo+k][cLo+j] read as its mirror P[24+cLo+j, 24+cLo+k] (coalesced)
+    const int nwv = T >> 6, wvid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    {
+        const int nit = (rr + 15) / 16, njt = (wa + 15) / 16;
+        for (int t = wvid; t < nit * njt; t += nwv) {
+            const int it = t / njt, jt = t % njt;
+            const int ai = it * 16 + li, bj = jt * 16 + li;
+            const bool aok = ai < rr, bok = bj < wa;
+            const double* ap = Hn + (size_t)ai * ldh + cLo;
+            const double* bp = P + (size_t)(24 + cLo + bj) + (size_t)(24 + cLo) * ld;
+            d4 acc = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < wa; k0 += 16) {
+                double a[4], b[4];
 #pragma unroll
-            for (int ii = 0; ii < 20; ++ii) acc[ii] = 0;
-            for (int k = 0; k < wa; ++k) {
-                const double pv = pcol[(size_t)k * ld];
-                const double* hk = Hn + (size_t)i0 * ldh + cLo + k;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 4 * u + lk;
+                    a[u] = (aok && k < wa) ? ap[k] : 0.0;
+                    b[u] = (bok && k < wa) ? bp[(size_t)k * ld] : 0.0;
+                }
 #pragma unroll
-                for (int ii = 0; ii < 20; ++ii) if (i0 + ii < rr) acc[ii] += hk[(size_t)ii * ldh] * pv;
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int ii = 0; ii < 20; ++ii) if (i0 + ii < rr) Tm[(size_t)(i0 + ii) * ldh + c] = acc[ii];
+            for (int r = 0; r < 4; ++r) {
+                const int row = it * 16 + lk + 4 * r;
+                if (row < rr && bj < wa) Tm[(size_t)row * ldh + cLo + bj] = acc[r];
+            }
         }
     }
     __syncthreads();
+    DBG_T(37);
+    // S = Tm Hn^T + sig2 I  (lower triangle stands for the symmetrised matrix .5 (S + S^T), Updater.cc:418)
     const int lds_s = rhomax + 1;
-    for (int e = tid; e < (rr + 1) * rr; e += T) {
-        const int i = e / rr, j = e % rr;   // row i (i == rr: the residual row), col j <= i
-        if (i < rr) {
-            if (j > i) continue;
-            double acc = 0;
-            const double* ti = Tm + (size_t)i * ldh + cLo;
-            const double* hj = Hn + (size_t)j * ldh + cLo;
-            for (int c = 0; c < wa; ++c) acc += ti[c] * hj[c];
-            // the lower triangle stands for the symmetrised matrix .5 (S + S^T) (Updater.cc:418)
-            if (i == j) acc += sig2;
-            S[i * lds_s + j] = acc;
-        } else {
-            S[rr * lds_s + j] = Hn[(size_t)j * ldh + c6];
+    {
+        const int nit = (rr + 15) / 16;
+        for (int t = wvid; t < nit * nit; t += nwv) {
+            const int it = t / nit, jt = t % nit;
+            if (jt > it) continue;
+            const int ai = it * 16 + li, bj = jt * 16 + li;
+            const bool aok = ai < rr, bok = bj < rr;
+            const double* ap = Tm + (size_t)ai * ldh + cLo;
+            const double* bp = Hn + (size_t)bj * ldh + cLo;
+            d4 acc = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < wa; k0 += 16) {
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 4 * u + lk;
+                    a[u] = (aok && k < wa) ? ap[k] : 0.0;
+                    b[u] = (bok && k < wa) ? bp[k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = it * 16 + lk + 4 * r;
+                if (row < rr && bj < rr && bj <= row) S[row * lds_s + bj] = acc[r] + ((row == bj) ? sig2 : 0.0);
+            }
         }
+        for (int j = tid; j < rr; j += T) S[rr * lds_s + j] = Hn[(size_t)j * ldh + c6];   // residual as an extra row
     }
     __syncthreads();
-    // Cholesky of S with the residual appended as an extra row: its entries become y = L^-1 r,
-    // gamma = |r^T S^-1 r| = y^T y.  (reference: colPivHouseholderQr().solve, Updater.cc:420)
-    for (int k = 0; k < rr; ++k) {
-        const double dkk = S[k * lds_s + k];
-        const double lkk = sqrt(dkk > 0 ? dkk : 1e-300);
-        __syncthreads();
-        for (int i = k + tid; i <= rr; i += T) S[i * lds_s + k] = (i == k) ? lkk : S[i * lds_s + k] / lkk;
-        __syncthreads();
-        for (int i = k + 1 + tid; i <= rr; i += T) {
-            const double lik = S[i * lds_s + k];
-            const int jmax = (i < rr) ? i : rr - 1;
-            for (int j = k + 1; j <= jmax; ++j) S[i * lds_s + j] -= lik * S[j * lds_s + k];
-        }
-        __syncthreads();
-    }
+    DBG_T(38);
+    // gamma = |r^T S^-1 r| by a square-root-free L D L^T of S with the residual row appended (reference:
+    // colPivHouseholderQr().solve, Updater.cc:420).  Columns stay unscaled (S[i][k] = l_ik d_k), so the residual row
+    // carries w = L^-1 r and gamma = sum_k w_k^2 / d_k.  Wave 0 only, lane <-> row: no block barriers.
     double gam = 0;
     if (wave0) {
-        double part = 0;
-        for (int k = lane; k < rr; k += 64) { double y = S[rr * lds_s + k]; part += y * y; }
-        gam = fabs(wave_sum(part));
+        double gsum = 0;
+        const int i = lane;
+        for (int k = 0; k < rr; ++k) {
+            const double dk = S[k * lds_s + k];
+            const double rd = 1.0 / (dk > 0 ? dk : 1e-300);
+            double fik = 0;
+            if (i > k && i <= rr) fik = S[i * lds_s + k] * rd;
+            if (i == rr) gsum += S[rr * lds_s + k] * fik;
+            const int jmax = (i < rr) ? i : rr - 1;
+            if (i > k && i <= rr)
+                for (int j = k + 1; j <= jmax; ++j) S[i * lds_s + j] -= fik * S[j * lds_s + k];
+            __builtin_amdgcn_wave_barrier();
+        }
+        gam = fabs(__shfl(gsum, rr, 64));
         if (lane == 0) misc[8] = gam;
     }
+    DBG_T(39);
     __syncthreads();
     gam = misc[8];
     const bool accept = gam < kChi2Dev[rr - 1];
@@ -546,6 +617,7 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         double* out = Hstack + (size_t)f * rhomax * ldh;
         for (int e = tid; e < rr * ldh; e += T) out[e] = Hn[e];
     }
+    DBG_T(40);
 }
 
 // =============================================================== U7 compression, information form
@@ -936,10 +1008,12 @@ __global__ __launch_bounds__(256) void augcomp_kernel(DevCfg cfg, int n, int do_
     const int n2 = do_aug ? ((n < nmax) ? n + 1 : nmax) : n;
     const int d2 = 24 + 6 * n2, xd2 = 26 + 7 * n2;
     const int tid = threadIdx.x;
+    DBG_T(20);
     if (tid < 26) xs[tid] = x[tid];
     if (blockIdx.x == 0) for (int e = tid; e < 576; e += 256) P11[e % 24][e / 24] = P[(size_t)(e % 24) + (size_t)(e / 24) * ld];
     for (int e = tid; e < 576; e += 256) Vk[e / 24][e % 24] = 0.0;
     __syncthreads();
+    DBG_T(21);
     const q4 qG = ldq(xs), qk = ldq(xs + 10);
     const d3 pG = ld3(xs + 4), pk = ld3(xs + 14);
     const m33 RG = q2r(qG), Rk = q2r(qk);
@@ -955,11 +1029,14 @@ __global__ __launch_bounds__(256) void augcomp_kernel(DevCfg cfg, int n, int do_
         Vk[15 + tid][15 + tid] = 1.0;
     }
     __syncthreads();
+    DBG_T(22);
     if (blockIdx.x == 0) {
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Vk[i][k] * P11[k][j]; Tm[i][j] = a; }
         __syncthreads();
+        DBG_T(23);
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Tm[i][k] * Vk[j][k]; P11[i][j] = a; }
         __syncthreads();
+        DBG_T(24);
         for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; P_out[(size_t)i + (size_t)j * ld] = .5 * (P11[i][j] + P11[j][i]); }
         // state: augmentation (System.cc:282-287,303-306) then composition (System.cc:360-365)
         for (int i = tid; i < xd2; i += 256) {
@@ -986,6 +1063,7 @@ __global__ __launch_bounds__(256) void augcomp_kernel(DevCfg cfg, int n, int do_
             const d3 pGk = mv33(tr33(RG), sub3(pk, pG));
             st3(pose_out, pGk); stq(pose_out + 3, qkG);
         }
+        DBG_T(25);
     } else {
         const int c6 = 6 * n2;
         for (int c = (blockIdx.x - 1) * 256 + tid; c < c6; c += (gridDim.x - 1) * 256) {

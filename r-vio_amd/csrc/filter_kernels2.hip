@@ -1,0 +1,511 @@
+// filter_kernels2.hip — second-generation single-workgroup kernels of the filter path
+// (replace propagate_kernel / solve_kernel_* / augcomp_kernel of filter_kernels.hip).
+// Rules applied (profiles/r01_*): no dynamic indexing of register arrays (it lands in scratch),
+// __restrict__ on every pointer, sparsity of Phi / Vk exploited (the LDS port of ONE CU is the
+// limiter), no loops over dependent global loads.
+#pragma once
+#include "rvio_dev.h"
+
+// skew(v)[i][j] with v in LDS (dynamic indexing is fine there):  [[0,-z,y],[z,0,-x],[-y,x,0]]
+__device__ __forceinline__ double skew_e(const double* v, int i, int j) {
+    if (i == j) return 0.0;
+    const double e = v[3 - i - j];
+    return (j == (i + 1) % 3) ? -e : e;
+}
+
+// =============================================================== P1 propagate (v3)
+// One workgroup, 256 threads.
+//  A  lane s <-> IMU sample s: trig, dR, f1..f4 and the two a-dependent vectors (parallel)
+//  B  the serial chain Rk <- dR Rk, dp, dv, pk, vk, gk in reference order (all threads, no broadcast)
+//  C  the ten non-trivial 3x3 blocks of rows 9..17 of Phi = I + dt F (PreIntegrator.cc:123-132), thread <-> (sample, i, j)
+//  D  per sample: rows 9..17 of Phi P and of Phi Psi, then columns 9..17 of (Phi P) Phi^T + Q — using only the
+//     4 / 7 / 13 non-zeros of a theta / p / v row of Phi
+#define PROP3_CH 16
+struct Prop3Sample { double dR[9], up[3], uv[3], w[3], dt, Rk[9], vk[3], gk[3]; };
+
+__global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                                         double* __restrict__ P, const rvio_imu* __restrict__ imu, int m) {
+    __shared__ double Pl[24][25];
+    __shared__ double Psi[24][25];
+    __shared__ double Phi9[PROP3_CH][9][25];
+    __shared__ double vxs[PROP3_CH][9];
+    __shared__ Prop3Sample sm[PROP3_CH];
+    __shared__ double xs[26];
+    const int tid = threadIdx.x;
+    const int ld = cfg.dmax;
+    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }
+    for (int e = tid; e < 576; e += 256) {
+        int i = e % 24, j = e / 24;
+        Pl[i][j] = P[i + (size_t)j * ld];
+        Psi[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid < 26) xs[tid] = x[tid];
+    __syncthreads();
+    const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
+    const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
+    m33 Rk = q2r(ldq(xs + 10)), RkT = tr33(Rk);
+    d3 pk = ld3(xs + 14), vk = vR, gk = gR;
+    d3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
+    const m33 I = eye33();
+    const double nG = cfg.gravity;
+    double Dt = 0;
+    // this thread's (row r9 of Phi rows 9..17, column c9) and the non-zero k-segments of that row
+    const int r9 = tid / 24, c9 = tid % 24, br = r9 / 3, ri = r9 % 3;
+    int sA0, sAn, sB0, sBn, sC0, sCn;
+    if (br == 0) { sA0 = 9; sAn = 3; sB0 = 18 + ri; sBn = 1; sC0 = 0; sCn = 0; }
+    else if (br == 1) { sA0 = 9; sAn = 3; sB0 = 12 + ri; sBn = 1; sC0 = 15; sCn = 3; }
+    else { sA0 = 6; sAn = 6; sB0 = 15; sBn = 6; sC0 = 21 + ri; sCn = 1; }
+    for (int s0 = 0; s0 < m; s0 += PROP3_CH) {
+        const int mc = (m - s0 < PROP3_CH) ? (m - s0) : PROP3_CH;
+        // ---- A
+        if (tid < mc) {
+            const rvio_imu u = imu[s0 + tid];
+            const d3 w = sub3(mk3(u.w[0], u.w[1], u.w[2]), bg), a = sub3(mk3(u.a[0], u.a[1], u.a[2]), ba);
+            const double dt = u.dt, w1 = nrm3(w);
+            const bool small = w1 < cfg.small_angle;
+            const double wdt = w1 * dt, wdt2 = wdt * wdt;
+            double sw, cw;
+            sincos(wdt, &sw, &cw);
+            const m33 wx = skew33(w), wx2 = mul33(wx, wx);
+            m33 dR; double f1, f2, f3, f4;
+            if (small) {
+                dR = add33(sub33(I, scl33(dt, wx)), scl33(dt * dt / 2, wx2));
+                f1 = -(dt * dt * dt) / 3; f2 = (dt * dt * dt * dt) / 8; f3 = -(dt * dt) / 2; f4 = (dt * dt * dt) / 6;
+            } else {
+                const double w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
+                dR = add33(sub33(I, scl33(sw / w1, wx)), scl33((1 - cw) / w2, wx2));
+                f1 = (wdt * cw - sw) / w3;
+                f2 = .5 * (wdt2 - 2 * cw - 2 * wdt * sw + 2) / w4;
+                f3 = (cw - 1) / w2;
+                f4 = (wdt - sw) / w3;
+            }
+            Prop3Sample& q = sm[tid];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q.dR[k] = dR.m[k];
+            st3(q.up, mv33(add33(add33(scl33(.5 * dt * dt, I), scl33(f1, wx)), scl33(f2, wx2)), a));
+            st3(q.uv, mv33(add33(add33(scl33(dt, I), scl33(f3, wx)), scl33(f4, wx2)), a));
+            st3(q.w, w); q.dt = dt;
+        }
+        __syncthreads();
+        // ---- B
+        for (int s = 0; s < mc; ++s) {
+            Prop3Sample& q = sm[s];
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) q.Rk[k] = Rk.m[k];
+                st3(q.vk, vk); st3(q.gk, gk);
+            }
+            const double dt = q.dt;
+            Dt += dt;
+            Rk = mul33(ldm33(q.dR), Rk); RkT = tr33(Rk);
+            dp = add3(dp, scl3(dt, dv));
+            dp = add3(dp, mv33(RkT, ld3(q.up)));
+            dv = add3(dv, mv33(RkT, ld3(q.uv)));
+            pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
+            vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
+            gk = unit3(mv33(Rk, gR));
+        }
+        __syncthreads();
+        // ---- C: thread <-> (sample s, i, j)
+        for (int e = tid; e < mc * 9; e += 256) {
+            const int s = e / 9, i = (e % 9) / 3, j = e % 3;
+            const Prop3Sample& q = sm[s];
+            const double dt = q.dt, id = (i == j) ? 1.0 : 0.0;
+            const double wxe = skew_e(q.w, i, j), vxe = skew_e(q.vk, i, j), gxe = skew_e(q.gk, i, j);
+            const double rtv = q.Rk[i] * skew_e(q.vk, 0, j) + q.Rk[3 + i] * skew_e(q.vk, 1, j) + q.Rk[6 + i] * skew_e(q.vk, 2, j);   // (Rk^T [v]x)(i,j)
+            double (*ph)[25] = Phi9[s];
+            ph[i][9 + j] = id - dt * wxe;       ph[i][18 + j] = -dt * id;
+            ph[3 + i][9 + j] = -dt * rtv;       ph[3 + i][12 + j] = id;           ph[3 + i][15 + j] = dt * q.Rk[3 * j + i];
+            ph[6 + i][6 + j] = -dt * nG * q.Rk[3 * i + j];
+            ph[6 + i][9 + j] = -dt * nG * gxe;  ph[6 + i][15 + j] = id - dt * wxe;
+            ph[6 + i][18 + j] = -dt * vxe;      ph[6 + i][21 + j] = -dt * id;
+            vxs[s][3 * i + j] = vxe;
+        }
+        __syncthreads();
+        // ---- D
+        for (int s = 0; s < mc; ++s) {
+            const double dt = sm[s].dt;
+            const double (*ph)[25] = Phi9[s];
+            double accP = 0, accS = 0;
+            if (tid < 216) {
+                for (int k = sA0; k < sA0 + sAn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
+                for (int k = sB0; k < sB0 + sBn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
+                for (int k = sC0; k < sC0 + sCn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
+            }
+            __syncthreads();
+            if (tid < 216) { Pl[9 + r9][c9] = accP; Psi[9 + r9][c9] = accS; }
+            __syncthreads();
+            double accC = 0;
+            if (tid < 216) {
+                for (int k = sA0; k < sA0 + sAn; ++k) accC += Pl[c9][k] * ph[r9][k];
+                for (int k = sB0; k < sB0 + sBn; ++k) accC += Pl[c9][k] * ph[r9][k];
+                for (int k = sC0; k < sC0 + sCn; ++k) accC += Pl[c9][k] * ph[r9][k];
+                // Q = dt G Sigma G^T (PreIntegrator.cc:135-140), non-zero blocks only
+                const int i = c9, j = 9 + r9;
+                const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
+                const double* vx = vxs[s];
+                if (bi == 3 && bj == 3) accC += (ii == jj) ? dt * cfg.sg2 : 0.0;
+                else if (bi == 3 && bj == 5) accC += dt * cfg.sg2 * vx[3 * jj + ii];
+                else if (bi == 5 && bj == 3) accC += dt * cfg.sg2 * vx[3 * ii + jj];
+                else if (bi == 5 && bj == 5) {
+                    double q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] +
+                               ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
+                    if (ii == jj) q += dt * cfg.sa2;
+                    accC += q;
+                }
+            }
+            __syncthreads();
+            if (tid < 216) Pl[c9][9 + r9] = accC;
+            if (tid >= 216 && tid < 219) Pl[18 + tid - 216][18 + tid - 216] += dt * cfg.swg2;
+            if (tid >= 219 && tid < 222) Pl[21 + tid - 219][21 + tid - 219] += dt * cfg.swa2;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        stq(x + 10, r2q(Rk));
+        st3(x + 14, pk);
+        st3(x + 17, vk);
+    }
+    // P11 back (symmetrised, PreIntegrator.cc:192); P22 is untouched and already symmetric
+    for (int e = tid; e < 576; e += 256) {
+        int i = e % 24, j = e / 24;
+        P[i + (size_t)j * ld] = .5 * (Pl[i][j] + Pl[j][i]);
+    }
+    // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191).  Rows of Psi outside 9..17 are identity rows,
+    // so only rows 9..17 of each clone column change: one thread per column, 24 loads, 9 outputs (+ mirror).
+    for (int c = tid; c < 6 * n; c += 256) {
+        double* pc = P + (size_t)(24 + c) * ld;
+        double col[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) col[k] = pc[k];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double acc = 0;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) acc += Psi[9 + r][k] * col[k];
+            pc[9 + r] = acc;
+            P[(24 + c) + (size_t)(9 + r) * ld] = acc;
+        }
+    }
+}
+
+// =============================================================== solve (v3): W = T^-1, y = W b, dx, x+
+// One workgroup of 256 threads (4 waves = one per SIMD).  IN-PLACE Gauss-Jordan inversion of T with partial
+// pivoting on the tableau M = [T | b]  (c6 x (c6+1), LDS or global scratch):
+//   * no row swaps: step k uses the not-yet-used row p_k with the largest |M[i][k]| as pivot row;
+//   * deferred pivot scaling: a pivot row is kept unscaled (its factor 1/piv_k is applied when reading the result);
+//   * for every other row i:  f = M[i][k]/piv;  M[i][j] -= f M[p][j] (j != k);  M[i][k] = -f;   M[p][k] := 1;
+//   * lane <-> column, wave <-> a quarter of the rows; the arg-max for column k+1 is folded into the elimination
+//     of step k (each wave reduces over its own rows, 4 partial results meet in LDS), so there is ONE barrier
+//     per column and no separate search pass.
+// Result: T^-1[k][p_j] = M[p_k][j] / piv_k,   y[k] = M[p_k][c6] / piv_k.
+#define SOLVE3_T 512
+#define SOLVE3_NW (SOLVE3_T / 64)
+template <bool USE_LDS>
+__device__ __forceinline__ void solve3_body(const DevCfg& cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
+                                            const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
+                                            double* __restrict__ Wout, double* __restrict__ x_out, double* __restrict__ Mg, double* sh) {
+    __shared__ int s_prow[6 * RVIO_MAX_LEN], s_invp[6 * RVIO_MAX_LEN];
+    __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
+    __shared__ double s_y[6 * RVIO_MAX_LEN];
+    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    __shared__ double s_cv[2][SOLVE3_NW];    // per-wave candidate |value| for the next pivot (double-buffered by step parity)
+    __shared__ int s_ci[2][SOLVE3_NW];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NC = c6 + 1;
+    const int ldm = USE_LDS ? (NC | 1) : (2 * ldh);
+    double* M = USE_LDS ? sh : Mg;
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    DBG_T(40);
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += SOLVE3_T) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += SOLVE3_T) x_out[i] = x[i];
+        return;
+    }
+    // rows of the tableau are dealt round-robin to the waves: row i belongs to wave i % SOLVE3_NW
+    for (int i = wv; i < c6; i += SOLVE3_NW)
+        for (int j = lane; j < NC; j += 64) M[(size_t)i * ldm + j] = (j < c6) ? Tg[(size_t)i * ldh + j] : Ab[(size_t)i * ldh + c6];
+    const int nrw = (c6 > wv) ? (c6 - wv + SOLVE3_NW - 1) / SOLVE3_NW : 0;   // rows owned by this wave: i = wv + NW*q, q < nrw
+    unsigned long long usedmask = 0;                                        // bit q: row wv + NW*q was a pivot row already
+    __syncthreads();
+    // first pivot: arg-max of column 0 over this wave's rows
+    {
+        double best = -1.0; int bi = 0;
+        for (int i = wv; i < c6; i += SOLVE3_NW) { const double v = fabs(M[(size_t)i * ldm]); if (v > best) { best = v; bi = i; } }
+        if (lane == 0) { s_cv[0][wv] = best; s_ci[0][wv] = bi; }
+    }
+    __syncthreads();
+    int ppr = -1;   // pivot row of the previous step: its column entry becomes 1 (stored form of 1/piv) only now,
+                    // after the barrier, when no wave can still be reading the old pivot value
+    DBG_T(41);
+    for (int k = 0; k < c6; ++k) {
+        const int par = k & 1;
+        if (k == 1) DBG_T(42);
+        if (k == 2) DBG_T(43);
+        if (k == 32) DBG_T(44);
+        if (ppr >= 0 && (ppr % SOLVE3_NW) == wv && lane == ((k - 1) & 63)) M[(size_t)ppr * ldm + (k - 1)] = 1.0;
+        // combine the per-wave candidates (ties -> smallest row index, like a serial top-down scan)
+        double best = s_cv[par][0]; int pr = s_ci[par][0];
+#pragma unroll
+        for (int w = 1; w < SOLVE3_NW; ++w) { const double v = s_cv[par][w]; const int ii = s_ci[par][w]; if (v > best || (v == best && ii < pr)) { best = v; pr = ii; } }
+        ppr = pr;
+        const double piv = M[(size_t)pr * ldm + k];
+        const double ipiv = 1.0 / piv;
+        if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if (!(best > 0)) meta->err |= 1; }
+        // pivot-row values for this lane's columns
+        double prv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; prv[u] = (j < NC) ? M[(size_t)pr * ldm + j] : 0.0; }
+        // eliminate this wave's rows, 8 rows in flight (all LDS loads of a batch are issued before the first use);
+        // the arg-max of column k+1 among not-yet-used rows is tracked on the fly by the lane that owns that column
+        if ((pr % SOLVE3_NW) == wv) usedmask |= 1ull << (pr / SOLVE3_NW);
+        double nbest = -1.0; int nbi = 0;
+        for (int q0 = 0; q0 < nrw; q0 += 8) {
+            double fb[8], mv[8][3];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int q = q0 + b, i = wv + SOLVE3_NW * q;
+                const bool ok = q < nrw;
+                fb[b] = ok ? M[(size_t)i * ldm + k] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; mv[b][u] = (ok && j < NC) ? M[(size_t)i * ldm + j] : 0.0; }
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int q = q0 + b, i = wv + SOLVE3_NW * q;
+                const bool live = (q < nrw) && (i != pr);
+                const double f = fb[b] * ipiv;
+                const bool unused = !((usedmask >> q) & 1ull);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int j = lane + 64 * u;
+                    const double nv = (j == k) ? -f : (mv[b][u] - f * prv[u]);
+                    if (live && j < NC) M[(size_t)i * ldm + j] = nv;
+                    const double av = fabs(nv);
+                    if (live && unused && j == k + 1 && av > nbest) { nbest = av; nbi = i; }
+                }
+            }
+        }
+        // the lane that owns column k+1 publishes this wave's candidate
+        if (k + 1 < c6 && lane == ((k + 1) & 63)) { s_cv[par ^ 1][wv] = nbest; s_ci[par ^ 1][wv] = nbi; }
+        __syncthreads();
+    }
+    DBG_T(45);
+    if ((ppr % SOLVE3_NW) == wv && lane == ((c6 - 1) & 63)) M[(size_t)ppr * ldm + (c6 - 1)] = 1.0;
+    __syncthreads();
+    // read the result out: W[k][p_j] = M[p_k][j] * ipiv_k ;  y[k] = M[p_k][c6] * ipiv_k
+    for (int e = tid; e < c6 * c6; e += SOLVE3_T) {
+        const int k = e / c6, c = e % c6;
+        Wout[(size_t)k * ldh + c] = M[(size_t)s_prow[k] * ldm + s_invp[c]] * s_ipiv[k];
+    }
+    for (int k = tid; k < c6; k += SOLVE3_T) s_y[k] = M[(size_t)s_prow[k] * ldm + c6] * s_ipiv[k];
+    __syncthreads();
+    DBG_T(46);
+    // dx = K r = Pc y   (Updater.cc:544)
+    for (int i = tid; i < d; i += SOLVE3_T) {
+        double acc = 0;
+        for (int k = 0; k < c6; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
+        s_dx[i] = acc;
+    }
+    __syncthreads();
+    // state injection (Updater.cc:546-613)
+    DBG_T(47);
+    const double* dx = s_dx;
+    if (tid == 0) {
+        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
+        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
+        st3(x_out + 7, unit3(ld3(x_out + 7)));
+        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
+        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
+    }
+    for (int p = tid - 64; p >= 0 && p < n; p += SOLVE3_T - 64) {
+        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
+        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
+    }
+}
+__global__ __launch_bounds__(SOLVE3_T) void solve3_kernel_lds(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
+                                                               const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
+                                                               double* __restrict__ Wout, double* __restrict__ x_out) {
+    extern __shared__ __align__(16) double sh[];
+    solve3_body<true>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, nullptr, sh);
+}
+__global__ __launch_bounds__(SOLVE3_T) void solve3_kernel_glb(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
+                                                               const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
+                                                               double* __restrict__ Wout, double* __restrict__ x_out, double* __restrict__ Mg) {
+    solve3_body<false>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, Mg, nullptr);
+}
+
+// =============================================================== S1 + S2 fused (v2): augmentation/slide + composition
+// System.cc:279-365.  J P J^T with J = [I; rows 9..14] is a gather (out[a][b] = P[src(a)][src(b)]); composition
+// multiplies the first 24 rows/columns by Vk, which is sparse: rows 0..8 have 4 / 9 / 6 non-zeros, rows 9..14 are
+// zero, rows 15..23 are identity rows.  Out-of-place (reads cur, writes cur^1).
+//   block 0      : the 24x24 corner Vk P11 Vk^T (symmetrised) + the state vector + the pose line
+//   blocks 1..   : every other entry, one thread per entry (coalesced along the column)
+__device__ __forceinline__ int aug_src2(int a, int n, int nmax, int do_aug) {
+    if (a < 24 || !do_aug) return a;
+    const int cb = (a - 24) / 6, off = (a - 24) % 6;
+    if (n < nmax) return (cb < n) ? a : 9 + off;
+    return (cb < nmax - 1) ? a + 6 : 9 + off;
+}
+__global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do_aug, const double* __restrict__ x, const double* __restrict__ P,
+                                                       double* __restrict__ x_out, double* __restrict__ P_out, double* __restrict__ pose_out) {
+    __shared__ double Vk[24][25];
+    __shared__ double P11[24][25];
+    __shared__ double Tm[24][25];
+    __shared__ double xs[26];
+    __shared__ double xo[17];
+    const int nmax = cfg.nmax, ld = cfg.dmax;
+    const int n2 = do_aug ? ((n < nmax) ? n + 1 : nmax) : n;
+    const int d2 = 24 + 6 * n2, xd2 = 26 + 7 * n2;
+    const int tid = threadIdx.x;
+    if (tid < 26) xs[tid] = x[tid];
+    if (blockIdx.x == 0) for (int e = tid; e < 576; e += 256) P11[e % 24][e / 24] = P[(size_t)(e % 24) + (size_t)(e / 24) * ld];
+    for (int e = tid; e < 576; e += 256) Vk[e / 24][e % 24] = 0.0;
+    __syncthreads();
+    if (tid < 64) {   // one wave builds Vk (System.cc:344-353) and the composed head of the state
+        const q4 qG = ldq(xs), qk = ldq(xs + 10);
+        const d3 pG = ld3(xs + 4), pk = ld3(xs + 14);
+        const m33 Rk = q2r(qk);
+        const d3 gk = unit3(mv33(Rk, ld3(xs + 7)));
+        const d3 pkG = mv33(Rk, sub3(pG, pk));
+        if (tid == 0) {
+            const m33 spx = skew33(pkG), sgx = skew33(gk);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    Vk[i][j] = Rk.m[3 * i + j];           Vk[i][9 + j] = (i == j) ? 1.0 : 0.0;
+                    Vk[3 + i][3 + j] = Rk.m[3 * i + j];   Vk[3 + i][9 + j] = spx.m[3 * i + j];   Vk[3 + i][12 + j] = -Rk.m[3 * i + j];
+                    Vk[6 + i][6 + j] = Rk.m[3 * i + j];   Vk[6 + i][9 + j] = sgx.m[3 * i + j];
+                }
+#pragma unroll
+            for (int i = 15; i < 24; ++i) Vk[i][i] = 1.0;
+            if (blockIdx.x == 0) {
+                const q4 qkG = qmul(qk, qG);
+                stq(xo, qkG); st3(xo + 4, pkG); st3(xo + 7, gk);
+                xo[10] = 0; xo[11] = 0; xo[12] = 0; xo[13] = 1; xo[14] = 0; xo[15] = 0; xo[16] = 0;
+                const d3 pGk = mv33(tr33(q2r(qG)), sub3(pk, pG));   // pose line (System.cc:371-374)
+                st3(pose_out, pGk); stq(pose_out + 3, qkG);
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Vk[i][k] * P11[k][j]; Tm[i][j] = a; }
+        __syncthreads();
+        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Tm[i][k] * Vk[j][k]; P11[i][j] = a; }
+        __syncthreads();
+        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; P_out[(size_t)i + (size_t)j * ld] = .5 * (P11[i][j] + P11[j][i]); }
+        // state: augmentation (System.cc:282-287,303-306) then composition (System.cc:360-365)
+        for (int i = tid; i < xd2; i += 256) {
+            double v;
+            if (i < 17) v = xo[i];
+            else if (i < 26) v = xs[i];
+            else {
+                int src = i;
+                if (do_aug) {
+                    const int cb = (i - 26) / 7, off = (i - 26) % 7;
+                    if (n < nmax) src = (cb < n) ? i : 10 + off;
+                    else src = (cb < nmax - 1) ? i + 7 : 10 + off;
+                }
+                v = (src < 26) ? xs[src] : x[src];
+            }
+            x_out[i] = v;
+        }
+    } else {
+        // entries with a >= 24 or b >= 24:  a = row, b = column (column-major: consecutive threads walk down a column)
+        const int total = d2 * d2;
+        for (int e = (blockIdx.x - 1) * 256 + tid; e < total; e += (gridDim.x - 1) * 256) {
+            const int a = e % d2, b = e / d2;
+            if (a < 24 && b < 24) continue;
+            double v;
+            if (a >= 24 && b >= 24) v = P[(size_t)aug_src2(a, n, nmax, do_aug) + (size_t)aug_src2(b, n, nmax, do_aug) * ld];
+            else {
+                const int i = (a < 24) ? a : b;                                   // row of Vk
+                const int sc = aug_src2((a < 24) ? b : a, n, nmax, do_aug);       // source clone column (P symmetric)
+                const double* pc = P + (size_t)sc * ld;
+                if (i >= 15) v = pc[i];
+                else if (i >= 9) v = 0.0;
+                else {
+                    const int bi = i / 3;
+                    double acc = Vk[i][3 * bi] * pc[3 * bi] + Vk[i][3 * bi + 1] * pc[3 * bi + 1] + Vk[i][3 * bi + 2] * pc[3 * bi + 2];
+                    acc += Vk[i][9] * pc[9] + Vk[i][10] * pc[10] + Vk[i][11] * pc[11];
+                    if (bi == 1) acc += Vk[i][12] * pc[12] + Vk[i][13] * pc[13] + Vk[i][14] * pc[14];
+                    v = acc;
+                }
+            }
+            P_out[(size_t)a + (size_t)b * ld] = v;
+        }
+    }
+}
+
+// =============================================================== U7 compression, information form (v2, FP64 MFMA)
+// partial[g] = sum over the stacked rows of feature group g of H^T [H | r]  (rows 0..c6-1, cols 0..c6).
+// grid = (groups of GRAM2_FG features, 16-row tiles of p); 4 waves, wave w owns the 16-column q-tiles w, w+4, w+8.
+// Rows are staged through LDS 32 at a time (coalesced), then v_mfma_f64_16x16x4_f64 with
+//   A[i = p][k = row] = H[row][p0+i],  B[k = row][j = q] = H[row][q].
+#define GRAM2_FG 8
+#define GRAM2_RB 64
+__global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const double* __restrict__ Hstack, const int* __restrict__ nrows,
+                                                        double* __restrict__ partial) {
+    extern __shared__ __align__(16) double hs[];   // [GRAM2_RB][ldh + 1]
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max, lds = ldh + 1;
+    const int g = blockIdx.x, p0 = blockIdx.y * 16;
+    if (p0 >= c6) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int ntile = (c6 + 1 + 15) / 16;
+    d4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    // compact row list of the group: rows [off[ff], off[ff+1]) belong to feature g*FG+ff
+    __shared__ int s_off[GRAM2_FG + 1];
+    if (tid == 0) {
+        int o = 0;
+        for (int ff = 0; ff < GRAM2_FG; ++ff) { s_off[ff] = o; const int f = g * GRAM2_FG + ff; o += (f < cfg.Fu) ? nrows[f] : 0; }
+        s_off[GRAM2_FG] = o;
+    }
+    __syncthreads();
+    const int R = s_off[GRAM2_FG];
+    for (int r0 = 0; r0 < R; r0 += GRAM2_RB) {
+        if (r0 > 0) __syncthreads();
+        // stage GRAM2_RB rows: wave w takes rows w, w+4, ...; lanes walk the columns (coalesced, no div/mod)
+        for (int r = wave; r < GRAM2_RB; r += 4) {
+            const int gr = r0 + r;
+            int ff = 0;
+#pragma unroll
+            for (int t = 1; t < GRAM2_FG; ++t) ff += (gr >= s_off[t]) ? 1 : 0;
+            const bool ok = gr < R;
+            const double* Hrow = Hstack + ((size_t)(g * GRAM2_FG + ff) * rhomax + (gr - s_off[ff])) * ldh;
+            for (int c = lane; c < ldh; c += 64) hs[r * lds + c] = ok ? Hrow[c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < GRAM2_RB / 4; ++ks) {
+            const double a = hs[(4 * ks + lk) * lds + p0 + li];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int jt = wave + 4 * t;
+                if (jt < ntile) {
+                    const int q = jt * 16 + li;
+                    const double b = (q < ldh) ? hs[(4 * ks + lk) * lds + q] : 0.0;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    double* out = partial + (size_t)g * ldh * ldh;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int jt = wave + 4 * t;
+        if (jt < ntile) {
+            const int q = jt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + lk + 4 * r;
+                if (p < c6 && q <= c6) out[(size_t)p * ldh + q] = acc[t][r];
+            }
+        }
+    }
+}

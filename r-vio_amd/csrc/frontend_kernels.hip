@@ -19,6 +19,9 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 // single reflection: valid (and identical to reflect101) whenever -n < i < 2n-1
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+// two branch-free reflections: identical to reflect101 for -2(n-1) <= i <= 3(n-1)  (the KLT search region stays within
+// [-23, n+22] and every pyramid level has n >= 16)
+__device__ __forceinline__ int reflect2(int i, int n) { return reflect1(reflect1(i, n), n); }
 
 // ------------------------------------------------------------------ pyramid level
 // thread (x,y) of level l:  dxy[y][x] = un-normalised 3x3 Scharr (reflect-101 neighbours, int16 (dx,dy));
@@ -104,13 +107,13 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
         //  a garbage estimate must never reach the reflect loops)
         if (jx0 + 8 >= -15 && jx0 + 8 < w && jy0 + 8 >= -15 && jy0 + 8 < h) {
             const int r = lane >> 1, c0 = (lane & 1) * 16;
-            const uint8_t* jrow = J + (size_t)reflect101(jy0 + r, h) * w;
+            const uint8_t* jrow = J + (size_t)reflect2(jy0 + r, h) * w;
             unsigned pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 unsigned v = 0;
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect101(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
+                for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect2(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
                 pk[g] = v;
             }
 #pragma unroll
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
                 jx0 = inx - 8; jy0 = iny - 8; ox = 8; oy = 8;
                 __syncthreads();
                 const int r = lane >> 1, c0 = (lane & 1) * 16;
-                const uint8_t* jrow = J + (size_t)reflect101(jy0 + r, h) * w;
+                const uint8_t* jrow = J + (size_t)reflect2(jy0 + r, h) * w;
                 unsigned pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     unsigned v = 0;
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect101(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
+                    for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect2(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
                     pk[g] = v;
                 }
 #pragma unroll

@@ -45,6 +45,14 @@ struct FilterMeta {
     int pad[2];
 };
 
+// phase stamps for performance debugging (tools/dbg_clocks.py): DBG_T(i) records clock64() in slot i
+__device__ long long g_dbg[64];
+#ifdef RVIO_DBG_CLOCKS
+#define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)
+#else
+#define DBG_T(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- small math
 struct d3 { double x, y, z; };
 struct m33 { double m[9]; };  // row-major

@@ -13,6 +13,8 @@
 #include "rvio_dev.h"
 #include "frontend_dev.h"
 #include "filter_kernels.hip"
+#include "filter_kernels2.hip"
+#include "solve4.hip"
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #pragma clang fp contract(fast)
@@ -36,7 +38,7 @@ struct rvio_hip {
     int *nrows = nullptr, *acc = nullptr, *ndof = nullptr;
     int n_groups = 0, feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
-    int solve_use_lds = 0;
+    int solve_use_lds = 0, solve_nch = 1;
     // staging
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
@@ -161,7 +163,7 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     DALLOC(h, h->meta, 1);
     for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
     DALLOC(h, h->Hstack, (size_t)d.Fu * d.rho_max * ldh);
-    h->n_groups = (d.Fu + GRAM_FG - 1) / GRAM_FG;
+    h->n_groups = (d.Fu + GRAM2_FG - 1) / GRAM2_FG;
     DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
     DALLOC(h, h->block, ldh * ldh);
     DALLOC(h, h->Ab, ldh * ldh);
@@ -206,13 +208,20 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     }
     if (h->feat_lds > 160 * 1024) { h->err = "per-feature LDS footprint exceeds 160 KiB"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double))));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
-        const size_t c6m = ldh - 1, NC = 2 * c6m + 1, ldm = NC | 1;
-        h->solve_lds = c6m * ldm * sizeof(double);
-        h->solve_use_lds = h->solve_lds <= 150 * 1024;
-        if (h->solve_use_lds) HIPCHK(h, hipFuncSetAttribute((const void*)solve_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+        const size_t c6m = ldh - 1, NC = c6m + 1, ldm = NC | 1;
+        h->solve_lds = c6m * ldm * sizeof(double) + 1024;   // + slack: tail lanes of the last row read (never write) past the row
+        h->solve_use_lds = h->solve_lds <= 140 * 1024;
+        h->solve_nch = (NC <= 64) ? 1 : (NC <= 128 ? 2 : 3);
+        if (h->solve_use_lds) {
+            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+        }
         else { h->solve_lds = 0; DALLOC(h, h->Mg, ldh * 2 * ldh); }
         const size_t c6t = (c6m + 15) / 16;
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
@@ -315,7 +324,7 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 
 // ------------------------------------------------------------------ P1
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
-    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m);
+    hipLaunchKernelGGL(propagate_kernel3, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -353,7 +362,8 @@ static int update_local_dev(rvio_hip* h, int rank, int world) {
     hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global);
-    hipLaunchKernelGGL(gram_kernel, dim3(h->n_groups, (6 * n + 15) / 16), dim3(256), 0, h->stream, d, n, h->Hstack, h->nrows, h->partial);
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(h->n_groups, (6 * n + 15) / 16), dim3(256), (size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double), h->stream,
+                       d, n, h->Hstack, h->nrows, h->partial);
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256))), dim3(256), 0, h->stream, d, n,
                        h->partial, h->n_groups, h->nrows, h->block);
     HIPCHK(h, hipGetLastError());
@@ -374,10 +384,14 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     }
     const int tt = (c6 + 31) / 32;
     hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf);
-    if (h->solve_use_lds)
-        hipLaunchKernelGGL(solve_kernel_lds, dim3(1), dim3(1024), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
+    if (!h->solve_use_lds)
+        hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1], h->Mg);
+    else if (h->solve_nch == 1)
+        hipLaunchKernelGGL(solve4_kernel_lds<1>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
+    else if (h->solve_nch == 2)
+        hipLaunchKernelGGL(solve4_kernel_lds<2>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
     else
-        hipLaunchKernelGGL(solve_kernel_glb, dim3(1), dim3(1024), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1], h->Mg);
+        hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
     // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
     hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
@@ -437,8 +451,8 @@ int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, do
 static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const DevCfg& d = h->dc;
     const int c = h->cur, o = c ^ 1;
-    const int cg = 1 + std::max(1, (6 * d.nmax + 255) / 256);
-    hipLaunchKernelGGL(augcomp_kernel, dim3(cg), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose);
+    const int cg = 1 + std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256));
+    hipLaunchKernelGGL(augcomp_kernel2, dim3(cg), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose);
     HIPCHK(h, hipGetLastError());
     h->cur = o;
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
@@ -638,6 +652,12 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     if (n > 0 && un_xy) HIPCHK(h, hipMemcpyAsync(un_xy, h->t.un2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {
+    if (!h || !out64) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg), sizeof(long long) * 64));
     return RVIO_OK;
 }
 }

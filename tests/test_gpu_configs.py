@@ -1,0 +1,122 @@
+"""GPU parity on the other BASELINE.json configurations (SURVEY.md section 8 size table).  They exercise the code paths cfg B
+does not: two/three 64-column chunks and the global-scratch tableau in the solve kernel, 128/256-thread feature
+workgroups, Tm in global scratch, larger pyramids (cfg D).  Same bar as test_gpu_filter.py."""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+# name -> (overrides, frames to record, frame indices to check)
+CASES = {
+    "A": (dict(), 34, [20, 33]),                                   # stock EuRoC: 200 f / 14 clones (d = 108)
+    "C": (dict(), 46, [30, 45]),                                   # 400 f / 20 clones (d = 144)
+    "E-shaped": (dict(n_features=400), 66, [50, 65]),              # 30 clones (d = 204), fewer features to keep the CPU oracle quick
+}
+
+
+def _cfg(name):
+    base = "E" if name.startswith("E") else name
+    return abi.config_named(base, enable_equalizer=0, **CASES[name][0])
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request, gpu_required):
+    from rvio_amd import hip
+    name = request.param
+    cfg = _cfg(name)
+    seq, recs = S.record_sequence(cfg, n_frames=CASES[name][1], duration=6.0)
+    h = hip.RvioHip(cfg)
+    yield name, cfg, seq, recs, h
+    h.close()
+
+
+def p_close(Pa, Pb):
+    return float(np.max(np.abs(Pa - Pb))) <= 1e-9 * np.max(np.abs(Pb)) + 1e-15
+
+
+def test_stage_parity(case):
+    name, cfg, seq, recs, h = case
+    for fi in CASES[name][2]:
+        r = recs[fi]
+        assert (len(r["x1"]) - 26) // 7 == cfg.max_track_len - 1          # window full
+        h.set_state(r["x0"], r["P0"])
+        h.propagate(r["inp"]["imu"])
+        x, P = h.get_state()
+        assert S.state_delta(x, r["x1"]) <= 1e-9 and p_close(P, r["P1"])
+        h.set_state(r["x1"], r["P1"])
+        h.update(r["types"], r["lens"], r["meas"])
+        x, P = h.get_state()
+        dg = h.update_diag()
+        assert np.array_equal(dg["accepted"], r["diag"]["accepted"])
+        assert np.allclose(dg["gamma"], r["diag"]["gamma"], rtol=1e-7, atol=1e-9)
+        assert S.state_delta(x, r["x2"]) <= 1e-9 and p_close(P, r["P2"])
+        h.set_state(r["x2"], r["P2"])
+        h.augment_compose(r["do_augment"])
+        x, P = h.get_state()
+        assert S.state_delta(x, r["x3"]) <= 1e-12 and p_close(P, r["P3"])
+
+
+def test_full_load_update(case):
+    """ceil(F/2) features, half of them at the maximum track length"""
+    name, cfg, seq, recs, h = case
+    r = recs[-1]
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    xo, Po, od = O.update(cfg, r["x1"], r["P1"], types, lens, meas)
+    assert od["n_good"] > len(types) // 2
+    h.set_state(r["x1"], r["P1"])
+    h.update(types, lens, meas)
+    x, P = h.get_state()
+    dg = h.update_diag()
+    assert np.array_equal(dg["accepted"], od["accepted"])
+    assert S.state_delta(x, xo) <= 1e-9 and p_close(P, Po)
+
+
+def test_free_running_sequence(case):
+    name, cfg, seq, recs, h0 = case
+    from rvio_amd import hip
+    h = hip.RvioHip(cfg)
+    w, a, n = seq.init_from_static(38)
+    h.initialize(w, a, n)
+    worst = 0.0
+    for r in recs:
+        inp = r["inp"]
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        x, P = h.get_state()
+        worst = max(worst, S.state_delta(x, r["x3"]))
+        pts, hl = h.get_points()
+        assert np.array_equal(pts, r["pts"]) and np.array_equal(hl, r["hist_len"])
+    h.close()
+    assert worst <= 1e-6, worst
+
+
+def test_images_1080p(gpu_required):
+    """cfg D geometry (1920x1080, 800 features): pyramid + KLT + book-keeping bit-exact on two rendered frames"""
+    from rvio_amd import hip
+    cfg = abi.config_named("D", enable_equalizer=0)
+    seq = rv.synth.SynthSequence(cfg, duration=4.0)
+    ks = [60, 61, 62]
+    imgs = [seq.render(k) for k in ks]
+    h = hip.RvioHip(cfg)
+    t = O.Tracker(cfg)
+    for k, img in zip(ks, imgs):
+        xy, vis = seq.project(k, noise=False)
+        cand, _ = seq.candidates(k, xy, vis)
+        imu = seq.imu_between(k)
+        oi = t.track(img, imu, cand)
+        h.track(img, imu, cand)
+        gi = h.frame_info()
+        for key in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "ransac_winner", "n_tracked_out"):
+            assert gi[key] == oi[key], (k, key, gi, oi)
+        pa, ha = h.get_points()
+        pb, hb = t.get_points()
+        assert np.array_equal(pa, pb) and np.array_equal(ha, hb)
+    lvl3, dxy3 = h.debug_pyramid(3)
+    ref = imgs[-1]
+    for _ in range(3):
+        ref = O.pyr_down(ref)
+    assert np.array_equal(lvl3, ref) and np.array_equal(dxy3, O.scharr(ref))
+    h.close()
