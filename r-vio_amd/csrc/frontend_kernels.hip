@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
     const double eps2 = 0.01 * 0.01;
     float nx = 0, ny = 0;
     int st = 1;
+    DBG_T(9);
     int wx_[4], wy_[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { int p = lane + 64 * q; wx_[q] = p % 15; wy_[q] = p / 15; }
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
             for (int g = 0; g < 4; ++g) ((unsigned*)Jr)[(r * KLT_JR + c0) / 4 + g] = pk[g];
         }
         __syncthreads();
+        DBG_T(10 + 3 * level);
         int Iw[4], Ixw[4], Iyw[4];
         long long s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
         if (minEig < 1e-3f || D < 1.1920929e-07f) { if (level == 0) st = 0; continue; }
         D = 1.f / D;
         float pdx = 0, pdy = 0;
+        DBG_T(11 + 3 * level);
         for (int j = 0; j < 30; ++j) {
+#ifdef RVIO_DBG_CLOCKS
+            if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[26 + level] = j + 1;
+#endif
             const int inx = (int)floorf(npx), iny = (int)floorf(npy);
             if (inx < -15 || inx >= w || iny < -15 || iny >= h) { if (level == 0) st = 0; break; }
             int ox = inx - jx0, oy = iny - jy0;
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int l
             if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { nx -= dx * 0.5f; ny -= dy * 0.5f; break; }
             pdx = dx; pdy = dy;
         }
+        DBG_T(12 + 3 * level);
         if (st && level == 0) {
             const float fx = nx - 7.f, fy = ny - 7.f;
             const int rx = (int)rintf(fx), ry = (int)rintf(fy);

@@ -17,6 +17,7 @@
 #include "solve4.hip"
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
+#include "klt3.hip"
 #pragma clang fp contract(fast)
 
 struct rvio_hip {
@@ -495,7 +496,7 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
     int rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
-    hipLaunchKernelGGL(klt_kernel, dim3(h->dc.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
                        h->t.tracked, h->t.status);
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
