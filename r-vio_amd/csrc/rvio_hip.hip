@@ -24,7 +24,13 @@ struct rvio_hip {
     rvio_config cfg;
     DevCfg dc;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // filter stream (and the stream of every non-pipelined call)
+    hipStream_t stream_t = nullptr;   // tracker stream of the pipelined whole-frame path
+    hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
+    hipEvent_t evT[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
+    long frame_no = 0;
+    bool piped = false;
+    struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[2];
     std::string err;
     // filter state (double-buffered)
     FilterMeta* meta = nullptr;
@@ -160,6 +166,12 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     *out = h;   // returned even on allocation failure so last_error is readable
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
+    h->ts = h->stream;
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], hipEventDisableTiming));
+    }
     const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
     DALLOC(h, h->meta, 1);
     for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
@@ -190,6 +202,9 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
     DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
     t.info = h->d_info;
+    h->tout[0] = {t.n_feat, t.types, t.len, t.meas};   // Tracker -> Updater hand-over, double-buffered for the pipelined path
+    DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
+    DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
     { int one = 1; HIPCHK(h, hipMemcpyAsync(t.first, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); }
     for (int b = 0; b < 2; ++b) {
         int w = d.W, hg = d.H;
@@ -235,8 +250,11 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
 void rvio_hip_destroy(rvio_hip* h) {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) hipFree(p);
+    for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); }
+    if (h->stream_t) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -244,6 +262,7 @@ const char* rvio_hip_last_error(const rvio_hip* h) { return h ? h->err.c_str() :
 void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
 int rvio_hip_sync(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream_t));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
@@ -434,6 +453,7 @@ int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
 int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -473,7 +493,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     for (int l = 0; l < d.levels; ++l) {
         const bool last = (l + 1 == d.levels);
         const uint8_t* src = (l == 0) ? d_img : p.img[l];
-        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->stream, src, p.w[l], p.h[l],
+        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
                            (l == 0) ? stride : p.w[l], (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
                            last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1]);
     }
@@ -483,9 +503,9 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
 
 // everything after Tracker.cc:246; status/tracked already on the device
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), (size_t)5 * h->dc.F + 16, h->stream, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
+    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), (size_t)5 * h->dc.F + 16, h->ts, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info);
-    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->stream, h->dc, h->t, d_cand, n_cand);
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -493,10 +513,11 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
 int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped && h->ts == h->stream) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
     int rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
-    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F), dim3(64), 0, h->ts, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
                        h->t.tracked, h->t.status);
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
@@ -532,6 +553,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
 int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const DevCfg& d = h->dc;
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
@@ -549,6 +571,7 @@ int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int3
 int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const DevCfg& d = h->dc;
     int np = 0;
     HIPCHK(h, hipMemcpyAsync(&np, h->t.n_pts, sizeof np, hipMemcpyDeviceToHost, h->stream));
@@ -594,10 +617,27 @@ static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
     }
     return augment_compose_dev(h, h->img_count > 1);      // System.cc:280
 }
+// Pipelined: the tracker (pyramid, KLT, RANSAC, book-keeping) never reads the filter state, so frame k's front end runs
+// on its own stream while frame k-1's propagate/update/augment still occupy the filter stream.  The Tracker -> Updater
+// hand-over is double-buffered; two events per buffer order (a) update(k) after track(k), (b) track(k+2) after update(k).
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    if (!h) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int b = (int)(h->frame_no & 1);
+    h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
+    if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
+    else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
+    h->piped = true;
+    h->ts = h->stream_t;
     int rc = rvio_hip_track_dev(h, d_img, stride, d_imu, m, d_cand, n_cand);
+    h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
-    return frame_tail_dev(h, d_imu, m);
+    HIPCHK(h, hipEventRecord(h->evT[b], h->stream_t));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
+    rc = frame_tail_dev(h, d_imu, m);
+    HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
+    h->frame_no++;
+    return rc;
 }
 // direct-track variant of the whole frame (host inputs)
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
@@ -610,6 +650,7 @@ int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned c
 int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     if (!h || !info) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     FilterMeta m;
     HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
@@ -637,6 +678,7 @@ extern "C" {
 int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy) {
     if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const PyrDev& p = h->pyr[h->pyr_cur];
     if (w) *w = p.w[level];
     if (hgt) *hgt = p.h[level];
@@ -650,6 +692,7 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
 int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     if (!h || n < 0 || n > h->dc.F) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     if (n > 0 && un_xy) HIPCHK(h, hipMemcpyAsync(un_xy, h->t.un2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
