@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the same sequence timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-streams", action="store_true")
+    ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     args = ap.parse_args()
 
     import torch
@@ -169,6 +171,9 @@ def main():
         if not args.no_latency:
             out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
                                     img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni))
+        if not args.no_streams:
+            out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
+                                               wi, ai, ni, n_frames, 1 + W, streams=args.streams)
         if not args.no_cpu:
             out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
             if xs_cpu is not None and "x_at_cpu_frames" in out:
@@ -226,19 +231,60 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
            "latency_ms_p95": {k: float(np.percentile(v, 95)) for k, v in lat.items() if v},
            "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
            "x_at_cpu_frames": x_at}
-    # ---- roofline of the dominant kernel (klt_kernel, HBM/L2 bound): algorithmic bytes per launch
-    # B_klt = per tracked feature, per level: 16x16 template (u8 + 2 x int16 gradient)
-    # + 16x16 search-window read per iteration.  Measured here: the track stage's device time per launch.
+    # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree)
+    # Dominant kernel by device time: the solve kernel (in-place Gauss-Jordan of T = s2 I + A Pcc, c6 = 6n columns).
+    # Algorithmic FP64 work per launch = c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8).
+    n = cfg.max_track_len - 1
+    c6 = 6 * n
     F = cfg.n_features
+    t_solve = h.time_kernel(0, 20) * 1e-6
+    t_klt = h.time_kernel(1, 20) * 1e-6
+    t_feat = h.time_kernel(2, 20) * 1e-6
+    fl_solve = 2.0 * c6 * c6 * (c6 + 1)
+    PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
+    res["roofline"] = {"bound": "mfma", "kernel": "solve4_kernel_lds (W = (s2 I + A Pcc)^-1, one workgroup)",
+                       "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
+                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": None, "avg_us": t_solve * 1e6,
+                       "note": "latency bound: a %dx%d FP64 elimination on ONE CU with one barrier per column; a single 752x480 stream "
+                               "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction" % (c6, c6 + 1)}
     it_l = 10
-    alg_bytes = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16
-    t_track = np.median(lat["track"]) * 1e-3
-    res["roofline"] = {"bound": "hbm", "kernel": "track stage (pyr_down x3 + scharr x4 + klt_kernel + ransac + bookkeep)",
-                       "achieved": (alg_bytes + cfg.width * cfg.height * 1.656) / t_track / 1e9, "peak": 8000.0, "unit": "GB/s",
-                       "frac": (alg_bytes + cfg.width * cfg.height * 1.656) / t_track / 1e9 / 8000.0, "traffic": None,
-                       "note": "single 752x480 stream is launch/latency bound (SURVEY.md 8d): 3.67 MB algorithmic per frame"}
+    by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10
+    res["roofline_other"] = [
+        {"bound": "hbm", "kernel": "klt_kernel3", "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s",
+         "frac": by_klt / t_klt / 1e9 / 8000.0, "avg_us": t_klt * 1e6},
+        {"bound": "mfma", "kernel": "feat_build_kernel (U1-U5, FP64 MFMA gate)", "achieved": None, "peak": PEAK_F64, "unit": "TFLOP/s",
+         "frac": None, "avg_us": t_feat * 1e6},
+    ]
     h.close()
     return res
+
+
+def multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, wi, ai, ni, n_frames, n_warm, streams=8):
+    """Aggregate throughput of `streams` independent filter instances (own handle, own HIP streams) fed the same resident
+    frames: kernels of different instances overlap on the 256 CUs.  One host thread issues every launch."""
+    from rvio_amd import hip
+    hs = [hip.RvioHip(cfg) for _ in range(streams)]
+    for h in hs:
+        h.initialize(wi, ai, ni)
+    def frame(h, i):
+        h.frame_dev(p_img + i * isb, cfg.width, p_imu + i * msb, int(imu_cnt[i]), p_cand + i * csb, int(cand_cnt[i]))
+    for i in range(n_warm):
+        for h in hs:
+            frame(h, i)
+    for h in hs:
+        h.sync()
+    t0 = time.perf_counter()
+    for i in range(n_warm, n_frames):
+        for h in hs:
+            frame(h, i)
+    for h in hs:
+        h.sync()
+    el = time.perf_counter() - t0
+    k = n_frames - n_warm
+    for h in hs:
+        h.close()
+    return {"streams": streams, "value": streams * k / el, "unit": "frames/s", "frames_per_stream": k,
+            "note": "one host thread, eager launches (no hipGraph yet): host-launch bound"}
 
 
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):

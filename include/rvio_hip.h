@@ -214,6 +214,10 @@ int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, do
  * (vFeatsTracked + its undistorted-normalised form) of the last track() call */
 int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy);
 int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy);
+/* Measurement hook for bench.py's roofline object: average device time (us, HIP events on the handle's stream)
+ * of `iters` back-to-back launches of one hot kernel on the operands the last frame left in HBM.
+ * which: 0 = solve kernel, 1 = KLT kernel, 2 = per-feature Jacobian/nullspace/gate kernel. */
+int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include "filter_kernels.hip"
 #include "filter_kernels2.hip"
 #include "solve4.hip"
+#include "solve6.hip"
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #include "klt3.hip"
@@ -46,6 +47,8 @@ struct rvio_hip {
     int n_groups = 0, feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
+    int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
+    size_t solve5_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
@@ -239,6 +242,19 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
             HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
         }
         else { h->solve_lds = 0; DALLOC(h, h->Mg, ldh * 2 * ldh); }
+        {   // fully unrolled solve kernel: variants <column chunks, rows per wave> for c6 <= 126
+            int rpw = 0, nch = 0;
+            if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 16; }
+            else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 24; }
+            else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 32; }
+            if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
+            if (h->solve5_variant) {
+                h->solve5_lds = (size_t)(4 * rpw) * (64 * nch + 1) * sizeof(double);
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
+            }
+        }
         const size_t c6t = (c6m + 15) / 16;
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
@@ -390,6 +406,25 @@ static int update_local_dev(rvio_hip* h, int rank, int world) {
     return RVIO_OK;
 }
 
+static void launch_solve(rvio_hip* h, int n, const double* Ab) {
+    const DevCfg& d = h->dc;
+    double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
+    if (h->solve5_variant == 1)
+        hipLaunchKernelGGL((solve6_kernel<1, 16>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (h->solve5_variant == 2)
+        hipLaunchKernelGGL((solve6_kernel<2, 24>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (h->solve5_variant == 3)
+        hipLaunchKernelGGL((solve6_kernel<2, 32>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (!h->solve_use_lds)
+        hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->Mg);
+    else if (h->solve_nch == 1)
+        hipLaunchKernelGGL(solve4_kernel_lds<1>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (h->solve_nch == 2)
+        hipLaunchKernelGGL(solve4_kernel_lds<2>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else
+        hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+}
+
 static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host, c6 = 6 * n, dd = 24 + c6;
@@ -404,14 +439,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     }
     const int tt = (c6 + 31) / 32;
     hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf);
-    if (!h->solve_use_lds)
-        hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1], h->Mg);
-    else if (h->solve_nch == 1)
-        hipLaunchKernelGGL(solve4_kernel_lds<1>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
-    else if (h->solve_nch == 2)
-        hipLaunchKernelGGL(solve4_kernel_lds<2>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
-    else
-        hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, h->x[h->cur], Pc, h->W, h->x[h->cur ^ 1]);
+    launch_solve(h, n, Ab);
     // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
     hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
@@ -698,6 +726,40 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
+// Average device time (microseconds, HIP events on the handle's stream) of `iters` back-to-back launches of one
+// hot kernel on the operands left behind by the last frame: which = 0 -> solve kernel (W = T^-1 + injection),
+// 1 -> klt_kernel3 on the two resident pyramids, 2 -> feat_build_kernel.  Outputs land in scratch / are idempotent.
+int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us) {
+    if (!h || !avg_us || iters < 1) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const DevCfg& d = h->dc;
+    const int n = h->n_clones_host;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int it = 0; it < iters; ++it) {
+        if (which == 0) {
+            launch_solve(h, n, h->block);
+        } else if (which == 1) {
+            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
+                               h->t.tracked, h->t.status);
+        } else {
+            hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global);
+        }
+    }
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_us = ms * 1e3f / iters;
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
 int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {
     if (!h || !out64) return RVIO_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));

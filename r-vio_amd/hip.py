@@ -10,7 +10,7 @@ import numpy as np
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librvio_hip.so")
+LIB_PATH = os.environ.get("RVIO_HIP_LIB", os.path.join(HERE, "librvio_hip.so"))   # override: A/B kernel experiments
 
 # every symbol include/rvio_hip.h declares (tests/test_abi.py checks the export list)
 SYMBOLS = [
@@ -21,6 +21,7 @@ SYMBOLS = [
     "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
+    "rvio_hip_debug_time_kernel",
 ]
 
 _LIB = None
@@ -242,6 +243,12 @@ class RvioHip:
         xy, un = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32)
         self._ck(self.L.rvio_hip_debug_tracked(self.h, n, _p(xy, fp), _p(un, fp)), "debug_tracked")
         return xy, un
+
+    def time_kernel(self, which, iters=20):
+        """average device time (us) of one hot kernel: 0 solve, 1 KLT, 2 per-feature build (HIP events, handle stream)"""
+        us = C.c_float(0)
+        self._ck(self.L.rvio_hip_debug_time_kernel(self.h, int(which), int(iters), C.byref(us)), "debug_time_kernel")
+        return float(us.value)
 
     def frame_info(self):
         info = abi.rvio_frame_info()
