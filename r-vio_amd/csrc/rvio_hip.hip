@@ -243,16 +243,21 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
         }
         else { h->solve_lds = 0; DALLOC(h, h->Mg, ldh * 2 * ldh); }
         {   // fully unrolled solve kernel: variants <column chunks, rows per wave> for c6 <= 126
-            int rpw = 0, nch = 0;
-            if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 16; }
-            else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 24; }
-            else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 32; }
+            int rpw = 0, nch = 0, nw = 8;
+            if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 8; }
+            else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 12; }
+            else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
+            if (h->solve5_variant == 1 && getenv("RVIO_SOLVE_4WAVES")) { h->solve5_variant = 4; rpw = 16; nw = 4; }   // A/B timing only
+            if (h->solve5_variant == 1 && getenv("RVIO_SOLVE_16WAVES")) { h->solve5_variant = 5; rpw = 4; nw = 16; }   // A/B timing only
             if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
             if (h->solve5_variant) {
-                h->solve5_lds = (size_t)(4 * rpw) * (64 * nch + 1) * sizeof(double);
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->solve5_lds, (size_t)1024)));
+                h->solve5_lds = (size_t)(nw * rpw) * (64 * nch + 1) * sizeof(double);
+                const int lds = (int)std::max(h->solve5_lds, (size_t)1024);
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 12, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             }
         }
         const size_t c6t = (c6m + 15) / 16;
@@ -410,11 +415,15 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     if (h->solve5_variant == 1)
-        hipLaunchKernelGGL((solve6_kernel<1, 16>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<1, 8, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
     else if (h->solve5_variant == 2)
-        hipLaunchKernelGGL((solve6_kernel<2, 24>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<2, 12, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
     else if (h->solve5_variant == 3)
-        hipLaunchKernelGGL((solve6_kernel<2, 32>), dim3(1), dim3(SOLVE6_T), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<2, 16, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (h->solve5_variant == 5)
+        hipLaunchKernelGGL((solve6_kernel<1, 4, 16>), dim3(1), dim3(1024), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+    else if (h->solve5_variant == 4)
+        hipLaunchKernelGGL((solve6_kernel<1, 16, 4>), dim3(1), dim3(256), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
     else if (!h->solve_use_lds)
         hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->Mg);
     else if (h->solve_nch == 1)
