@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-streams", action="store_true")
+    ap.add_argument("--no-equalizer", action="store_true", help="Tracker.EnableEqualizer: 0 (skip CLAHE)")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     args = ap.parse_args()
 
@@ -95,7 +96,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = abi.config_named(args.config, enable_equalizer=0)
+    # Tracker.EnableEqualizer: 1 in the stock config (config/rvio_euroc.yaml): CLAHE runs on every frame
+    cfg = abi.config_named(args.config, enable_equalizer=0 if args.no_equalizer else 1)
     K, W = args.steps, args.warmup
     n_frames = 1 + W + K   # first image (seed) + warmup + timed
     seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt = build_inputs(cfg, n_frames)
@@ -160,8 +162,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f64 (filter) / u8+i32+f32 (KLT)", "data": "synthetic",
-        "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer off"
-                               % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1),
+        "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer %s"
+                               % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off"),
                    "parallelism": "1 process/GPU; feature-sharded updater + 1 all-gather/frame" if world > 1 else "single GPU"},
         "gpu_ms_per_step_events": gpu_ms / K,
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
@@ -242,7 +244,7 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     t_feat = h.time_kernel(2, 20) * 1e-6
     fl_solve = 2.0 * c6 * c6 * (c6 + 1)
     PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
-    res["roofline"] = {"bound": "mfma", "kernel": "solve4_kernel_lds (W = (s2 I + A Pcc)^-1, one workgroup)",
+    res["roofline"] = {"bound": "mfma", "kernel": "solve6_kernel (W = (s2 I + A Pcc)^-1, one workgroup)",
                        "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
                        "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": None, "avg_us": t_solve * 1e6,
                        "note": "latency bound: a %dx%d FP64 elimination on ONE CU with one barrier per column; a single 752x480 stream "

@@ -105,6 +105,70 @@ void scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy) {
     }
 }
 
+// cv::CLAHE::apply for CV_8UC1 (OpenCV imgproc/src/clahe.cpp, 3.3+ / 4.x: CLAHE_CalcLut_Body + CLAHE_Interpolation_Body;
+// third-party, not vendored in the reference: restated from the published algorithm, PARITY UNPINNED).
+// The reference calls it as createCLAHE(3.0, Size(5,5))->apply(im, im)  (Tracker.cc:198-202).
+//  * the image is extended to the right/bottom by (tiles - size % tiles) pixels, BORDER_REFLECT_101, unless BOTH
+//    dimensions divide evenly (a dimension that divides evenly is still extended by a full `tiles` pixels);
+//  * per tile: 256-bin histogram, clip at max(1, int(clip * area / 256)), excess redistributed evenly, the residual
+//    one count every max(256/residual, 1) bins; lut[i] = saturate(cvRound(cumsum[i] * (255.f / area)));
+//  * per pixel: bilinear blend (float) of the four neighbouring tile LUTs, cvRound.
+void clahe_apply(const uint8_t* src, int w, int h, int stride, double clip, int tiles_x, int tiles_y, uint8_t* dst, int dstride) {
+    int ew = w, eh = h;
+    if (w % tiles_x != 0 || h % tiles_y != 0) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
+    const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+    const float lut_scale = 255.0f / (float)area;
+    int clip_limit = 0;
+    if (clip > 0.0) { clip_limit = (int)(clip * area / 256); clip_limit = std::max(clip_limit, 1); }
+    std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+    for (int t = 0; t < tiles_x * tiles_y; ++t) {
+        const int ty = t / tiles_x, tx = t % tiles_x;
+        int hist[256] = {0};
+        for (int y = ty * th; y < (ty + 1) * th; ++y) {
+            const uint8_t* row = src + (size_t)reflect101(y, h) * stride;
+            for (int x = tx * tw; x < (tx + 1) * tw; ++x) hist[row[reflect101(x, w)]]++;
+        }
+        if (clip_limit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < 256; ++i)
+                if (hist[i] > clip_limit) { clipped += hist[i] - clip_limit; hist[i] = clip_limit; }
+            const int batch = clipped / 256;
+            int residual = clipped - batch * 256;
+            for (int i = 0; i < 256; ++i) hist[i] += batch;
+            if (residual != 0) {
+                const int step = std::max(256 / residual, 1);
+                for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+            }
+        }
+        int sum = 0;
+        for (int i = 0; i < 256; ++i) {
+            sum += hist[i];
+            const int v = cv_round((float)sum * lut_scale);
+            lut[(size_t)t * 256 + i] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < h; ++y) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tiles_y - 1);
+        const uint8_t* p1 = &lut[(size_t)ty1 * tiles_x * 256];
+        const uint8_t* p2 = &lut[(size_t)ty2 * tiles_x * 256];
+        for (int x = 0; x < w; ++x) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tiles_x - 1);
+            const int v = src[(size_t)y * stride + x];
+            const int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+            const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 + ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
+            const int r = cv_round(res);
+            dst[(size_t)y * dstride + x] = (uint8_t)std::min(std::max(r, 0), 255);
+        }
+    }
+}
+
 const int kWin = 15, kMaxLevel = 3;
 
 Pyramid build_pyramid(const uint8_t* img, int w, int h, int stride, bool with_deriv) {
@@ -393,13 +457,21 @@ orc_tracker* orc_tracker_create(const rvio_config* cfg) {
 }
 void orc_tracker_destroy(orc_tracker* T) { delete T; }
 
-// Tracker::track, Tracker.cc:179-396 (image already mono8; CLAHE not applied: enable_equalizer must be 0)
+void orc_clahe(const uint8_t* img, int w, int h, int stride, uint8_t* out) { clahe_apply(img, w, h, stride, 3.0, 5, 5, out, w); }
+
+// Tracker::track, Tracker.cc:179-396 (image already mono8)
 static void track_impl(orc_tracker* T, const uint8_t* img, int stride, const float* given_xy, const unsigned char* given_flag,
                        const rvio_imu* imu, int m, const float* cand, int n_cand, rvio_frame_info* info) {
     const rvio_config& c = T->cfg;
     const int w = c.width, h = c.height;
     rvio_frame_info fi; std::memset(&fi, 0, sizeof fi);
     Pyramid cur;
+    std::vector<uint8_t> eq;
+    if (img && c.enable_equalizer) {   // Tracker.cc:198-202
+        eq.resize((size_t)w * h);
+        clahe_apply(img, w, h, stride, 3.0, 5, 5, eq.data(), w);
+        img = eq.data(); stride = w;
+    }
     if (img) cur = build_pyramid(img, w, h, stride, true);
     T->types.clear(); T->meas.clear(); T->meas.resize(T->Fu);
     if (T->first) {  // :204-234

@@ -77,6 +77,9 @@ void orc_scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy);
 void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
              const float* pts_xy, int n, float* out_xy, unsigned char* status);
 
+/* ---- T0: cv::createCLAHE(3.0, Size(5,5))->apply, Tracker.cc:198-202 (OpenCV clahe.cpp restated); out is w*h, packed ---- */
+void orc_clahe(const uint8_t* img, int w, int h, int stride, uint8_t* out);
+
 /* ---- T1/T6: Tracker::track, Tracker.cc:179-396 (detector replaced by caller-supplied corners) ---- */
 typedef struct orc_tracker orc_tracker;
 orc_tracker* orc_tracker_create(const rvio_config* cfg);

@@ -1,0 +1,73 @@
+// clahe.hip — T0: cv::createCLAHE(3.0, Size(5,5))->apply(im, im)   (Tracker.cc:198-202, enable_equalizer = 1).
+// OpenCV's imgproc/src/clahe.cpp (CLAHE_CalcLut_Body + CLAHE_Interpolation_Body, 8-bit path) restated for the device;
+// bit-exact against oracle/frontend.cpp:clahe_apply (integer histogram work; float blend with contraction off and
+// round-half-even, the two roundings OpenCV's cvRound performs).  Included inside the fp-contract(off) region.
+//   clahe_lut_kernel    one workgroup per tile: per-wave LDS histograms (reflect-101 extension to the right/bottom),
+//                       clip, redistribute, cumulative sum (DPP scan), LUT
+//   clahe_interp_kernel one thread per pixel: bilinear blend of the four neighbouring tile LUTs (LUTs staged in LDS)
+#pragma once
+
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
+                                                        int clip_limit, float lut_scale, uint8_t* __restrict__ lut) {
+    __shared__ int hist[4][256];
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x, ty = t / tiles_x, tx = t % tiles_x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hist[k][tid] = 0;
+    __syncthreads();
+    for (int r = wv; r < th; r += 4) {
+        const uint8_t* row = src + (size_t)reflect1(ty * th + r, h) * stride;
+        for (int c = lane; c < tw; c += 64) atomicAdd(&hist[wv][row[reflect1(tx * tw + c, w)]], 1);
+    }
+    __syncthreads();
+    int hv = (hist[0][tid] + hist[1][tid]) + (hist[2][tid] + hist[3][tid]);
+    if (clip_limit > 0) {
+        const int excess = hv > clip_limit ? hv - clip_limit : 0;
+        hv -= excess;
+        int clipped;
+        block_exscan(excess, &clipped, s_w);
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            const int step = 256 / residual > 1 ? 256 / residual : 1;
+            if (tid % step == 0 && tid / step < residual) hv += 1;
+        }
+    }
+    int total;
+    const int sum = block_exscan(hv, &total, s_w) + hv;      // inclusive
+    int v = (int)rintf((float)sum * lut_scale);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    lut[(size_t)t * 256 + tid] = (uint8_t)v;
+}
+
+#define CLAHE_MAX_TILES 64
+__global__ __launch_bounds__(256) void clahe_interp_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tiles_y,
+                                                           float inv_tw, float inv_th, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst) {
+    __shared__ uint32_t s_lut[CLAHE_MAX_TILES * 64];
+    const int tid = threadIdx.x;
+    const int nwords = tiles_x * tiles_y * 64;
+    const uint32_t* lut32 = (const uint32_t*)lut;
+    for (int e = tid; e < nwords; e += 256) s_lut[e] = lut32[e];
+    __syncthreads();
+    const uint8_t* L = (const uint8_t*)s_lut;
+    const int x = blockIdx.x * 64 + (tid & 63), y = blockIdx.y * 4 + (tid >> 6);
+    if (x >= w || y >= h) return;
+    const float tyf = (float)y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+    ty1 = ty1 > 0 ? ty1 : 0; ty2 = ty2 < tiles_y - 1 ? ty2 : tiles_y - 1;
+    const float txf = (float)x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    tx1 = tx1 > 0 ? tx1 : 0; tx2 = tx2 < tiles_x - 1 ? tx2 : tiles_x - 1;
+    const int v = src[(size_t)y * stride + x];
+    const uint8_t* p1 = L + ty1 * tiles_x * 256;
+    const uint8_t* p2 = L + ty2 * tiles_x * 256;
+    const int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+    const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 + ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
+    int r = (int)rintf(res);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    dst[(size_t)y * w + x] = (uint8_t)r;
+}

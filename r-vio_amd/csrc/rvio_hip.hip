@@ -19,6 +19,7 @@
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #include "klt3.hip"
+#include "clahe.hip"
 #pragma clang fp contract(fast)
 
 struct rvio_hip {
@@ -53,6 +54,9 @@ struct rvio_hip {
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
+    uint8_t *d_eq = nullptr, *d_lut = nullptr;   // CLAHE output image and tile LUTs (enable_equalizer)
+    int cl_tx = 0, cl_ty = 0, cl_tw = 0, cl_th = 0, cl_clip = 0;
+    float cl_scale = 0.f;
     float* d_in_xy = nullptr;
     unsigned char* d_in_st = nullptr;
     // tracker
@@ -158,7 +162,6 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     *out = nullptr;
     if (cfg->fisheye) return RVIO_ERR_UNSUPPORTED;
     if (cfg->max_track_len < 3 || cfg->max_track_len > RVIO_MAX_LEN || cfg->n_features < 2 || cfg->min_track_len < 2) return RVIO_ERR_INVALID;
-    if (cfg->enable_equalizer) return RVIO_ERR_UNSUPPORTED;   // CLAHE (Tracker.cc:198-202) is a SURVEY 8(f) "next" row
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) return RVIO_ERR_NO_DEVICE;
     rvio_hip* h = new rvio_hip();
@@ -191,6 +194,17 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     DALLOC(h, h->d_imu, RVIO_MAX_IMU);
     DALLOC(h, h->d_cand, (size_t)2 * d.F);
     DALLOC(h, h->d_img, (size_t)d.W * d.H);
+    if (cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
+        h->cl_tx = 5; h->cl_ty = 5;
+        int ew = d.W, eh = d.H;
+        if (d.W % h->cl_tx != 0 || d.H % h->cl_ty != 0) { ew = d.W + (h->cl_tx - d.W % h->cl_tx); eh = d.H + (h->cl_ty - d.H % h->cl_ty); }
+        h->cl_tw = ew / h->cl_tx; h->cl_th = eh / h->cl_ty;
+        const int area = h->cl_tw * h->cl_th;
+        h->cl_clip = std::max((int)(3.0 * area / 256), 1);
+        h->cl_scale = 255.0f / (float)area;
+        DALLOC(h, h->d_eq, (size_t)d.W * d.H);
+        DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
+    }
     DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
     DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
     DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
@@ -526,6 +540,13 @@ int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
 static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int b) {
     const DevCfg& d = h->dc;
     PyrDev& p = h->pyr[b];
+    if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
+        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
+                           h->cl_clip, h->cl_scale, h->d_lut);
+        hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+                           1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq);
+        d_img = h->d_eq; stride = d.W;
+    }
     // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
     for (int l = 0; l < d.levels; ++l) {
         const bool last = (l + 1 == d.levels);

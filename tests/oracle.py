@@ -177,6 +177,15 @@ def pyr_down(img):
     return out
 
 
+def clahe(img):
+    """cv::createCLAHE(3.0, Size(5,5))->apply restated (Tracker.cc:198-202)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_clahe(_p(img, up), w, h, w, _p(out, up))
+    return out
+
+
 def scharr(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
