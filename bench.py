@@ -176,6 +176,7 @@ def main():
         if not args.no_streams:
             out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
                                                wi, ai, ni, n_frames, 1 + W, streams=args.streams)
+            out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
         if not args.no_cpu:
             out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
             if xs_cpu is not None and "x_at_cpu_frames" in out:
@@ -244,9 +245,19 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     t_feat = h.time_kernel(2, 20) * 1e-6
     fl_solve = 2.0 * c6 * c6 * (c6 + 1)
     PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
+    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read live, so this is the committed
+    # rocprofv3 --pmc result (profiles/r01_c_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as fh:
+            e = [v for k, v in json.load(fh).items() if k.startswith("solve6_kernel")][0]
+        traffic = 1024.0 * (e["fetch_kb_mean"] + e["write_kb_mean"])
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
     res["roofline"] = {"bound": "mfma", "kernel": "solve6_kernel (W = (s2 I + A Pcc)^-1, one workgroup)",
                        "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
-                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": None, "avg_us": t_solve * 1e6,
+                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r01_c_pmc_traffic.md)",
+                       "avg_us": t_solve * 1e6,
                        "note": "latency bound: a %dx%d FP64 elimination on ONE CU with one barrier per column; a single 752x480 stream "
                                "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction" % (c6, c6 + 1)}
     it_l = 10
@@ -287,6 +298,29 @@ def multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, isb, 
         h.close()
     return {"streams": streams, "value": streams * k / el, "unit": "frames/s", "frames_per_stream": k,
             "note": "one host thread, eager launches (no hipGraph yet): host-launch bound"}
+
+
+def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n_warm):
+    """PCIe-inclusive rate: the same frames handed over as HOST buffers (rvio_hip_frame: image + IMU + corners copied H2D on
+    the tracker stream every frame).  Reported beside `value`, never as `value`."""
+    from rvio_amd import hip
+    h = hip.RvioHip(cfg)
+    h.initialize(wi, ai, ni)
+    n = len(imgs)
+
+    def frame(i):
+        h.frame(imgs[i], imu_arr[i, : imu_cnt[i]], cand_arr[i, : cand_cnt[i]])
+    for i in range(n_warm):
+        frame(i)
+    h.sync()
+    t0 = time.perf_counter()
+    for i in range(n_warm, n):
+        frame(i)
+    h.sync()
+    el = time.perf_counter() - t0
+    h.close()
+    return {"value": (n - n_warm) / el, "unit": "frames/s", "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + cand_arr[0].nbytes),
+            "note": "pageable host memory, hipMemcpyAsync on the tracker stream"}
 
 
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):

@@ -7,21 +7,43 @@
 //   clahe_interp_kernel one thread per pixel: bilinear blend of the four neighbouring tile LUTs (LUTs staged in LDS)
 #pragma once
 
-__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
-                                                        int clip_limit, float lut_scale, uint8_t* __restrict__ lut) {
-    __shared__ int hist[4][256];
-    __shared__ int s_w[4];
+#define CLAHE_LUT_T 1024
+__global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
+                                                                int clip_limit, float lut_scale, uint8_t* __restrict__ lut) {
+    __shared__ int hist[16][256];
+    __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t = blockIdx.x, ty = t / tiles_x, tx = t % tiles_x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hist[k][tid] = 0;
+    for (int k = 0; k < 4; ++k) hist[4 * k + (tid >> 8)][tid & 255] = 0;
     __syncthreads();
-    for (int r = wv; r < th; r += 4) {
-        const uint8_t* row = src + (size_t)reflect1(ty * th + r, h) * stride;
-        for (int c = lane; c < tw; c += 64) atomicAdd(&hist[wv][row[reflect1(tx * tw + c, w)]], 1);
+    // wave <-> every 16th row of the tile, two rows x 256 columns of byte loads in flight before the LDS atomics
+    for (int r = wv; r < th; r += 32) {
+        const uint8_t* row0 = src + (size_t)reflect1(ty * th + r, h) * stride;
+        const bool has1 = r + 16 < th;
+        const uint8_t* row1 = src + (size_t)reflect1(ty * th + (has1 ? r + 16 : r), h) * stride;
+        for (int c0 = 0; c0 < tw; c0 += 256) {
+            int v0[4], v1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + lane + 64 * j;
+                const int xs = reflect1(tx * tw + (c < tw ? c : 0), w);
+                v0[j] = c < tw ? (int)row0[xs] : -1;
+                v1[j] = (c < tw && has1) ? (int)row1[xs] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (v0[j] >= 0) atomicAdd(&hist[wv][v0[j]], 1);
+                if (v1[j] >= 0) atomicAdd(&hist[wv][v1[j]], 1);
+            }
+        }
     }
     __syncthreads();
-    int hv = (hist[0][tid] + hist[1][tid]) + (hist[2][tid] + hist[3][tid]);
+    int hv = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hv += hist[k][tid];
+    }
     if (clip_limit > 0) {
         const int excess = hv > clip_limit ? hv - clip_limit : 0;
         hv -= excess;
@@ -39,7 +61,7 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t* __restric
     const int sum = block_exscan(hv, &total, s_w) + hv;      // inclusive
     int v = (int)rintf((float)sum * lut_scale);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    lut[(size_t)t * 256 + tid] = (uint8_t)v;
+    if (tid < 256) lut[(size_t)t * 256 + tid] = (uint8_t)v;
 }
 
 #define CLAHE_MAX_TILES 64

@@ -54,6 +54,9 @@ struct rvio_hip {
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
+    uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
+    rvio_imu* hb_imu[2] = {nullptr, nullptr};
+    float* hb_cand[2] = {nullptr, nullptr};
     uint8_t *d_eq = nullptr, *d_lut = nullptr;   // CLAHE output image and tile LUTs (enable_equalizer)
     int cl_tx = 0, cl_ty = 0, cl_tw = 0, cl_th = 0, cl_clip = 0;
     float cl_scale = 0.f;
@@ -541,7 +544,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     const DevCfg& d = h->dc;
     PyrDev& p = h->pyr[b];
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
-        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
+        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, h->d_lut);
         hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                            1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq);
@@ -696,6 +699,29 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
     h->frame_no++;
     return rc;
+}
+// The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253 (a cv::Mat and the IMU list).
+// The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap
+// the previous frame's filter work like the tracker kernels do.
+int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
+    if (!h || !img || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nc = std::min(n_cand, h->dc.F);
+    if (nc > 0 && !cand_xy) return RVIO_ERR_INVALID;
+    if (!h->hb_img[0])
+        for (int k = 0; k < 2; ++k) {
+            DALLOC(h, h->hb_img[k], (size_t)h->dc.W * h->dc.H);
+            DALLOC(h, h->hb_imu[k], (size_t)RVIO_MAX_IMU);
+            DALLOC(h, h->hb_cand[k], (size_t)2 * h->dc.F);
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // DALLOC clears on the filter stream
+        }
+    const int b = (int)(h->frame_no & 1);
+    if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
+    else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->hb_img[b], h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream_t));
+    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
+    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
+    return rvio_hip_frame_dev(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, h->hb_cand[b], nc);
 }
 // direct-track variant of the whole frame (host inputs)
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rvio_hip_stream", "rvio_hip_sync", "rvio_hip_set_state", "rvio_hip_get_state", "rvio_hip_initialize",
     "rvio_hip_propagate", "rvio_hip_update", "rvio_hip_augment_compose", "rvio_hip_track", "rvio_hip_track_dev",
     "rvio_hip_track_points", "rvio_hip_get_tracks", "rvio_hip_get_tracker_points", "rvio_hip_update_tracked",
-    "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
+    "rvio_hip_frame", "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel",
@@ -149,6 +149,14 @@ class RvioHip:
         cand = np.ascontiguousarray(cand, np.float32)
         self._ck(self.L.rvio_hip_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
                                        _p(cand, fp), len(cand)), "track")
+
+    def frame(self, img, imu, cand):
+        """whole MonoVIO body from host buffers (System.cc:253-367)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        imu = np.ascontiguousarray(imu)
+        cand = np.ascontiguousarray(cand, np.float32)
+        self._ck(self.L.rvio_hip_frame(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
+                                       _p(cand, fp), len(cand)), "frame")
 
     def track_points(self, tracked, status, imu, cand):
         tracked = np.ascontiguousarray(tracked, np.float32)

@@ -82,6 +82,31 @@ def test_tracker_sequence_bit_exact(gpu_required, frames):
     h.close()
 
 
+def test_whole_frame_from_host_buffers(gpu_required, frames):
+    """rvio_hip_frame (host image / IMU / corners, copies on the tracker stream, no sync between frames) gives the same
+    states as the oracle's System::MonoVIO body — the pipelined staging must not let frame k+1's copies disturb frame k."""
+    from rvio_amd import hip
+    import scenarios as S
+    cfg, seq, ks, imgs = frames
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    for k, img in zip(ks, imgs):
+        xy, vis = seq.project(k, noise=False)
+        cand, _ = seq.candidates(k, xy, vis)
+        imu = seq.imu_between(k)
+        s.frame(imu, cand, img=img)
+        h.frame(img.copy(), imu.copy(), cand.copy())     # temporaries: the call must have consumed them on return
+    h.sync()
+    xa, Pa = h.get_state()
+    xb, Pb = s.get_state()
+    h.close()
+    assert S.state_delta(xa, xb) <= 1e-6
+
+
 def test_whole_frame_with_images(gpu_required, frames):
     """System::MonoVIO body on images: HIP vs oracle states within 1e-6 over the sequence."""
     from rvio_amd import hip
