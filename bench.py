@@ -2,8 +2,8 @@
 """bench.py — camera frames/s of the MI355X-native R-VIO hot path (BASELINE.json metric).
 
 A "step" is one pass of the per-frame hot path (System::MonoVIO timed body, System.cc:253-367:
-KLT track + RANSAC + book-keeping -> IMU propagate -> MSCKF update -> augment/compose) over one
-synthetic EuRoC-shaped 752x480 frame with its ~10 IMU samples and its detector corner list, all
+CLAHE + corner detection + KLT track + RANSAC + book-keeping -> IMU propagate -> MSCKF update ->
+augment/compose) over one synthetic EuRoC-shaped 752x480 frame with its ~10 IMU samples, all
 resident in HBM before the timed region.  N=1 workload = BASELINE.json configs[1] (cfg B: 200
 features, 10-clone window).  N>1: the feature-sharded updater — every rank runs the
 replicated front end + propagate, builds the Jacobians / nullspace / gate / compression of its
@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-streams", action="store_true")
     ap.add_argument("--no-equalizer", action="store_true", help="Tracker.EnableEqualizer: 0 (skip CLAHE)")
+    ap.add_argument("--host-corners", action="store_true",
+                    help="feed a caller-side corner list (projected landmarks) instead of running the device detector")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     args = ap.parse_args()
 
@@ -112,6 +114,10 @@ def main():
     imu_stride_b = d_imu.shape[1]
     cand_stride_b = cfg.n_features * 2 * 4
     p_img, p_imu, p_cand = d_imgs.data_ptr(), d_imu.data_ptr(), d_cand.data_ptr()
+    if not args.host_corners:
+        # stock behaviour: FeatureDetector::DetectWithSubPix runs inside the library (NULL corner list), also in the CPU baseline
+        p_cand, cand_stride_b, cand_arr = 0, 0, None
+        cand_cnt = np.zeros_like(cand_cnt)
 
     wi, ai, ni = seq.init_from_static(K0)
     h.initialize(wi, ai, ni)
@@ -162,8 +168,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f64 (filter) / u8+i32+f32 (KLT)", "data": "synthetic",
-        "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer %s"
-                               % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off"),
+        "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer %s, corners from %s"
+                               % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off",
+                                  "a caller-side list" if args.host_corners else "the device detector (GFTT + cornerSubPix)"),
                    "parallelism": "1 process/GPU; feature-sharded updater + 1 all-gather/frame" if world > 1 else "single GPU"},
         "gpu_ms_per_step_events": gpu_ms / K,
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
@@ -180,7 +187,13 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
             if xs_cpu is not None and "x_at_cpu_frames" in out:
-                out["max_state_delta_vs_cpu"] = float(np.max(np.abs(_qfix(out.pop("x_at_cpu_frames")) - _qfix(xs_cpu))))
+                xg = _qfix(out.pop("x_at_cpu_frames"))
+                out["max_state_delta_vs_cpu"] = float(np.max(np.abs(xg - _qfix(xs_cpu[0]))))
+                out["max_state_delta_vs_cpu_information_form"] = float(np.max(np.abs(xg - _qfix(xs_cpu[1]))))
+                out["parity_note"] = ("vs_cpu = the literal restatement of the reference (Givens QR + rank truncation, Updater.cc:469-529) after "
+                                      "the same free-running frames; information_form = the same oracle with the update in the device's "
+                                      "formulation.  They differ only in updates where the reference's order-dependent rank truncation discards "
+                                      "informative rows (tests/test_truncation.py, DESIGN.md section 3)")
         out.pop("x_at_cpu_frames", None)
     h.close()
     if rank == 0:
@@ -309,7 +322,7 @@ def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni,
     n = len(imgs)
 
     def frame(i):
-        h.frame(imgs[i], imu_arr[i, : imu_cnt[i]], cand_arr[i, : cand_cnt[i]])
+        h.frame(imgs[i], imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]])
     for i in range(n_warm):
         frame(i)
     h.sync()
@@ -319,7 +332,8 @@ def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni,
     h.sync()
     el = time.perf_counter() - t0
     h.close()
-    return {"value": (n - n_warm) / el, "unit": "frames/s", "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + cand_arr[0].nbytes),
+    return {"value": (n - n_warm) / el, "unit": "frames/s",
+            "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + (0 if cand_arr is None else cand_arr[0].nbytes)),
             "note": "pageable host memory, hipMemcpyAsync on the tracker stream"}
 
 
@@ -333,11 +347,16 @@ def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, n
     tms = []
     t0 = time.perf_counter()
     for i in range(n):
-        info, t, pp, pq = s.frame(imu_arr[i, : imu_cnt[i]], cand_arr[i, : cand_cnt[i]], img=imgs[i])
+        info, t, pp, pq = s.frame(imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]], img=imgs[i])
         tms.append(t)
     el = time.perf_counter() - t0
     tms = np.array(tms)[20:]
-    xs, _ = s.get_state()
+    xs_lit, _ = s.get_state()
+    s2 = O.System(cfg, information_form=True)          # untimed: the same frames with the update in the device's formulation
+    s2.set_state(x0, P0)
+    for i in range(n):
+        s2.frame(imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]], img=imgs[i])
+    xs = (xs_lit, s2.get_state()[0])
     return ({"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
              "sample": "first %d frames of the same synthetic sequence, oracle/liborc.so (g++ -O3, single thread); "
                        "p50 ms: track %.3f propagate %.3f update %.3f augment+compose %.3f"

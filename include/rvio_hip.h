@@ -165,6 +165,16 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride,
  * RANSAC, book-keeping, refill) runs on the device as in rvio_hip_track. */
 int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
+/* Corner lists.  Every image entry point (rvio_hip_track, rvio_hip_track_dev, rvio_hip_frame,
+ * rvio_hip_frame_dev) accepts cand_xy == NULL: the library then runs
+ * FeatureDetector::DetectWithSubPix (FeatureDetector.cc:55-75: goodFeaturesToTrack with
+ * s*nMinDist, s = 1 on the first image / 2 on refills, + cornerSubPix) on the device, on the image
+ * the tracker sees (after CLAHE), on its own stream beside pyramid/KLT/RANSAC.  A non-NULL list
+ * replaces the detector (caller-side detection).  rvio_hip_get_corners copies the device
+ * detector's last result out: refined corners, the corners before cornerSubPix and the
+ * min-eigenvalue map (W*H floats); each pointer may be NULL. */
+int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, float* eig);
+
 /* Copy the device-resident mvFeatTypesForUpdate / mvlFeatMeasForUpdate out.
  * Buffers must hold ceil(n_features/2) entries (x max_track_len x 2 floats). */
 int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas);

@@ -474,7 +474,16 @@ static void track_impl(orc_tracker* T, const uint8_t* img, int stride, const flo
     }
     if (img) cur = build_pyramid(img, w, h, stride, true);
     T->types.clear(); T->meas.clear(); T->meas.resize(T->Fu);
+    // corners: the caller's list, or (cand == NULL) FeatureDetector::DetectWithSubPix on the image the tracker sees
+    std::vector<float> det;
+    auto corners_for = [&](int s_factor) {
+        if (cand || !img) return;
+        det.assign((size_t)2 * T->F, 0.f);
+        n_cand = orc_detect(&c, img, stride, s_factor, det.data());
+        cand = det.data();
+    };
     if (T->first) {  // :204-234
+        corners_for(1);
         int n = std::min(n_cand, T->F);
         if (n > 0) {
             T->feats.clear();
@@ -535,6 +544,7 @@ static void track_impl(orc_tracker* T, const uint8_t* img, int stride, const flo
         }
         if (!T->freeIdx.empty()) {  // refill :344-387
             std::vector<Pt> corners;
+            corners_for(2);
             for (int i = 0; i < std::min(n_cand, T->F); ++i) corners.push_back({cand[2 * i], cand[2 * i + 1]});
             std::deque<Pt> fresh;
             find_newer(T, corners, newFeats, fresh);
@@ -595,9 +605,14 @@ struct orc_system {
     orc_tracker* trk;
     std::vector<double> x, P;
     int xdim = 26, d = 24, nClones = 0, nImg = 0;
+    int info_form = 0;    // 1: update through orc_update_local/global (the device's formulation) instead of the literal path
+    int last_rank = -1;   // nRank of the literal path's last tall compression (-1: fat / no update)
 };
 
 extern "C" {
+
+void orc_system_set_information_form(orc_system* S, int on) { S->info_form = on; }
+int orc_system_last_rank(orc_system* S) { return S->last_rank; }
 
 orc_system* orc_system_create(const rvio_config* cfg) {
     orc_system* S = new orc_system();
@@ -638,7 +653,16 @@ void orc_system_frame(orc_system* S, const uint8_t* img, int stride, const float
         rvio_tracks tr = {nf, ML, types.data(), len.data(), meas.data()};
         std::vector<double> xo(S->x.size()), Po(S->P.size());
         int32_t inf[4];
-        orc_update(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, &tr, xo.data(), Po.data(), nullptr, nullptr, nullptr, nullptr, inf);
+        if (S->info_form) {   // analysis mode: the information-form restatement of the same update (no rank truncation)
+            const int nc6 = 6 * S->nClones;
+            std::vector<double> blk((size_t)nc6 * (nc6 + 1) + 2);
+            orc_update_local(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, &tr, 0, 1, blk.data());
+            orc_update_global(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, blk.data(), 1, xo.data(), Po.data(), inf);
+            S->last_rank = -1;
+        } else {
+            orc_update(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, &tr, xo.data(), Po.data(), nullptr, nullptr, nullptr, nullptr, inf);
+            S->last_rank = inf[2];
+        }
         std::memcpy(S->x.data(), xo.data(), sizeof(double) * S->xdim);
         std::memcpy(S->P.data(), Po.data(), sizeof(double) * S->d * S->d);
         fi.n_feat_accepted = inf[0]; fi.n_rows = inf[1]; fi.updated = inf[3];

@@ -80,7 +80,15 @@ void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
 /* ---- T0: cv::createCLAHE(3.0, Size(5,5))->apply, Tracker.cc:198-202 (OpenCV clahe.cpp restated); out is w*h, packed ---- */
 void orc_clahe(const uint8_t* img, int w, int h, int stride, uint8_t* out);
 
-/* ---- T1/T6: Tracker::track, Tracker.cc:179-396 (detector replaced by caller-supplied corners) ---- */
+/* ---- T7: FeatureDetector::DetectWithSubPix, FeatureDetector.cc:55-75 (OpenCV goodFeaturesToTrack + cornerSubPix restated) ---- */
+void orc_min_eig(const uint8_t* img, int w, int h, int stride, float* eig);
+int orc_gftt(const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance, float* out_xy);
+void orc_corner_subpix(const uint8_t* img, int w, int h, int stride, float* pts_xy, int n, int win);
+/* s = 1 on the first image, 2 on refills (Tracker.cc:207,350); out_xy holds n_features points; returns the count */
+int orc_detect(const rvio_config* cfg, const uint8_t* img, int stride, int s, float* out_xy);
+
+/* ---- T1/T6: Tracker::track, Tracker.cc:179-396.  cand_xy == NULL (with an image) runs the detector above on the
+ * (equalised) image like the reference; a non-NULL list replaces it (detector supplied by the caller) ---- */
 typedef struct orc_tracker orc_tracker;
 orc_tracker* orc_tracker_create(const rvio_config* cfg);
 void orc_tracker_destroy(orc_tracker*);
@@ -101,6 +109,10 @@ void orc_system_set_state(orc_system*, const double* x, int xdim, const double* 
 void orc_system_get_state(orc_system*, double* x, int* xdim, double* P, int* d);
 /* one frame; t_ms[0]=track, t_ms[1]=propagate, t_ms[2]=update, t_ms[3]=augment+compose */
 orc_tracker* orc_system_tracker(orc_system*);
+/* analysis: run Updater::update in the information form [A|b] = Hw^T [Hw | r] (orc_update_local/global), which keeps the
+ * rows the reference's rank truncation (Updater.cc:516-529) drops; last_rank = nRank of the literal path's last update */
+void orc_system_set_information_form(orc_system*, int on);
+int orc_system_last_rank(orc_system*);
 /* img==NULL selects direct-track mode (tracked_xy/status given) */
 void orc_system_frame(orc_system*, const uint8_t* img, int stride, const float* tracked_xy, const unsigned char* status,
                       const rvio_imu* imu, int m,

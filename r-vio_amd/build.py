@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librvio_hip.so")
-SOURCES = ["rvio_hip.hip", "filter_kernels.hip", "filter_kernels2.hip", "solve4.hip", "solve6.hip", "frontend_kernels.hip", "klt3.hip", "clahe.hip", "rvio_dev.h", "frontend_dev.h",
+SOURCES = ["rvio_hip.hip", "filter_kernels.hip", "filter_kernels2.hip", "solve4.hip", "solve6.hip", "frontend_kernels.hip", "klt3.hip", "clahe.hip", "detector.hip", "rvio_dev.h", "frontend_dev.h",
            "chi2_table.inc", os.path.join("..", "..", "include", "rvio_hip.h")]
 
 

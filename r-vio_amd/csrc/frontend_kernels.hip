@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // lengths hist_len[F]; which free slot a new feature takes is storage only and never reaches an output.
 // Dynamic LDS: tfs[F] float2 (new feature order), cds[F] float2 (candidates), cid_t[F] / cid_c[F] short (grid cell
 // of each tracked point / candidate, -1 = outside), cellp[4][F] float2 (per-wave ChessGrid cell).
-__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand) {
+// n_cand_dev != NULL: the corner count lives on the device (device detector), n_cand is ignored.
+__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev) {
     extern __shared__ __align__(16) unsigned char dsh[];
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
     float2* feats = (float2*)t.feats;
     float2* un1 = (float2*)t.un1;
     float2* tu = (float2*)t.tmp_un;
+    if (n_cand_dev) n_cand = *n_cand_dev;
     const int nc = n_cand < F ? n_cand : F;
     for (int c = tid; c < nc; c += 256) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
     int nMeas = 0;

@@ -20,6 +20,7 @@
 #include "frontend_kernels.hip"
 #include "klt3.hip"
 #include "clahe.hip"
+#include "detector.hip"
 #pragma clang fp contract(fast)
 
 struct rvio_hip {
@@ -49,11 +50,15 @@ struct rvio_hip {
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
-    size_t solve5_lds = 0;
+    size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
+    DetDev det = {};                              // device detector (T7), allocated on first use
+    bool det_ready = false, use_det = false;
+    hipStream_t stream_d = nullptr;               // detector stream: forks from / joins the tracker stream
+    hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
     rvio_imu* hb_imu[2] = {nullptr, nullptr};
     float* hb_cand[2] = {nullptr, nullptr};
@@ -288,9 +293,13 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
 void rvio_hip_destroy(rvio_hip* h) {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->stream_d) hipStreamSynchronize(h->stream_d);
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) hipFree(p);
+    if (h->evD0) hipEventDestroy(h->evD0);
+    if (h->evD1) hipEventDestroy(h->evD1);
+    if (h->stream_d) hipStreamDestroy(h->stream_d);
     for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); }
     if (h->stream_t) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -300,6 +309,7 @@ const char* rvio_hip_last_error(const rvio_hip* h) { return h ? h->err.c_str() :
 void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
 int rvio_hip_sync(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
+    if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d));
     HIPCHK(h, hipStreamSynchronize(h->stream_t));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
@@ -462,6 +472,9 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
         const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
         hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, n, d_blocks, world, (size_t)(ldh * ldh), h->Ab);
         Ab = h->Ab;
+    } else if (d_blocks != h->block) {   // a caller-owned block: the truncation below works on our copy
+        HIPCHK(h, hipMemcpyAsync(h->Ab, d_blocks, sizeof(double) * ldh * ldh, hipMemcpyDeviceToDevice, h->stream));
+        Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
     hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf);
@@ -539,6 +552,56 @@ int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
     return augment_compose_dev(h, do_augment);
 }
 
+// ------------------------------------------------------------------ T7 detector (device), allocated on first use
+static int detector_init(rvio_hip* h) {
+    if (h->det_ready) return RVIO_OK;
+    const DevCfg& d = h->dc;
+    DetDev& q = h->det;
+    const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist), cell2 = (int)std::nearbyint((double)(2.f * h->cfg.min_dist));
+    if (cell1 < 1) { h->err = "Tracker.nMinDist < 1 is not supported by the device detector"; return RVIO_ERR_UNSUPPORTED; }
+    if ((int)std::floor(.5 * h->cfg.min_dist) != SP_WIN) { h->err = "device cornerSubPix is built for floor(nMinDist/2) == 7"; return RVIO_ERR_UNSUPPORTED; }
+    const size_t npx = (size_t)d.W * d.H;
+    q.W = d.W; q.H = d.H; q.F = d.F; q.min_dist = h->cfg.min_dist; q.quality = (double)h->cfg.qual_lvl;
+    q.max_cells = ((d.W + cell1 - 1) / cell1) * ((d.H + cell1 - 1) / cell1);
+    q.first = h->t.first;
+    DALLOC(h, q.eig, npx); DALLOC(h, q.maxkey, 1); DALLOC(h, q.counters, 4); DALLOC(h, q.cell_cnt, (size_t)q.max_cells);
+    DALLOC(h, q.cell_ent, (size_t)(d.W + cell2) * (d.H + cell2)); DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
+    DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, q.xy, (size_t)2 * d.F);
+    float* mask = nullptr;
+    DALLOC(h, mask, (size_t)SP_WW * SP_WW);
+    // cornerSubPix window (cornersubpix.cpp): float expf on the host, so that device and oracle share glibc's values
+    float hm[SP_WW * SP_WW];
+    for (int i = 0; i < SP_WW; ++i) {
+        const float y = (float)(i - SP_WIN) / (float)SP_WIN;
+        const float vy = std::exp(-y * y);
+        for (int j = 0; j < SP_WW; ++j) { const float x = (float)(j - SP_WIN) / (float)SP_WIN; hm[i * SP_WW + j] = (float)(vy * std::exp(-x * x)); }
+    }
+    const int minkey = (int)0x80000000;
+    HIPCHK(h, hipMemcpyAsync(mask, hm, sizeof hm, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(q.maxkey, &minkey, sizeof minkey, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    q.spmask = mask;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->evD0, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->evD1, hipEventDisableTiming));
+    h->det_ready = true;
+    return RVIO_OK;
+}
+// forks from the tracker stream (the image `img` is complete there), runs beside pyramid/KLT/RANSAC, joined before book-keeping
+static int detect_dev(rvio_hip* h, const uint8_t* img, int stride) {
+    const DevCfg& d = h->dc;
+    HIPCHK(h, hipEventRecord(h->evD0, h->ts));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
+    const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH);
+    hipLaunchKernelGGL(mineig_kernel, g, dim3(256), 0, h->stream_d, img, stride, h->det);
+    hipLaunchKernelGGL(nms_kernel, g, dim3(256), 0, h->stream_d, h->det);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GREEDY_T), 0, h->stream_d, h->det);
+    hipLaunchKernelGGL(subpix_kernel, dim3(d.F), dim3(64), 0, h->stream_d, img, stride, h->det);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
+    return RVIO_OK;
+}
+
 // ------------------------------------------------------------------ T1..T6
 static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int b) {
     const DevCfg& d = h->dc;
@@ -549,6 +612,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                            1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq);
         d_img = h->d_eq; stride = d.W;
+    }
+    if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
+        const int rc = detect_dev(h, d_img, stride);
+        if (rc != RVIO_OK) return rc;
     }
     // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
     for (int l = 0; l < d.levels; ++l) {
@@ -566,7 +633,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), (size_t)5 * h->dc.F + 16, h->ts, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info);
-    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand);
+    if (h->use_det) {   // join the detector stream: its corner list replaces the caller's
+        HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, (const float*)h->det.xy, 0, (const int*)(h->det.counters + 2));
+    } else
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -575,8 +646,11 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped && h->ts == h->stream) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    int rc;
+    h->use_det = (d_cand == nullptr);   // no corner list from the caller: run FeatureDetector::DetectWithSubPix on the device
+    if (h->use_det && (rc = detector_init(h)) != RVIO_OK) return rc;
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
-    int rc = build_pyramid_dev(h, d_img, stride, nb);
+    rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
     hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F), dim3(64), 0, h->ts, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
                        h->t.tracked, h->t.status);
@@ -591,8 +665,8 @@ int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     const int nc = std::min(n_cand, h->dc.F);
     HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
-    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
-    return rvio_hip_track_dev(h, h->d_img, h->dc.W, h->d_imu, m, h->d_cand, nc);
+    if (nc > 0 && cand_xy) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
+    return rvio_hip_track_dev(h, h->d_img, h->dc.W, h->d_imu, m, cand_xy ? h->d_cand : nullptr, cand_xy ? nc : 0);
 }
 
 // direct-track mode: the caller supplies the KLT result
@@ -608,6 +682,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
     HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);
+    h->use_det = false;   // no image in this mode
     return post_klt_dev(h, h->d_imu, m, h->d_cand, nc);
 }
 
@@ -706,8 +781,7 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
     if (!h || !img || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    const int nc = std::min(n_cand, h->dc.F);
-    if (nc > 0 && !cand_xy) return RVIO_ERR_INVALID;
+    const int nc = cand_xy ? std::min(n_cand, h->dc.F) : 0;   // cand_xy == NULL: device detector
     if (!h->hb_img[0])
         for (int k = 0; k < 2; ++k) {
             DALLOC(h, h->hb_img[k], (size_t)h->dc.W * h->dc.H);
@@ -721,7 +795,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     HIPCHK(h, hipMemcpy2DAsync(h->hb_img[b], h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream_t));
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
-    return rvio_hip_frame_dev(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, h->hb_cand[b], nc);
+    return rvio_hip_frame_dev(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc);
 }
 // direct-track variant of the whole frame (host inputs)
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
@@ -758,6 +832,21 @@ int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]) {
 
 // ------------------------------------------------------------------ diagnostics for parity tests
 extern "C" {
+// output of the device detector for the most recent image: corner count, refined corners, goodFeaturesToTrack corners
+// before cornerSubPix, and the min-eigenvalue map (each pointer may be NULL)
+int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, float* eig) {
+    if (!h) return RVIO_ERR_INVALID;
+    if (!h->det_ready) { h->err = "the device detector has not run (pass a NULL corner list to track/frame)"; return RVIO_ERR_INVALID; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream_d));
+    int cnt[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpy(cnt, h->det.counters, sizeof cnt, hipMemcpyDeviceToHost));
+    if (n) *n = cnt[2];
+    if (xy && cnt[2] > 0) HIPCHK(h, hipMemcpy(xy, h->det.xy, sizeof(float) * 2 * cnt[2], hipMemcpyDeviceToHost));
+    if (raw_xy && cnt[2] > 0) HIPCHK(h, hipMemcpy(raw_xy, h->det.raw_xy, sizeof(float) * 2 * cnt[2], hipMemcpyDeviceToHost));
+    if (eig) HIPCHK(h, hipMemcpy(eig, h->det.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
+    return RVIO_OK;
+}
 // pyramid level `level` of the most recent image: u8 image (w*h) and int16 (dx,dy) derivative (w*h*2)
 int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy) {
     if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;

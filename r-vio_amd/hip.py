@@ -21,7 +21,7 @@ SYMBOLS = [
     "rvio_hip_frame", "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
-    "rvio_hip_debug_time_kernel",
+    "rvio_hip_debug_time_kernel", "rvio_hip_get_corners",
 ]
 
 _LIB = None
@@ -143,20 +143,37 @@ class RvioHip:
         self._ck(self.L.rvio_hip_augment_compose(self.h, int(do_augment)), "augment_compose")
 
     # ---- front end
-    def track(self, img, imu, cand):
-        img = np.ascontiguousarray(img, np.uint8)
-        imu = np.ascontiguousarray(imu)
+    @staticmethod
+    def _cand(cand):
+        """(pointer, count) of a corner list; None selects the device detector"""
+        if cand is None:
+            return None, 0, None
         cand = np.ascontiguousarray(cand, np.float32)
-        self._ck(self.L.rvio_hip_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
-                                       _p(cand, fp), len(cand)), "track")
+        return _p(cand, fp), len(cand), cand
 
-    def frame(self, img, imu, cand):
-        """whole MonoVIO body from host buffers (System.cc:253-367)"""
+    def track(self, img, imu, cand=None):
         img = np.ascontiguousarray(img, np.uint8)
         imu = np.ascontiguousarray(imu)
-        cand = np.ascontiguousarray(cand, np.float32)
+        cp, cn, _keep = self._cand(cand)
+        self._ck(self.L.rvio_hip_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
+                                       cp, cn), "track")
+
+    def frame(self, img, imu, cand=None):
+        """whole MonoVIO body from host buffers (System.cc:253-367); cand=None: device detector"""
+        img = np.ascontiguousarray(img, np.uint8)
+        imu = np.ascontiguousarray(imu)
+        cp, cn, _keep = self._cand(cand)
         self._ck(self.L.rvio_hip_frame(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
-                                       _p(cand, fp), len(cand)), "frame")
+                                       cp, cn), "frame")
+
+    def get_corners(self, want_eig=False):
+        """last result of the device detector: (refined corners, goodFeaturesToTrack corners[, min-eigenvalue map])"""
+        F = self.cfg.n_features
+        n = C.c_int32(0)
+        xy, raw = np.zeros((F, 2), np.float32), np.zeros((F, 2), np.float32)
+        eig = np.zeros((self.cfg.height, self.cfg.width), np.float32) if want_eig else None
+        self._ck(self.L.rvio_hip_get_corners(self.h, C.byref(n), _p(xy, fp), _p(raw, fp), _p(eig, fp) if want_eig else None), "get_corners")
+        return (xy[: n.value].copy(), raw[: n.value].copy()) + ((eig,) if want_eig else ())
 
     def track_points(self, tracked, status, imu, cand):
         tracked = np.ascontiguousarray(tracked, np.float32)

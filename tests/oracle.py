@@ -186,6 +186,39 @@ def clahe(img):
     return out
 
 
+def min_eig(img):
+    """cv::cornerMinEigenVal(blockSize 3, ksize 3) restated"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    lib().orc_min_eig(_p(img, up), w, h, w, _p(out, fp))
+    return out
+
+
+def gftt(img, max_corners, quality, min_distance):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((max(max_corners, 1), 2), np.float32)
+    n = lib().orc_gftt(_p(img, up), w, h, w, int(max_corners), C.c_double(quality), C.c_double(min_distance), _p(out, fp))
+    return out[:n].copy()
+
+
+def corner_subpix(img, pts, win=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    pts = np.ascontiguousarray(pts, np.float32).copy()
+    lib().orc_corner_subpix(_p(img, up), w, h, w, _p(pts, fp), len(pts), int(win))
+    return pts
+
+
+def detect(cfg, img, s):
+    """FeatureDetector::DetectWithSubPix (FeatureDetector.cc:55-75)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((cfg.n_features, 2), np.float32)
+    n = lib().orc_detect(C.byref(cfg), _p(img, up), img.shape[1], int(s), _p(out, fp))
+    return out[:n].copy()
+
+
 def scharr(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
@@ -216,13 +249,18 @@ class Tracker:
             lib().orc_tracker_destroy(self.h)
             self.h = None
 
-    def track(self, img, imu, cand):
+    def track(self, img, imu, cand=None):
+        """cand=None: the oracle runs FeatureDetector::DetectWithSubPix itself (as the reference does)"""
         img = np.ascontiguousarray(img, np.uint8)
         imu = np.ascontiguousarray(imu)
-        cand = np.ascontiguousarray(cand, np.float32)
         info = abi.rvio_frame_info()
+        if cand is None:
+            cp, cn = None, 0
+        else:
+            cand = np.ascontiguousarray(cand, np.float32)
+            cp, cn = _p(cand, fp), len(cand)
         lib().orc_tracker_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
-                                _p(cand, fp), len(cand), C.byref(info))
+                                cp, cn, C.byref(info))
         return info.asdict()
 
     def track_points(self, tracked, status, imu, cand):
@@ -253,10 +291,17 @@ class Tracker:
 class System:
     """oracle mirror of the timed body of System::MonoVIO."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, information_form=False):
+        """information_form=True: analysis mode — the update runs in the device's formulation ([A|b] = Hw^T[Hw|r]),
+        which keeps the rows the reference's rank truncation (Updater.cc:516-529) drops."""
         self.cfg = cfg
         self.h = C.c_void_p(lib().orc_system_create(C.byref(cfg)))
         self.nmax = cfg.max_track_len - 1
+        if information_form:
+            lib().orc_system_set_information_form(self.h, 1)
+
+    def last_rank(self):
+        return int(lib().orc_system_last_rank(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -277,7 +322,12 @@ class System:
 
     def frame(self, imu, cand, img=None, tracked=None, status=None):
         imu = np.ascontiguousarray(imu)
-        cand = np.ascontiguousarray(cand, np.float32)
+        if cand is None:
+            cand = np.zeros((0, 2), np.float32)
+            cand_p = None
+        else:
+            cand = np.ascontiguousarray(cand, np.float32)
+            cand_p = _p(cand, fp)
         info = abi.rvio_frame_info()
         tms, pp, pq = np.zeros(4), np.zeros(3), np.zeros(4)
         if img is not None:
@@ -288,7 +338,7 @@ class System:
             status = np.ascontiguousarray(status, np.uint8)
             ia, st, tx, ss = None, 0, _p(tracked, fp), _p(status, up)
         lib().orc_system_frame(self.h, ia, st, tx, ss, imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
-                               _p(cand, fp), len(cand), C.byref(info), _p(tms, dp), _p(pp, dp), _p(pq, dp))
+                               cand_p, len(cand), C.byref(info), _p(tms, dp), _p(pp, dp), _p(pq, dp))
         return info.asdict(), tms, pp, pq
 
     def tracker(self):
