@@ -147,8 +147,10 @@ void rect_subpix(const uint8_t* src, int w, int h, int stride, float cx, float c
     }
 }
 
-// cornerSubPix, cornersubpix.cpp.  Accumulation order of the five double sums: canonical = row sums left->right, then the rows
-// top->bottom (OpenCV adds the 225 terms in one row-major chain; the difference is O(1e-16) relative).
+// cornerSubPix, cornersubpix.cpp.  Accumulation order of the five double sums (OpenCV adds the 225 terms in one row-major
+// chain; any fixed order differs from it by O(1e-16) relative): canonical = the terms on a zero-padded 16 x 16 grid, per
+// row a balanced binary tree over the columns, the rows in groups of four ((R0 + R1) + (R2 + R3)), the four groups the
+// same way.  Written for window half-sizes <= 7 (<= 15 rows / columns).
 void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps) {
     const int ww = 2 * win + 1, pw = ww + 2;
     std::vector<float> mask((size_t)ww * ww), patch((size_t)pw * pw);
@@ -169,23 +171,42 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
         double err = 0;
         do {
             rect_subpix(src, w, h, stride, cx, cy, pw, pw, patch.data());
-            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            // term[q][i][j] on a 16 x 16 grid (row / column 15 are zero padding)
+            static thread_local double term[5][16][16];
+            std::memset(term, 0, sizeof term);
             for (int i = 0; i < ww; ++i) {
                 const float* sp = &patch[(size_t)(i + 1) * pw + 1];
                 const double py = i - win;
-                double ra = 0, rb = 0, rc = 0, r1 = 0, r2 = 0;
                 for (int j = 0; j < ww; ++j) {
+                    const double px = j - win;
                     const double m = mask[(size_t)i * ww + j];
                     const double tgx = sp[j + 1] - sp[j - 1];
                     const double tgy = sp[j + pw] - sp[j - pw];
                     const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                    const double px = j - win;
-                    ra += gxx; rb += gxy; rc += gyy;
-                    r1 += gxx * px + gxy * py;
-                    r2 += gxy * px + gyy * py;
+                    term[0][i][j] = gxx; term[1][i][j] = gxy; term[2][i][j] = gyy;
+                    term[3][i][j] = gxx * px + gxy * py;
+                    term[4][i][j] = gxy * px + gyy * py;
                 }
-                a += ra; b += rb; c += rc; bb1 += r1; bb2 += r2;
             }
+            // per row a balanced tree over the 16 columns: (j, j+8), then +4, +2, +1 -> R_i; groups of four rows
+            // W_w = (R_4w + R_4w+1) + (R_4w+2 + R_4w+3); total = (W_0 + W_1) + (W_2 + W_3)
+            double tot[5];
+            for (int q = 0; q < 5; ++q) {
+                double R[16];
+                for (int i = 0; i < 16; ++i) {
+                    double* v = term[q][i];
+                    for (int s = 8; s >= 1; s >>= 1) {
+                        double t[16];
+                        for (int j = 0; j < 16; ++j) t[j] = v[j] + v[(j + s) & 15];
+                        for (int j = 0; j < 16; ++j) v[j] = t[j];
+                    }
+                    R[i] = v[0];
+                }
+                double Wg[4];
+                for (int g = 0; g < 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
+                tot[q] = (Wg[0] + Wg[1]) + (Wg[2] + Wg[3]);
+            }
+            const double a = tot[0], b = tot[1], c = tot[2], bb1 = tot[3], bb2 = tot[4];
             const double det = a * c - b * b;
             if (std::fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
             const double scale = 1.0 / det;

@@ -6,12 +6,18 @@
 //   mineig_kernel     Sobel 3x3 (scaled) -> products -> 3x3 box (double) -> lambda_min, + image maximum (atomic on an ordered key)
 //   nms_kernel        threshold at max*quality, strict 3x3 local maxima away from the border -> candidate list + per-cell buckets
 //   greedy_kernel     OpenCV's sequential min-distance selection in descending-strength order, computed as the
-//                     lexicographically-first maximal independent set by priority rounds (a candidate is taken once no
-//                     stronger undecided candidate lies within the distance; it is dropped once a taken one does): the
-//                     fixpoint equals the sequential result; then rank-by-counting keeps the strongest nFeatures in order
-//   subpix_kernel     one wave per corner: 17x17 bilinear patch in LDS, lane <-> row of the 15x15 window, double sums in
-//                     the oracle's canonical order (row sums left->right, rows top->bottom), 2x2 solve, <= 30 iterations
+//                     lexicographically-first maximal independent set by priority rounds: a candidate is dropped once a
+//                     STRONGER candidate within the distance is taken, and taken once all of those are dropped; the
+//                     fixpoint equals the sequential result.  Rank-by-counting keeps the strongest nFeatures, in order.
+//   neigh_kernel      (many workgroups) the stronger neighbours of every candidate -> lists; greedy_kernel (one workgroup)
+//                     runs the rounds on those lists with the candidate states in LDS, then ranks
+//   subpix_kernel     one workgroup of 4 waves per corner: the neighbourhood cached in LDS, 17x17 bilinear patch, one
+//                     window term per thread, double sums in the oracle's canonical tree order, 2x2 solve, <= 30 iterations
 #pragma once
+
+#define DET_NBCAP 64          // stronger-neighbour list capacity per candidate (global memory)
+#define DET_FAST_N 2048       // up to this many candidates neigh_kernel buckets them in LDS
+#define DET_FAST_CELLS 4096   // ... given at most this many grid cells
 
 struct DetDev {
     const int* first;        // Tracker's mbIsTheFirstImage (device)
@@ -19,10 +25,14 @@ struct DetDev {
     int* maxkey;             // ordered-int key of the image maximum
     int* counters;           // [0] n candidates, [1] n accepted, [2] n output corners
     int* cell_cnt;           // [cells at s=1]
-    unsigned long long* cell_ent;   // bucketed candidate keys  [(W+64)*(H+64)]
+    unsigned long long* cell_ent;   // bucketed candidate keys  [(W+cell)*(H+cell)]
+    int* cell_ci;                   // ... and their index in `cand`
+    int* nb;                        // general path: stronger neighbours within the distance, per candidate  [n_cap][DET_NBCAP]
+    int* nb_cnt;                    // list length, or -1 if it overflowed (that candidate scans its cells every round)
+    int n_cap;                      // candidates with a neighbour list (the rest scan)
     unsigned long long* cand;       // flat candidate keys      [W*H]
     unsigned long long* acc;        // accepted keys            [W*H]
-    unsigned char* state;           // per pixel: 1 undecided, 2 taken, 3 dropped (only candidate pixels are ever read)
+    unsigned char* state;           // general path, per candidate: 1 undecided, 2 taken, 3 dropped
     float* raw_xy;           // goodFeaturesToTrack output [F][2]
     float* xy;               // after cornerSubPix         [F][2]
     const float* spmask;     // 15x15 Gaussian window of cornerSubPix (host-computed: expf is glibc's)
@@ -36,20 +46,21 @@ __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f);
 __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
 
 #define DET_TW 64
-#define DET_TH 4
-__global__ __launch_bounds__(256) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
+#define DET_TH 8
+#define DET_T (DET_TW * DET_TH)
+__global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
     __shared__ float sdx[DET_TH + 2][DET_TW + 2], sdy[DET_TH + 2][DET_TW + 2];
-    __shared__ int s_max[4];
+    __shared__ int s_max[DET_TH];
     const int W = d.W, H = d.H;
     const int tid = threadIdx.x, x0 = blockIdx.x * DET_TW, y0 = blockIdx.y * DET_TH;
     if (blockIdx.x == 0 && blockIdx.y == 0) {          // per-frame reset of the detector's counters (nothing in this kernel reads them)
-        for (int i = tid; i < d.max_cells; i += 256) d.cell_cnt[i] = 0;
+        for (int i = tid; i < d.max_cells; i += DET_T) d.cell_cnt[i] = 0;
         if (tid < 3) d.counters[tid] = 0;
     }
     const double scale = 1.0 / (4.0 * 3.0 * 255.0);
     const float k1 = (float)scale, k0 = (float)(2.0 * scale);
     // gradients on the (TW+2) x (TH+2) halo; positions outside the image take the gradient AT the reflected position
-    for (int e = tid; e < (DET_TW + 2) * (DET_TH + 2); e += 256) {
+    for (int e = tid; e < (DET_TW + 2) * (DET_TH + 2); e += DET_T) {
         const int ly = e / (DET_TW + 2), lx = e % (DET_TW + 2);
         const int gy = reflect1(y0 + ly - 1, H), gx = reflect1(x0 + lx - 1, W);
         float dxv = 0.f, dyv = 0.f;
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(256) void mineig_kernel(const uint8_t* __restrict__
     __syncthreads();
     if (tid == 0) {
         int m = s_max[0];
-        for (int k = 1; k < 4; ++k) m = s_max[k] > m ? s_max[k] : m;
+        for (int k = 1; k < DET_TH; ++k) m = s_max[k] > m ? s_max[k] : m;
         atomicMax(d.maxkey, m);
     }
 }
@@ -112,9 +123,9 @@ __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* ce
     *gw = (d.W + *cell - 1) / *cell; *gh = (d.H + *cell - 1) / *cell;
 }
 
-__global__ __launch_bounds__(256) void nms_kernel(DetDev d) {
+__global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d) {
     const int W = d.W, H = d.H;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * DET_TW + (threadIdx.x & 63), y = blockIdx.y * DET_TH + (threadIdx.x >> 6);
     if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) return;
     const float mx = ord2f(*d.maxkey);
     const float thr = (float)((double)mx * d.quality);
@@ -130,71 +141,196 @@ __global__ __launch_bounds__(256) void nms_kernel(DetDev d) {
     det_geometry(d, &md, &cell, &gw, &gh);
     const int idx = y * W + x;
     const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)idx;   // v > 0: bits are ordered
-    d.state[idx] = 1;
-    d.cand[atomicAdd(&d.counters[0], 1)] = key;
+    const int ci = atomicAdd(&d.counters[0], 1);
+    d.cand[ci] = key;
     const int c = (y / cell) * gw + (x / cell);
-    d.cell_ent[(size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1)] = key;
+    const size_t slot = (size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1);
+    d.cell_ent[slot] = key;
+    d.cell_ci[slot] = ci;
+}
+
+#define NEIGH_T 1024
+#define NEIGH_BLOCKS 8
+// LDS of neigh_kernel's bucket build: keys 8 B, packed xy 4, cell 2, slot 2, order 2 per candidate + cell starts
+#define NEIGH_LDS (DET_FAST_N * (8 + 4 + 2 + 2 + 2) + (DET_FAST_CELLS + 2) * 4)
+
+// Every candidate collects its STRONGER neighbours within the distance — only those decide its fate: it is dropped when
+// one of them is taken, taken when all of them are dropped.  OpenCV searches the 3x3 grid cells around the candidate.
+// Up to DET_FAST_N candidates every workgroup rebuilds compact cell buckets in its LDS (a few microseconds) and walks
+// them; denser candidate sets walk the global buckets nms_kernel filled.  Lists go to d.nb (global, L2 resident).
+__global__ __launch_bounds__(NEIGH_T) void neigh_kernel(DetDev d) {
+    extern __shared__ __align__(16) unsigned char ndyn[];
+    __shared__ int s_w[16];
+    const int W = d.W, tid = threadIdx.x;
+    float md; int cell, gw, gh;
+    det_geometry(d, &md, &cell, &gw, &gh);
+    const double md2 = (double)md * (double)md;
+    const int n = d.counters[0], ncell = gw * gh;
+    if (n <= DET_FAST_N && ncell <= DET_FAST_CELLS) {
+        unsigned long long* fkey = (unsigned long long*)ndyn;                           // [N]
+        unsigned int* fxy = (unsigned int*)(fkey + DET_FAST_N);                          // [N] x | y << 16
+        int* cstart = (int*)(fxy + DET_FAST_N);                                          // [CELLS + 2]
+        unsigned short* fcell = (unsigned short*)(cstart + DET_FAST_CELLS + 2);          // [N]
+        unsigned short* fslot = fcell + DET_FAST_N;                                      // [N]
+        unsigned short* order = fslot + DET_FAST_N;                                      // [N]
+        for (int c = tid; c < ncell; c += NEIGH_T) cstart[c] = 0;
+        __syncthreads();
+        for (int c = tid; c < n; c += NEIGH_T) {
+            const unsigned long long key = d.cand[c];
+            const int idx = (int)(key & 0xffffffffull), x = idx % W, y = idx / W;
+            const int cc = (y / cell) * gw + (x / cell);
+            fkey[c] = key; fxy[c] = (unsigned)x | ((unsigned)y << 16); fcell[c] = (unsigned short)cc;
+            fslot[c] = (unsigned short)atomicAdd(&cstart[cc], 1);
+        }
+        __syncthreads();
+        {   // exclusive scan of the bucket counts (`per` consecutive cells per thread, wave scans, 16 wave totals)
+            const int per = (ncell + NEIGH_T - 1) / NEIGH_T, b0 = tid * per, lane = tid & 63, wv = tid >> 6;
+            int sum = 0;
+            for (int k = 0; k < per; ++k) if (b0 + k < ncell) sum += cstart[b0 + k];
+            const int inc = wave_incl_scan(sum);
+            if (lane == 63) s_w[wv] = inc;
+            __syncthreads();
+            int run = inc - sum;
+            for (int w = 0; w < wv; ++w) run += s_w[w];
+            for (int k = 0; k < per; ++k) if (b0 + k < ncell) { const int c = cstart[b0 + k]; cstart[b0 + k] = run; run += c; }
+            if (tid == NEIGH_T - 1) cstart[ncell] = run;
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += NEIGH_T) order[cstart[fcell[c]] + fslot[c]] = (unsigned short)c;
+        __syncthreads();
+        for (int c = blockIdx.x * NEIGH_T + tid; c < n; c += gridDim.x * NEIGH_T) {
+            const unsigned long long key = fkey[c];
+            const int x = (int)(fxy[c] & 0xffffu), y = (int)(fxy[c] >> 16), xc = x / cell, yc = y / cell;
+            const int y1 = yc > 0 ? yc - 1 : 0, y2 = yc + 1 < gh ? yc + 1 : gh - 1, x1 = xc > 0 ? xc - 1 : 0, x2 = xc + 1 < gw ? xc + 1 : gw - 1;
+            int m = 0;
+            int* list = d.nb + (size_t)c * DET_NBCAP;
+            for (int yy = y1; yy <= y2; ++yy) {
+                const int e0 = cstart[yy * gw + x1], e1 = cstart[yy * gw + x2 + 1];      // the cells of a grid row are contiguous
+                for (int e = e0; e < e1; ++e) {
+                    const int j = order[e];
+                    if (!(fkey[j] > key)) continue;
+                    const float ddx = (float)x - (float)(fxy[j] & 0xffffu), ddy = (float)y - (float)(fxy[j] >> 16);
+                    if ((double)(ddx * ddx + ddy * ddy) < md2) { if (m < DET_NBCAP) list[m] = j; ++m; }
+                }
+            }
+            d.nb_cnt[c] = m <= DET_NBCAP ? m : -1;
+        }
+        return;
+    }
+    const size_t cap = (size_t)cell * cell;
+    for (int c = blockIdx.x * NEIGH_T + tid; c < n && c < d.n_cap; c += gridDim.x * NEIGH_T) {
+        const unsigned long long key = d.cand[c];
+        const int idx = (int)(key & 0xffffffffull);
+        const int x = idx % W, y = idx / W, xc = x / cell, yc = y / cell;
+        int cnt9[9], cid9[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int xx = xc + (q % 3) - 1, yy = yc + (q / 3) - 1;
+            const bool in = xx >= 0 && yy >= 0 && xx < gw && yy < gh;
+            cid9[q] = in ? yy * gw + xx : 0;
+            cnt9[q] = in ? d.cell_cnt[cid9[q]] : 0;
+        }
+        int m = 0;
+        int* list = d.nb + (size_t)c * DET_NBCAP;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const unsigned long long* ent = d.cell_ent + (size_t)cid9[q] * cap;
+            const int* eci = d.cell_ci + (size_t)cid9[q] * cap;
+            for (int e = 0; e < cnt9[q]; ++e) {
+                const unsigned long long k2 = ent[e];
+                if (!(k2 > key)) continue;
+                const int i2 = (int)(k2 & 0xffffffffull);
+                const float ddx = (float)x - (float)(i2 % W), ddy = (float)y - (float)(i2 / W);
+                if ((double)(ddx * ddx + ddy * ddy) < md2) { if (m < DET_NBCAP) list[m] = eci[e]; ++m; }
+            }
+        }
+        d.nb_cnt[c] = m <= DET_NBCAP ? m : -1;
+    }
 }
 
 #define GREEDY_T 1024
+#define DET_LDS_ST 32768      // candidate states kept in LDS (the rest in global memory)
+#define DET_LDS_TK 4096       // taken keys ranked from LDS
+// Priority rounds over the neighbour lists until every candidate is decided, then rank-by-counting: one workgroup.
 __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
+    __shared__ unsigned char lst[DET_LDS_ST];
+    __shared__ unsigned long long tk[DET_LDS_TK];
     const int W = d.W, tid = threadIdx.x;
     float md; int cell, gw, gh;
     det_geometry(d, &md, &cell, &gw, &gh);
     const double md2 = (double)md * (double)md;
     const int n = d.counters[0];
-    volatile unsigned char* st = d.state;
+    volatile unsigned char* ls = lst;
+    volatile unsigned char* gs = d.state;
+#define ST_GET(ci) ((ci) < DET_LDS_ST ? ls[(ci)] : gs[(ci)])
+#define ST_SET(ci, v) do { if ((ci) < DET_LDS_ST) ls[(ci)] = (v); else gs[(ci)] = (v); } while (0)
     const size_t cap = (size_t)cell * cell;
-    int pending;
+    DBG_T(56);
+    for (int c = tid; c < n; c += GREEDY_T) ST_SET(c, 1);
+    __threadfence_block();
+    __syncthreads();
+    int pending, rounds = 0;
     do {
-        pending = 0;
+        pending = 0; ++rounds;
         for (int c = tid; c < n; c += GREEDY_T) {
-            const unsigned long long key = d.cand[c];
-            const int idx = (int)(key & 0xffffffffull);
-            if (st[idx] != 1) continue;
-            const int x = idx % W, y = idx / W, xc = x / cell, yc = y / cell;
-            const int x1 = xc > 0 ? xc - 1 : 0, y1 = yc > 0 ? yc - 1 : 0, x2 = xc + 1 < gw ? xc + 1 : gw - 1, y2 = yc + 1 < gh ? yc + 1 : gh - 1;
+            if (ST_GET(c) != 1) continue;
             bool drop = false, wait = false;
-            for (int yy = y1; yy <= y2; ++yy)
-                for (int xx = x1; xx <= x2; ++xx) {
-                    const int cc = yy * gw + xx, cnt = d.cell_cnt[cc];
-                    const unsigned long long* ent = d.cell_ent + (size_t)cc * cap;
-                    for (int e = 0; e < cnt; ++e) {
-                        const unsigned long long k2 = ent[e];
-                        if (k2 == key) continue;
-                        const int i2 = (int)(k2 & 0xffffffffull);
-                        const float ddx = (float)x - (float)(i2 % W), ddy = (float)y - (float)(i2 / W);
-                        if ((double)(ddx * ddx + ddy * ddy) < md2) {
-                            const unsigned char s2 = st[i2];
-                            if (s2 == 2) drop = true;
-                            else if (s2 == 1 && k2 > key) wait = true;
+            const int m = c < d.n_cap ? d.nb_cnt[c] : -1;
+            if (m >= 0) {
+                const int* list = d.nb + (size_t)c * DET_NBCAP;
+                for (int e = 0; e < m; ++e) { const unsigned char s2 = ST_GET(list[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
+            } else {   // list overflow / beyond n_cap: scan the 3x3 cells of the global buckets
+                const unsigned long long key = d.cand[c];
+                const int idx = (int)(key & 0xffffffffull);
+                const int x = idx % W, y = idx / W, xc = x / cell, yc = y / cell;
+                const int x1 = xc > 0 ? xc - 1 : 0, y1 = yc > 0 ? yc - 1 : 0, x2 = xc + 1 < gw ? xc + 1 : gw - 1, y2 = yc + 1 < gh ? yc + 1 : gh - 1;
+                for (int yy = y1; yy <= y2; ++yy)
+                    for (int xx = x1; xx <= x2; ++xx) {
+                        const int cc = yy * gw + xx, cnt = d.cell_cnt[cc];
+                        const unsigned long long* ent = d.cell_ent + (size_t)cc * cap;
+                        const int* eci = d.cell_ci + (size_t)cc * cap;
+                        for (int e = 0; e < cnt; ++e) {
+                            const unsigned long long k2 = ent[e];
+                            if (!(k2 > key)) continue;
+                            const int i2 = (int)(k2 & 0xffffffffull);
+                            const float ddx = (float)x - (float)(i2 % W), ddy = (float)y - (float)(i2 / W);
+                            if ((double)(ddx * ddx + ddy * ddy) < md2) { const unsigned char s2 = ST_GET(eci[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
                         }
                     }
-                }
-            if (drop) st[idx] = 3;
-            else if (!wait) st[idx] = 2;
+            }
+            if (drop) ST_SET(c, 3);
+            else if (!wait) ST_SET(c, 2);
             else pending = 1;
         }
         __threadfence_block();
         pending = __syncthreads_or(pending);
     } while (pending);
-    // taken candidates -> list; rank by counting; the strongest F in descending order
-    for (int c = tid; c < n; c += GREEDY_T) {
-        const unsigned long long key = d.cand[c];
-        if (st[(int)(key & 0xffffffffull)] == 2) d.acc[atomicAdd(&d.counters[1], 1)] = key;
-    }
+    DBG_T(59);
+#ifdef RVIO_DBG_CLOCKS
+    if (tid == 0) { g_dbg[62] = n; g_dbg[63] = rounds; }
+#endif
+    // taken candidates -> list; rank by counting; the strongest F leave in descending order
+    for (int c = tid; c < n; c += GREEDY_T)
+        if (ST_GET(c) == 2) d.acc[atomicAdd(&d.counters[1], 1)] = d.cand[c];
+#undef ST_GET
+#undef ST_SET
     __threadfence_block();
     __syncthreads();
     const int na = ((volatile int*)d.counters)[1];
+    const bool in_lds = na <= DET_LDS_TK;
+    if (in_lds) for (int a = tid; a < na; a += GREEDY_T) tk[a] = d.acc[a];
+    __syncthreads();
     for (int a = tid; a < na; a += GREEDY_T) {
-        const unsigned long long key = d.acc[a];
+        const unsigned long long key = in_lds ? tk[a] : d.acc[a];
         int r = 0;
-        for (int b = 0; b < na; ++b) r += (d.acc[b] > key) ? 1 : 0;
+        if (in_lds) for (int b = 0; b < na; ++b) r += (tk[b] > key) ? 1 : 0;
+        else for (int b = 0; b < na; ++b) r += (d.acc[b] > key) ? 1 : 0;
         if (r < d.F) {
             const int idx = (int)(key & 0xffffffffull);
             d.raw_xy[2 * r] = (float)(idx % W); d.raw_xy[2 * r + 1] = (float)(idx / W);
         }
     }
+    DBG_T(60);
     if (tid == 0) {
         d.counters[2] = na < d.F ? na : d.F;
         *d.maxkey = (int)0x80000000;                       // consumed by nms_kernel; ready for the next image
@@ -204,15 +340,37 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
 #define SP_WIN 7
 #define SP_WW (2 * SP_WIN + 1)
 #define SP_PW (SP_WW + 2)
-__global__ __launch_bounds__(64) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
+#define SP_MARG 12
+#define SP_RS (SP_PW + 1 + 2 * SP_MARG)
+#define SP_T 256
+// one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
+__global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
     __shared__ float patch[SP_PW * SP_PW];
     __shared__ float smask[SP_WW * SP_WW];
-    const int p = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned char reg[SP_RS * SP_RS];
+    __shared__ double s_part[4][5];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = d.counters[2];
     if (p >= n) return;
     const int W = d.W, H = d.H;
-    for (int e = lane; e < SP_WW * SP_WW; e += 64) smask[e] = d.spmask[e];
+    for (int e = tid; e < SP_WW * SP_WW; e += SP_T) smask[e] = d.spmask[e];
     const float tx = d.raw_xy[2 * p], ty = d.raw_xy[2 * p + 1];
+    // the estimate may wander SP_MARG px from the start before a sample has to come from global memory again:
+    // cache that neighbourhood (coordinates clamped at load time = the replicated border)
+    const int rx0 = (int)tx - (SP_PW - 1) / 2 - SP_MARG, ry0 = (int)ty - (SP_PW - 1) / 2 - SP_MARG;
+    for (int e = tid; e < SP_RS * SP_RS; e += SP_T) {
+        const int j = e / SP_RS, i = e % SP_RS;
+        reg[e] = src[(size_t)min(max(ry0 + j, 0), H - 1) * stride + min(max(rx0 + i, 0), W - 1)];
+    }
+    __syncthreads();
+    auto pix = [&](int x, int y) -> float {
+        const int i = x - rx0, j = y - ry0;
+        if ((unsigned)i < (unsigned)SP_RS && (unsigned)j < (unsigned)SP_RS) return (float)reg[j * SP_RS + i];
+        return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)];
+    };
+    const int wi = tid >> 4, wj = tid & 15;
+    const bool live = wi < SP_WW && wj < SP_WW;
+    const double wm = live ? (double)d.spmask[wi * SP_WW + wj] : 0.0, px = wj - SP_WIN, py = wi - SP_WIN;
     float cx = tx, cy = ty;
     const double eps = 1e-2 * 1e-2;
     int iter = 0;
@@ -226,41 +384,42 @@ __global__ __launch_bounds__(64) void subpix_kernel(const uint8_t* __restrict__ 
             const float b = oy - (float)iy;
             a = fmaxf(a, 0.0001f);
             const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
-            for (int e = lane; e < SP_PW * SP_PW; e += 64) {
+            for (int e = tid; e < SP_PW * SP_PW; e += SP_T) {
                 const int i = e / SP_PW, j = e % SP_PW;
-                const int ya = min(max(iy + i, 0), H - 1), yb = min(max(iy + i + 1, 0), H - 1);
-                const int xa = min(max(ix + j, 0), W - 1), xb = min(max(ix + j + 1, 0), W - 1);
-                const uint8_t* r0 = src + (size_t)ya * stride;
-                const uint8_t* r1 = src + (size_t)yb * stride;
-                patch[e] = (((float)r0[xa] * a11 + (float)r0[xb] * a12) + (float)r1[xa] * a21) + (float)r1[xb] * a22;
+                patch[e] = ((pix(ix + j, iy + i) * a11 + pix(ix + j + 1, iy + i) * a12) + pix(ix + j, iy + i + 1) * a21) + pix(ix + j + 1, iy + i + 1) * a22;
             }
         }
         __syncthreads();
-        // lane <-> window row: the row's five sums, left to right
         double ra = 0, rb = 0, rc = 0, r1s = 0, r2s = 0;
-        if (lane < SP_WW) {
-            const float* sp = &patch[(lane + 1) * SP_PW + 1];
-            const double py = lane - SP_WIN;
-#pragma unroll
-            for (int j = 0; j < SP_WW; ++j) {
-                const double m = smask[lane * SP_WW + j];
-                const double tgx = sp[j + 1] - sp[j - 1];
-                const double tgy = sp[j + SP_PW] - sp[j - SP_PW];
-                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                const double px = j - SP_WIN;
-                ra += gxx; rb += gxy; rc += gyy;
-                r1s += gxx * px + gxy * py;
-                r2s += gxy * px + gyy * py;
-            }
+        if (live) {
+            const float* sp = &patch[(wi + 1) * SP_PW + 1 + wj];
+            const double tgx = sp[1] - sp[-1];
+            const double tgy = sp[SP_PW] - sp[-SP_PW];
+            const double gxx = tgx * tgx * wm, gxy = tgx * tgy * wm, gyy = tgy * tgy * wm;
+            ra = gxx; rb = gxy; rc = gyy;
+            r1s = gxx * px + gxy * py;
+            r2s = gxy * px + gyy * py;
         }
-        // rows top to bottom (uniform result on every lane)
-        double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-#pragma unroll
-        for (int i = 0; i < SP_WW; ++i) {
-            a += readlane_f64(ra, i); b += readlane_f64(rb, i); c += readlane_f64(rc, i);
-            bb1 += readlane_f64(r1s, i); bb2 += readlane_f64(r2s, i);
+        // canonical order (oracle/detector.cpp): per window row a balanced tree over the 16 columns (j, j+8), (.., +4), (.., +2),
+        // (.., +1) = four DPP row rotations; per wave (rows 4w..4w+3) (R0 + R1) + (R2 + R3); then (W0 + W1) + (W2 + W3)
+        ra += dpp_f64<0x128>(ra); rb += dpp_f64<0x128>(rb); rc += dpp_f64<0x128>(rc); r1s += dpp_f64<0x128>(r1s); r2s += dpp_f64<0x128>(r2s);
+        ra += dpp_f64<0x124>(ra); rb += dpp_f64<0x124>(rb); rc += dpp_f64<0x124>(rc); r1s += dpp_f64<0x124>(r1s); r2s += dpp_f64<0x124>(r2s);
+        ra += dpp_f64<0x122>(ra); rb += dpp_f64<0x122>(rb); rc += dpp_f64<0x122>(rc); r1s += dpp_f64<0x122>(r1s); r2s += dpp_f64<0x122>(r2s);
+        ra += dpp_f64<0x121>(ra); rb += dpp_f64<0x121>(rb); rc += dpp_f64<0x121>(rc); r1s += dpp_f64<0x121>(r1s); r2s += dpp_f64<0x121>(r2s);
+        {
+            const double w0 = (readlane_f64(ra, 0) + readlane_f64(ra, 16)) + (readlane_f64(ra, 32) + readlane_f64(ra, 48));
+            const double w1 = (readlane_f64(rb, 0) + readlane_f64(rb, 16)) + (readlane_f64(rb, 32) + readlane_f64(rb, 48));
+            const double w2 = (readlane_f64(rc, 0) + readlane_f64(rc, 16)) + (readlane_f64(rc, 32) + readlane_f64(rc, 48));
+            const double w3 = (readlane_f64(r1s, 0) + readlane_f64(r1s, 16)) + (readlane_f64(r1s, 32) + readlane_f64(r1s, 48));
+            const double w4 = (readlane_f64(r2s, 0) + readlane_f64(r2s, 16)) + (readlane_f64(r2s, 32) + readlane_f64(r2s, 48));
+            if (lane == 0) { s_part[wv][0] = w0; s_part[wv][1] = w1; s_part[wv][2] = w2; s_part[wv][3] = w3; s_part[wv][4] = w4; }
         }
-        __syncthreads();                                     // patch is rewritten by the next iteration
+        __syncthreads();
+        const double a = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
+        const double b = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
+        const double c = (s_part[0][2] + s_part[1][2]) + (s_part[2][2] + s_part[3][2]);
+        const double bb1 = (s_part[0][3] + s_part[1][3]) + (s_part[2][3] + s_part[3][3]);
+        const double bb2 = (s_part[0][4] + s_part[1][4]) + (s_part[2][4] + s_part[3][4]);
         const double det = a * c - b * b;
         if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
         const double scale = 1.0 / det;
@@ -270,7 +429,8 @@ __global__ __launch_bounds__(64) void subpix_kernel(const uint8_t* __restrict__ 
         err = (double)(ex * ex + ey * ey);
         cx = nx; cy = ny;
         if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
+        __syncthreads();                                     // s_part / patch are rewritten by the next iteration
     } while (++iter < 30 && err > eps);
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
-    if (lane == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+    if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }

@@ -565,7 +565,10 @@ static int detector_init(rvio_hip* h) {
     q.max_cells = ((d.W + cell1 - 1) / cell1) * ((d.H + cell1 - 1) / cell1);
     q.first = h->t.first;
     DALLOC(h, q.eig, npx); DALLOC(h, q.maxkey, 1); DALLOC(h, q.counters, 4); DALLOC(h, q.cell_cnt, (size_t)q.max_cells);
-    DALLOC(h, q.cell_ent, (size_t)(d.W + cell2) * (d.H + cell2)); DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
+    DALLOC(h, q.cell_ent, (size_t)(d.W + cell2) * (d.H + cell2)); DALLOC(h, q.cell_ci, (size_t)(d.W + cell2) * (d.H + cell2));
+    q.n_cap = (int)std::min(npx, (size_t)16384);
+    DALLOC(h, q.nb, (size_t)q.n_cap * DET_NBCAP); DALLOC(h, q.nb_cnt, (size_t)q.n_cap);
+    DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
     DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, q.xy, (size_t)2 * d.F);
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)SP_WW * SP_WW);
@@ -581,6 +584,7 @@ static int detector_init(rvio_hip* h) {
     HIPCHK(h, hipMemcpyAsync(q.maxkey, &minkey, sizeof minkey, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     q.spmask = mask;
+    HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, hipEventDisableTiming));
@@ -593,10 +597,11 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride) {
     HIPCHK(h, hipEventRecord(h->evD0, h->ts));
     HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH);
-    hipLaunchKernelGGL(mineig_kernel, g, dim3(256), 0, h->stream_d, img, stride, h->det);
-    hipLaunchKernelGGL(nms_kernel, g, dim3(256), 0, h->stream_d, h->det);
+    hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det);
+    hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det);
+    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det);
     hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GREEDY_T), 0, h->stream_d, h->det);
-    hipLaunchKernelGGL(subpix_kernel, dim3(d.F), dim3(64), 0, h->stream_d, img, stride, h->det);
+    hipLaunchKernelGGL(subpix_kernel, dim3(d.F), dim3(SP_T), 0, h->stream_d, img, stride, h->det);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
     return RVIO_OK;
