@@ -26,189 +26,6 @@ __device__ const double kChi2Dev[500] = {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// =============================================================== P1 propagate
-// One workgroup, 256 threads.
-//  phase A  lane s <-> IMU sample s: everything that depends on the sample alone (trig, dR, f1..f4)
-//  phase B  the short serial chain Rk <- dR Rk, dp, dv, pk, vk, gk (reference order)
-//  phase C  Phi rows 9..17 (the only non-identity rows of Phi = I + dt F, PreIntegrator.cc:123-132)
-//           for all samples at once
-//  phase D  per sample: rows 9..17 of (Phi P), Psi <- Phi Psi, columns 9..17 of (Phi P) Phi^T + Q
-#define PROP_CH 16
-struct PropSample {      // per-sample scratch in LDS
-    double dR[9], up[3], uv[3], w[3], dt, Dt, small;
-    double Rk[9], vk[3], gk[3];   // PRE-step values used by F (PreIntegrator.cc:123-131)
-};
-
-__global__ __launch_bounds__(256) void propagate_kernel(DevCfg cfg, FilterMeta* meta, int n, double* x, double* P,
-                                                        const rvio_imu* imu, int m) {
-    __shared__ double Pl[24][25];
-    __shared__ double Psi[24][25];
-    __shared__ double Phi9[PROP_CH][9][25];
-    __shared__ double vxs[PROP_CH][9];
-    __shared__ PropSample sm[PROP_CH];
-    __shared__ double xs[26];
-    const int tid = threadIdx.x;
-    const int ld = cfg.dmax;
-    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }
-    for (int e = tid; e < 576; e += 256) {
-        int i = e % 24, j = e / 24;
-        Pl[i][j] = P[i + (size_t)j * ld];
-        Psi[i][j] = (i == j) ? 1.0 : 0.0;
-    }
-    if (tid < 26) xs[tid] = x[tid];
-    __syncthreads();
-    const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
-    const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
-    m33 Rk = q2r(ldq(xs + 10)), RkT = tr33(Rk);
-    d3 pk = ld3(xs + 14), vk = vR, gk = gR;
-    d3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
-    const m33 I = eye33();
-    const double nG = cfg.gravity;
-    double Dt = 0;
-    const int r9 = tid / 24, c9 = tid % 24;  // valid for tid < 216
-    DBG_T(0);
-    for (int s0 = 0; s0 < m; s0 += PROP_CH) {
-        const int mc = (m - s0 < PROP_CH) ? (m - s0) : PROP_CH;
-        // ---- phase A
-        DBG_T(1);
-        if (tid < mc) {
-            const rvio_imu u = imu[s0 + tid];
-            const d3 w = sub3(mk3(u.w[0], u.w[1], u.w[2]), bg), a = sub3(mk3(u.a[0], u.a[1], u.a[2]), ba);
-            const double dt = u.dt, w1 = nrm3(w);
-            const bool small = w1 < cfg.small_angle;
-            const double wdt = w1 * dt, wdt2 = wdt * wdt;
-            const double cw = cos(wdt), sw = sin(wdt);
-            const m33 wx = skew33(w), wx2 = mul33(wx, wx);
-            m33 dR; double f1, f2, f3, f4;
-            if (small) {
-                dR = add33(sub33(I, scl33(dt, wx)), scl33(dt * dt / 2, wx2));
-                f1 = -(dt * dt * dt) / 3; f2 = (dt * dt * dt * dt) / 8; f3 = -(dt * dt) / 2; f4 = (dt * dt * dt) / 6;
-            } else {
-                const double w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
-                dR = add33(sub33(I, scl33(sw / w1, wx)), scl33((1 - cw) / w2, wx2));
-                f1 = (wdt * cw - sw) / w3;
-                f2 = .5 * (wdt2 - 2 * cw - 2 * wdt * sw + 2) / w4;
-                f3 = (cw - 1) / w2;
-                f4 = (wdt - sw) / w3;
-            }
-            PropSample& q = sm[tid];
-            for (int k = 0; k < 9; ++k) q.dR[k] = dR.m[k];
-            st3(q.up, mv33(add33(add33(scl33(.5 * dt * dt, I), scl33(f1, wx)), scl33(f2, wx2)), a));
-            st3(q.uv, mv33(add33(add33(scl33(dt, I), scl33(f3, wx)), scl33(f4, wx2)), a));
-            st3(q.w, w); q.dt = dt;
-        }
-        __syncthreads();
-        DBG_T(2);
-        // ---- phase B (every thread runs the same short chain: no broadcast needed)
-        for (int s = 0; s < mc; ++s) {
-            PropSample& q = sm[s];
-            if (tid == 0) { for (int k = 0; k < 9; ++k) q.Rk[k] = Rk.m[k]; st3(q.vk, vk); st3(q.gk, gk); }
-            const double dt = q.dt;
-            Dt += dt;
-            Rk = mul33(ldm33(q.dR), Rk); RkT = tr33(Rk);
-            dp = add3(dp, scl3(dt, dv));
-            dp = add3(dp, mv33(RkT, ld3(q.up)));
-            dv = add3(dv, mv33(RkT, ld3(q.uv)));
-            pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
-            vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
-            gk = unit3(mv33(Rk, gR));
-        }
-        __syncthreads();
-        DBG_T(3);
-        // ---- phase C: Phi9[s][r][c] for all samples of the chunk
-        for (int e = tid; e < mc * 216; e += 256) {
-            const int s = e / 216, rc = e % 216, r = rc / 24, c = rc % 24;
-            const PropSample& q = sm[s];
-            const int br = r / 3, i = r % 3, bc = c / 3, j = c % 3;
-            const double id = (i == j) ? 1.0 : 0.0, dt = q.dt;
-            double v = 0.0;
-            if (br == 0) {            // theta_k rows
-                if (bc == 3) v = id - dt * skew33(ld3(q.w)).m[3 * i + j];
-                else if (bc == 6) v = -dt * id;
-            } else if (br == 1) {     // p_k rows:  -Rk^T [v]x | I | Rk^T
-                if (bc == 3) {
-                    const m33 vx = skew33(ld3(q.vk));
-                    v = -dt * (q.Rk[i] * vx.m[j] + q.Rk[3 + i] * vx.m[3 + j] + q.Rk[6 + i] * vx.m[6 + j]);
-                } else if (bc == 4) v = id;
-                else if (bc == 5) v = dt * q.Rk[3 * j + i];
-            } else {                  // v rows
-                if (bc == 2) v = -dt * nG * q.Rk[3 * i + j];
-                else if (bc == 3) v = -dt * nG * skew33(ld3(q.gk)).m[3 * i + j];
-                else if (bc == 5) v = id - dt * skew33(ld3(q.w)).m[3 * i + j];
-                else if (bc == 6) v = -dt * skew33(ld3(q.vk)).m[3 * i + j];
-                else if (bc == 7) v = -dt * id;
-            }
-            Phi9[s][r][c] = v;
-            if (rc < 9) vxs[s][rc] = skew33(ld3(q.vk)).m[rc];
-        }
-        __syncthreads();
-        DBG_T(4);
-        // ---- phase D
-        for (int s = 0; s < mc; ++s) {
-            const double dt = sm[s].dt;
-            double accP = 0, accS = 0;
-            if (tid < 216) {
-#pragma unroll 8
-                for (int k = 0; k < 24; ++k) { const double f = Phi9[s][r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
-            }
-            __syncthreads();
-            if (tid < 216) { Pl[9 + r9][c9] = accP; Psi[9 + r9][c9] = accS; }
-            __syncthreads();
-            double accC = 0;
-            if (tid < 216) {
-#pragma unroll 8
-                for (int k = 0; k < 24; ++k) accC += Pl[c9][k] * Phi9[s][r9][k];
-                // Q = dt G Sigma G^T (PreIntegrator.cc:135-140), non-zero blocks only
-                const int i = c9, j = 9 + r9;
-                const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
-                const double* vx = vxs[s];
-                if (bi == 3 && bj == 3) accC += (ii == jj) ? dt * cfg.sg2 : 0.0;
-                else if (bi == 3 && bj == 5) accC += dt * cfg.sg2 * vx[3 * jj + ii];
-                else if (bi == 5 && bj == 3) accC += dt * cfg.sg2 * vx[3 * ii + jj];
-                else if (bi == 5 && bj == 5) {
-                    double q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] +
-                               ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
-                    if (ii == jj) q += dt * cfg.sa2;
-                    accC += q;
-                }
-            }
-            __syncthreads();
-            if (tid < 216) Pl[c9][9 + r9] = accC;
-            if (tid >= 216 && tid < 219) Pl[18 + tid - 216][18 + tid - 216] += dt * cfg.swg2;
-            if (tid >= 219 && tid < 222) Pl[21 + tid - 219][21 + tid - 219] += dt * cfg.swa2;
-            __syncthreads();
-        }
-    }
-    DBG_T(5);
-    if (tid == 0) {
-        stq(x + 10, r2q(Rk));
-        st3(x + 14, pk);
-        st3(x + 17, vk);
-    }
-    DBG_T(6);
-    // P11 back (symmetrised, PreIntegrator.cc:192); P22 is untouched and already symmetric
-    for (int e = tid; e < 576; e += 256) {
-        int i = e % 24, j = e / 24;
-        P[i + (size_t)j * ld] = .5 * (Pl[i][j] + Pl[j][i]);
-    }
-    DBG_T(7);
-    // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191): one thread per clone column
-    for (int c = tid; c < 6 * n; c += 256) {
-        double col[24];
-        double* pc = P + (size_t)(24 + c) * ld;
-#pragma unroll
-        for (int k = 0; k < 24; ++k) col[k] = pc[k];
-        for (int i = 0; i < 24; ++i) {
-            double acc = 0;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) acc += Psi[i][k] * col[k];
-            pc[i] = acc;
-            P[(24 + c) + (size_t)i * ld] = acc;
-        }
-    }
-    DBG_T(8);
-}
-
 // =============================================================== U1..U5 per feature
 // One workgroup per feature slot.  Dynamic LDS (doubles):
 //   xcl[7*nmax] pose[(L-1)*24] hrr[L*6] hf[2L*3] lr[(L-1)*18] vh[3*2L] misc[16]
@@ -620,33 +437,9 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
     DBG_T(40);
 }
 
-// =============================================================== U7 compression, information form
-// partial[g][p][q] = sum over the rows of feature group g of H[row][p] * H[row][q],
-// q = 0..c6 (column c6 is the residual -> b).  grid = (groups, ceil(c6/16)), 256 threads.
-#define GRAM_FG 4
-__global__ __launch_bounds__(256) void gram_kernel(DevCfg cfg, int n, const double* Hstack, const int* nrows, double* partial) {
-    const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max;
-    const int g = blockIdx.x, p0 = blockIdx.y * 16;
-    if (p0 >= c6) return;
-    const int f0 = g * GRAM_FG;
-    const int ncol = c6 + 1;
-    int nr[GRAM_FG];
-#pragma unroll
-    for (int ff = 0; ff < GRAM_FG; ++ff) nr[ff] = (f0 + ff < cfg.Fu) ? nrows[f0 + ff] : 0;
-    double* out = partial + (size_t)g * cfg.ldh * cfg.ldh;
-    for (int e = threadIdx.x; e < 16 * ncol; e += 256) {
-        const int p = p0 + e / ncol, q = e % ncol;
-        if (p >= c6) continue;
-        double acc = 0;
-#pragma unroll
-        for (int ff = 0; ff < GRAM_FG; ++ff) {
-            const double* H = Hstack + (size_t)(f0 + ff) * rhomax * ldh;
-            for (int r = 0; r < nr[ff]; ++r) acc += H[(size_t)r * ldh + p] * H[(size_t)r * ldh + q];
-        }
-        out[(size_t)p * ldh + q] = acc;
-    }
-}
-
+// =============================================================== U7 compression, information form (reduction stage)
+// partial[g][p][q] = sum over the rows of feature group g of H[row][p] * H[row][q], q = 0..c6 (column c6 is the residual -> b),
+// is produced by gram_mfma_kernel (filter_kernels2.hip); the kernels below reduce it.
 // block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
                                                           const int* nrows, double* block) {
@@ -722,123 +515,6 @@ __global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const do
             if (row < c6) Tm[(size_t)row * ldh + col] = acc[r] + ((row == col) ? s2 : 0.0);
         }
     }
-}
-
-// =============================================================== solve: W = T^-1, y = W b, dx, x+
-// One workgroup of 1024 threads.  Tableau M = [T | b | I]  (c6 x NC, NC = 2 c6 + 1) in LDS (or in
-// global scratch when it does not fit).  Gauss-Jordan with partial pivoting, NO row swaps and
-// deferred pivot scaling: step k picks the unused row p with max |M[i][k]|, every other row i does
-// M[i][j] -= (M[i][k]/piv) M[p][j] for the still-active columns.  Every wave re-derives p itself from
-// LDS, so ONE barrier per column suffices.  Solution row k is row p_k of the tableau times 1/piv_k.
-template <bool USE_LDS>
-__device__ __forceinline__ void solve_body(const DevCfg& cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
-                                           const double* x, const double* P, double* Wout, double* x_out, double* Mg, double* sh) {
-    __shared__ int s_prow[6 * RVIO_MAX_LEN];
-    __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
-    __shared__ double s_y[6 * RVIO_MAX_LEN];
-    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
-    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = T >> 6;
-    const int NC = 2 * c6 + 1;
-    const int ldm = USE_LDS ? (NC | 1) : (2 * ldh);
-    double* M = USE_LDS ? sh : Mg;
-    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
-    const bool upd = n_good > 2;                       // Updater.cc:460
-    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
-    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
-        for (int e = tid; e < c6 * c6; e += T) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
-        for (int i = tid; i < xd; i += T) x_out[i] = x[i];
-        return;
-    }
-    for (int e = tid; e < c6 * NC; e += T) {
-        const int r = e / NC, c = e % NC;
-        double v;
-        if (c < c6) v = Tg[(size_t)r * ldh + c];
-        else if (c == c6) v = Ab[(size_t)r * ldh + c6];
-        else v = (c - c6 - 1 == r) ? 1.0 : 0.0;
-        M[(size_t)r * ldm + c] = v;
-    }
-    __syncthreads();
-    unsigned long long used0 = 0, used1 = 0, used2 = 0;   // rows already chosen as pivots (uniform per wave)
-    for (int k = 0; k < c6; ++k) {
-        // pivot search: lane <-> row (rows lane, lane+64, lane+128)
-        double best = -1.0; int bi = 0;
-        for (int i = lane, q = 0; i < c6; i += 64, ++q) {
-            const unsigned long long um = (q == 0) ? used0 : (q == 1 ? used1 : used2);
-            if (!((um >> lane) & 1ull)) { const double v = fabs(M[(size_t)i * ldm + k]); if (v > best) { best = v; bi = i; } }
-        }
-        // wave arg-max: 4 DPP row-rotate steps (16-lane rows), then the 4 row winners through readlane
-#define ARGMAX_STEP(CTRL)                                                                             \
-        {                                                                                             \
-            const double ov = dpp_f64<CTRL>(best);                                                    \
-            const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, 0xf, 0xf, false);                \
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }                         \
-        }
-        ARGMAX_STEP(0x128) ARGMAX_STEP(0x124) ARGMAX_STEP(0x122) ARGMAX_STEP(0x121)
-#undef ARGMAX_STEP
-        {
-            double b0 = readlane_f64(best, 0); int i0 = __builtin_amdgcn_readlane(bi, 0);
-#pragma unroll
-            for (int rw = 16; rw < 64; rw += 16) {
-                const double ov = readlane_f64(best, rw); const int oi = __builtin_amdgcn_readlane(bi, rw);
-                if (ov > b0 || (ov == b0 && oi < i0)) { b0 = ov; i0 = oi; }
-            }
-            best = b0; bi = i0;
-        }
-        const int pr = bi;
-        if (pr < 64) used0 |= 1ull << pr; else if (pr < 128) used1 |= 1ull << (pr - 64); else used2 |= 1ull << (pr - 128);
-        const double piv = M[(size_t)pr * ldm + k];
-        const double ipiv = 1.0 / piv;
-        if (tid == 0) { s_prow[k] = pr; s_ipiv[k] = ipiv; if (!(best > 0)) meta->err |= 1; }
-        // eliminate: wave w owns rows w, w+NW, ...; lanes own the active columns j > k
-        const int j0 = k + 1 + lane;
-        double prv[6];
-#pragma unroll
-        for (int u = 0; u < 6; ++u) { const int j = j0 + 64 * u; prv[u] = (j < NC) ? M[(size_t)pr * ldm + j] : 0.0; }
-        for (int i = wv; i < c6; i += NW) {
-            if (i == pr) continue;
-            const double f = M[(size_t)i * ldm + k] * ipiv;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) { const int j = j0 + 64 * u; if (j < NC) M[(size_t)i * ldm + j] -= f * prv[u]; }
-        }
-        __syncthreads();
-    }
-    // unscramble: solution row k = tableau row prow[k] * ipiv[k]
-    for (int e = tid; e < c6 * c6; e += T) {
-        const int k = e / c6, j = e % c6;
-        Wout[(size_t)k * ldh + j] = M[(size_t)s_prow[k] * ldm + c6 + 1 + j] * s_ipiv[k];
-    }
-    for (int k = tid; k < c6; k += T) s_y[k] = M[(size_t)s_prow[k] * ldm + c6] * s_ipiv[k];
-    __syncthreads();
-    // dx = K r = Pc y   (Updater.cc:544)
-    for (int i = tid; i < d; i += T) {
-        double acc = 0;
-        for (int k = 0; k < c6; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
-        s_dx[i] = acc;
-    }
-    __syncthreads();
-    // state injection (Updater.cc:546-613)
-    const double* dx = s_dx;
-    if (tid == 0) {
-        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
-        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
-        st3(x_out + 7, unit3(ld3(x_out + 7)));
-        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
-        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
-    }
-    for (int p = tid - 64; p >= 0 && p < n; p += T - 64) {
-        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
-        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
-    }
-}
-__global__ __launch_bounds__(1024) void solve_kernel_lds(DevCfg cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
-                                                         const double* x, const double* P, double* Wout, double* x_out) {
-    extern __shared__ __align__(16) double sh[];
-    solve_body<true>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, nullptr, sh);
-}
-__global__ __launch_bounds__(1024) void solve_kernel_glb(DevCfg cfg, FilterMeta* meta, int n, const double* Tg, const double* Ab,
-                                                         const double* x, const double* P, double* Wout, double* x_out, double* Mg) {
-    solve_body<false>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, Mg, nullptr);
 }
 
 // =============================================================== U = Pc W, G = U A, P1 = P - G Pc^T
@@ -984,102 +660,6 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
         if (row < d && col < d) {
             Pout[(size_t)row + (size_t)col * ld] = v;
             if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
-        }
-    }
-}
-
-// =============================================================== S1 + S2 fused: augmentation/slide + composition
-// System.cc:279-365.  J P J^T with J = [I; rows 9..14] is a gather (out[a][b] = P[src(a)][src(b)]); composition
-// multiplies the first 24 rows/columns by Vk.  Out-of-place (reads cur, writes cur^1).
-// block 0: the 24x24 corner Vk P11 Vk^T (symmetrised) + the state vector; other blocks: one clone column per thread.
-__device__ __forceinline__ int aug_src(int a, int n, int nmax, int do_aug) {
-    if (a < 24 || !do_aug) return a;
-    const int cb = (a - 24) / 6, off = (a - 24) % 6;
-    if (n < nmax) return (cb < n) ? a : 9 + off;
-    return (cb < nmax - 1) ? a + 6 : 9 + off;
-}
-__global__ __launch_bounds__(256) void augcomp_kernel(DevCfg cfg, int n, int do_aug, const double* x, const double* P,
-                                                      double* x_out, double* P_out, double* pose_out) {
-    __shared__ double Vk[24][25];
-    __shared__ double P11[24][25];
-    __shared__ double Tm[24][25];
-    __shared__ double xs[26];
-    const int nmax = cfg.nmax, ld = cfg.dmax;
-    const int n2 = do_aug ? ((n < nmax) ? n + 1 : nmax) : n;
-    const int d2 = 24 + 6 * n2, xd2 = 26 + 7 * n2;
-    const int tid = threadIdx.x;
-    DBG_T(20);
-    if (tid < 26) xs[tid] = x[tid];
-    if (blockIdx.x == 0) for (int e = tid; e < 576; e += 256) P11[e % 24][e / 24] = P[(size_t)(e % 24) + (size_t)(e / 24) * ld];
-    for (int e = tid; e < 576; e += 256) Vk[e / 24][e % 24] = 0.0;
-    __syncthreads();
-    DBG_T(21);
-    const q4 qG = ldq(xs), qk = ldq(xs + 10);
-    const d3 pG = ld3(xs + 4), pk = ld3(xs + 14);
-    const m33 RG = q2r(qG), Rk = q2r(qk);
-    const d3 gk = unit3(mv33(Rk, ld3(xs + 7)));
-    const q4 qkG = qmul(qk, qG);
-    const d3 pkG = mv33(Rk, sub3(pG, pk));
-    if (tid < 9) {
-        const int i = tid / 3, j = tid % 3;
-        const m33 spx = skew33(pkG), sgx = skew33(gk);
-        Vk[i][j] = Rk.m[3 * i + j];           Vk[i][9 + j] = (i == j) ? 1.0 : 0.0;
-        Vk[3 + i][3 + j] = Rk.m[3 * i + j];   Vk[3 + i][9 + j] = spx.m[3 * i + j];   Vk[3 + i][12 + j] = -Rk.m[3 * i + j];
-        Vk[6 + i][6 + j] = Rk.m[3 * i + j];   Vk[6 + i][9 + j] = sgx.m[3 * i + j];
-        Vk[15 + tid][15 + tid] = 1.0;
-    }
-    __syncthreads();
-    DBG_T(22);
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Vk[i][k] * P11[k][j]; Tm[i][j] = a; }
-        __syncthreads();
-        DBG_T(23);
-        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; double a = 0; for (int k = 0; k < 24; ++k) a += Tm[i][k] * Vk[j][k]; P11[i][j] = a; }
-        __syncthreads();
-        DBG_T(24);
-        for (int e = tid; e < 576; e += 256) { int i = e / 24, j = e % 24; P_out[(size_t)i + (size_t)j * ld] = .5 * (P11[i][j] + P11[j][i]); }
-        // state: augmentation (System.cc:282-287,303-306) then composition (System.cc:360-365)
-        for (int i = tid; i < xd2; i += 256) {
-            double v;
-            if (i < 4) v = (&qkG.x)[i];
-            else if (i < 7) v = (&pkG.x)[i - 4];
-            else if (i < 10) v = (&gk.x)[i - 7];
-            else if (i < 13) v = 0.0;
-            else if (i == 13) v = 1.0;
-            else if (i < 17) v = 0.0;
-            else if (i < 26) v = xs[i];
-            else {
-                int src = i;
-                if (do_aug) {
-                    const int cb = (i - 26) / 7, off = (i - 26) % 7;
-                    if (n < nmax) src = (cb < n) ? i : 10 + off;
-                    else src = (cb < nmax - 1) ? i + 7 : 10 + off;
-                }
-                v = (src < 26) ? xs[src] : x[src];
-            }
-            x_out[i] = v;
-        }
-        if (tid == 0) {   // pose line (System.cc:371-374)
-            const d3 pGk = mv33(tr33(RG), sub3(pk, pG));
-            st3(pose_out, pGk); stq(pose_out + 3, qkG);
-        }
-        DBG_T(25);
-    } else {
-        const int c6 = 6 * n2;
-        for (int c = (blockIdx.x - 1) * 256 + tid; c < c6; c += (gridDim.x - 1) * 256) {
-            const int sc = aug_src(24 + c, n, nmax, do_aug);
-            double col[24];
-            const double* pc = P + (size_t)sc * ld;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) col[k] = pc[k];
-            for (int i = 0; i < 24; ++i) {
-                double a = 0;
-#pragma unroll
-                for (int k = 0; k < 24; ++k) a += Vk[i][k] * col[k];
-                P_out[(size_t)i + (size_t)(24 + c) * ld] = a;
-                P_out[(size_t)(24 + c) + (size_t)i * ld] = a;
-            }
-            for (int r = 24; r < d2; ++r) P_out[(size_t)r + (size_t)(24 + c) * ld] = pc[aug_src(r, n, nmax, do_aug)];
         }
     }
 }

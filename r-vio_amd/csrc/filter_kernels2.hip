@@ -1,5 +1,5 @@
-// filter_kernels2.hip — second-generation single-workgroup kernels of the filter path
-// (replace propagate_kernel / solve_kernel_* / augcomp_kernel of filter_kernels.hip).
+// filter_kernels2.hip — single-workgroup kernels of the filter path (propagate, augmentation + composition) and the
+// MFMA Gram kernel of the compression.
 // Rules applied (profiles/r01_*): no dynamic indexing of register arrays (it lands in scratch),
 // __restrict__ on every pointer, sparsity of Phi / Vk exploited (the LDS port of ONE CU is the
 // limiter), no loops over dependent global loads.
@@ -187,155 +187,6 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
             P[(24 + c) + (size_t)(9 + r) * ld] = acc;
         }
     }
-}
-
-// =============================================================== solve (v3): W = T^-1, y = W b, dx, x+
-// One workgroup of 256 threads (4 waves = one per SIMD).  IN-PLACE Gauss-Jordan inversion of T with partial
-// pivoting on the tableau M = [T | b]  (c6 x (c6+1), LDS or global scratch):
-//   * no row swaps: step k uses the not-yet-used row p_k with the largest |M[i][k]| as pivot row;
-//   * deferred pivot scaling: a pivot row is kept unscaled (its factor 1/piv_k is applied when reading the result);
-//   * for every other row i:  f = M[i][k]/piv;  M[i][j] -= f M[p][j] (j != k);  M[i][k] = -f;   M[p][k] := 1;
-//   * lane <-> column, wave <-> a quarter of the rows; the arg-max for column k+1 is folded into the elimination
-//     of step k (each wave reduces over its own rows, 4 partial results meet in LDS), so there is ONE barrier
-//     per column and no separate search pass.
-// Result: T^-1[k][p_j] = M[p_k][j] / piv_k,   y[k] = M[p_k][c6] / piv_k.
-#define SOLVE3_T 512
-#define SOLVE3_NW (SOLVE3_T / 64)
-template <bool USE_LDS>
-__device__ __forceinline__ void solve3_body(const DevCfg& cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
-                                            const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
-                                            double* __restrict__ Wout, double* __restrict__ x_out, double* __restrict__ Mg, double* sh) {
-    __shared__ int s_prow[6 * RVIO_MAX_LEN], s_invp[6 * RVIO_MAX_LEN];
-    __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
-    __shared__ double s_y[6 * RVIO_MAX_LEN];
-    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
-    __shared__ double s_cv[2][SOLVE3_NW];    // per-wave candidate |value| for the next pivot (double-buffered by step parity)
-    __shared__ int s_ci[2][SOLVE3_NW];
-    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int NC = c6 + 1;
-    const int ldm = USE_LDS ? (NC | 1) : (2 * ldh);
-    double* M = USE_LDS ? sh : Mg;
-    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
-    const bool upd = n_good > 2;                       // Updater.cc:460
-    DBG_T(40);
-    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
-    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
-        for (int e = tid; e < c6 * c6; e += SOLVE3_T) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
-        for (int i = tid; i < xd; i += SOLVE3_T) x_out[i] = x[i];
-        return;
-    }
-    // rows of the tableau are dealt round-robin to the waves: row i belongs to wave i % SOLVE3_NW
-    for (int i = wv; i < c6; i += SOLVE3_NW)
-        for (int j = lane; j < NC; j += 64) M[(size_t)i * ldm + j] = (j < c6) ? Tg[(size_t)i * ldh + j] : Ab[(size_t)i * ldh + c6];
-    const int nrw = (c6 > wv) ? (c6 - wv + SOLVE3_NW - 1) / SOLVE3_NW : 0;   // rows owned by this wave: i = wv + NW*q, q < nrw
-    unsigned long long usedmask = 0;                                        // bit q: row wv + NW*q was a pivot row already
-    __syncthreads();
-    // first pivot: arg-max of column 0 over this wave's rows
-    {
-        double best = -1.0; int bi = 0;
-        for (int i = wv; i < c6; i += SOLVE3_NW) { const double v = fabs(M[(size_t)i * ldm]); if (v > best) { best = v; bi = i; } }
-        if (lane == 0) { s_cv[0][wv] = best; s_ci[0][wv] = bi; }
-    }
-    __syncthreads();
-    int ppr = -1;   // pivot row of the previous step: its column entry becomes 1 (stored form of 1/piv) only now,
-                    // after the barrier, when no wave can still be reading the old pivot value
-    DBG_T(41);
-    for (int k = 0; k < c6; ++k) {
-        const int par = k & 1;
-        if (k == 1) DBG_T(42);
-        if (k == 2) DBG_T(43);
-        if (k == 32) DBG_T(44);
-        if (ppr >= 0 && (ppr % SOLVE3_NW) == wv && lane == ((k - 1) & 63)) M[(size_t)ppr * ldm + (k - 1)] = 1.0;
-        // combine the per-wave candidates (ties -> smallest row index, like a serial top-down scan)
-        double best = s_cv[par][0]; int pr = s_ci[par][0];
-#pragma unroll
-        for (int w = 1; w < SOLVE3_NW; ++w) { const double v = s_cv[par][w]; const int ii = s_ci[par][w]; if (v > best || (v == best && ii < pr)) { best = v; pr = ii; } }
-        ppr = pr;
-        const double piv = M[(size_t)pr * ldm + k];
-        const double ipiv = 1.0 / piv;
-        if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if (!(best > 0)) meta->err |= 1; }
-        // pivot-row values for this lane's columns
-        double prv[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; prv[u] = (j < NC) ? M[(size_t)pr * ldm + j] : 0.0; }
-        // eliminate this wave's rows, 8 rows in flight (all LDS loads of a batch are issued before the first use);
-        // the arg-max of column k+1 among not-yet-used rows is tracked on the fly by the lane that owns that column
-        if ((pr % SOLVE3_NW) == wv) usedmask |= 1ull << (pr / SOLVE3_NW);
-        double nbest = -1.0; int nbi = 0;
-        for (int q0 = 0; q0 < nrw; q0 += 8) {
-            double fb[8], mv[8][3];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int q = q0 + b, i = wv + SOLVE3_NW * q;
-                const bool ok = q < nrw;
-                fb[b] = ok ? M[(size_t)i * ldm + k] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; mv[b][u] = (ok && j < NC) ? M[(size_t)i * ldm + j] : 0.0; }
-            }
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int q = q0 + b, i = wv + SOLVE3_NW * q;
-                const bool live = (q < nrw) && (i != pr);
-                const double f = fb[b] * ipiv;
-                const bool unused = !((usedmask >> q) & 1ull);
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int j = lane + 64 * u;
-                    const double nv = (j == k) ? -f : (mv[b][u] - f * prv[u]);
-                    if (live && j < NC) M[(size_t)i * ldm + j] = nv;
-                    const double av = fabs(nv);
-                    if (live && unused && j == k + 1 && av > nbest) { nbest = av; nbi = i; }
-                }
-            }
-        }
-        // the lane that owns column k+1 publishes this wave's candidate
-        if (k + 1 < c6 && lane == ((k + 1) & 63)) { s_cv[par ^ 1][wv] = nbest; s_ci[par ^ 1][wv] = nbi; }
-        __syncthreads();
-    }
-    DBG_T(45);
-    if ((ppr % SOLVE3_NW) == wv && lane == ((c6 - 1) & 63)) M[(size_t)ppr * ldm + (c6 - 1)] = 1.0;
-    __syncthreads();
-    // read the result out: W[k][p_j] = M[p_k][j] * ipiv_k ;  y[k] = M[p_k][c6] * ipiv_k
-    for (int e = tid; e < c6 * c6; e += SOLVE3_T) {
-        const int k = e / c6, c = e % c6;
-        Wout[(size_t)k * ldh + c] = M[(size_t)s_prow[k] * ldm + s_invp[c]] * s_ipiv[k];
-    }
-    for (int k = tid; k < c6; k += SOLVE3_T) s_y[k] = M[(size_t)s_prow[k] * ldm + c6] * s_ipiv[k];
-    __syncthreads();
-    DBG_T(46);
-    // dx = K r = Pc y   (Updater.cc:544)
-    for (int i = tid; i < d; i += SOLVE3_T) {
-        double acc = 0;
-        for (int k = 0; k < c6; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
-        s_dx[i] = acc;
-    }
-    __syncthreads();
-    // state injection (Updater.cc:546-613)
-    DBG_T(47);
-    const double* dx = s_dx;
-    if (tid == 0) {
-        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
-        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
-        st3(x_out + 7, unit3(ld3(x_out + 7)));
-        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
-        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
-    }
-    for (int p = tid - 64; p >= 0 && p < n; p += SOLVE3_T - 64) {
-        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
-        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
-    }
-}
-__global__ __launch_bounds__(SOLVE3_T) void solve3_kernel_lds(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
-                                                               const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
-                                                               double* __restrict__ Wout, double* __restrict__ x_out) {
-    extern __shared__ __align__(16) double sh[];
-    solve3_body<true>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, nullptr, sh);
-}
-__global__ __launch_bounds__(SOLVE3_T) void solve3_kernel_glb(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
-                                                               const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
-                                                               double* __restrict__ Wout, double* __restrict__ x_out, double* __restrict__ Mg) {
-    solve3_body<false>(cfg, meta, n, Tg, Ab, x, P, Wout, x_out, Mg, nullptr);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition

@@ -4,8 +4,7 @@
 //
 //   pyr_level_kernel  one launch per pyramid level: Scharr derivative of level l (calcSharrDeriv),
 //                     cv::pyrDown l -> l+1, and (level 0) the copy of the frame into the pyramid
-//   klt_kernel        LKTrackerInvoker, all levels, one wave per feature, template and search
-//                     windows staged in LDS (Tracker.cc:244)
+//   (klt_kernel3      LKTrackerInvoker, all levels, one wave per feature — klt3.hip; CLAHE — clahe.hip; detector — detector.hip)
 //   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
 //   bookkeep_kernel   track book-keeping + FindNewer + refill        (Tracker.cc:271-393, FeatureDetector.cc:78-150)
 #include "rvio_dev.h"
@@ -58,149 +57,7 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------ KLT
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-// One wave per feature; lane l owns window pixels p = l + 64 q (q < 4, p < 225).
-//   Ip  16x16 u8   prev-image patch  (window + 1 for the bilinear taps)      staged once per level
-//   dIp 16x16 i32  packed (dx | dy<<16) Scharr patch                         staged once per level
-//   Jr  32x32 u8   next-image search region around the current estimate      restaged only if the window leaves it
-// The template (I, Ix, Iy) lives in registers; 64-bit integer sums make the result order-free.
-#define KLT_JR 32
-__global__ __launch_bounds__(64) void klt_kernel(PyrDev prev, PyrDev next, int levels, const int* n_pts_ptr,
-                                                 const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status) {
-    __shared__ uint8_t Ip[16 * 16];
-    __shared__ int dIp[16 * 16];
-    __shared__ uint8_t Jr[KLT_JR * KLT_JR];
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const float px = pts[2 * f], py = pts[2 * f + 1];
-    if (f >= *n_pts_ptr) return;
-    const float FLT_SCALE = 1.f / (1 << 20);
-    const double eps2 = 0.01 * 0.01;
-    float nx = 0, ny = 0;
-    int st = 1;
-    DBG_T(9);
-    int wx_[4], wy_[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { int p = lane + 64 * q; wx_[q] = p % 15; wy_[q] = p / 15; }
-    for (int level = levels - 1; level >= 0; --level) {
-        const uint8_t* I = prev.img[level]; const int* dI = (const int*)prev.dxy[level]; const uint8_t* J = next.img[level];
-        const int w = prev.w[level], h = prev.h[level];
-        const float sc = (float)(1. / (1 << level));
-        float ppx = px * sc, ppy = py * sc;
-        if (level == levels - 1) { nx = ppx; ny = ppy; } else { nx = nx * 2.f; ny = ny * 2.f; }
-        ppx -= 7.f; ppy -= 7.f;
-        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        if (ipx < -15 || ipx >= w || ipy < -15 || ipy >= h) { if (level == 0) st = 0; continue; }
-        float a = ppx - ipx, b = ppy - ipy;
-        int iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));
-        int iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
-        int iw10 = (int)rintf((1.f - a) * b * (1 << 14));
-        int iw11 = (1 << 14) - iw00 - iw01 - iw10;
-        // ---- stage the 16x16 template source (image: reflect-101, derivative: zero outside) and the J region
-        float npx = nx - 7.f, npy = ny - 7.f;
-        int jx0 = (int)floorf(npx) - 8, jy0 = (int)floorf(npy) - 8;
-        __syncthreads();   // previous level's LDS readers are done
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = lane + 64 * q, X = ipx + (e & 15), Y = ipy + (e >> 4);
-            Ip[e] = I[(size_t)reflect1(Y, h) * w + reflect1(X, w)];
-            dIp[e] = (X < 0 || Y < 0 || X >= w || Y >= h) ? 0 : dI[(size_t)Y * w + X];
-        }
-        // (only when the first window is inside the image: otherwise iteration 0 bails out before reading, and
-        //  a garbage estimate must never reach the reflect loops)
-        if (jx0 + 8 >= -15 && jx0 + 8 < w && jy0 + 8 >= -15 && jy0 + 8 < h) {
-            const int r = lane >> 1, c0 = (lane & 1) * 16;
-            const uint8_t* jrow = J + (size_t)reflect2(jy0 + r, h) * w;
-            unsigned pk[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                unsigned v = 0;
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect2(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
-                pk[g] = v;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ((unsigned*)Jr)[(r * KLT_JR + c0) / 4 + g] = pk[g];
-        }
-        __syncthreads();
-        DBG_T(10 + 3 * level);
-        int Iw[4], Ixw[4], Iyw[4];
-        long long s11 = 0, s12 = 0, s22 = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            Iw[q] = 0; Ixw[q] = 0; Iyw[q] = 0;
-            if (lane + 64 * q < 225) {
-                const int o = wy_[q] * 16 + wx_[q];
-                const int ival = descale(Ip[o] * iw00 + Ip[o + 1] * iw01 + Ip[o + 16] * iw10 + Ip[o + 17] * iw11, 14 - 5);
-                const int d00 = dIp[o], d01 = dIp[o + 1], d10 = dIp[o + 16], d11 = dIp[o + 17];
-                const int ixv = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 + (short)(d11 & 0xffff) * iw11, 14);
-                const int iyv = descale((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 + (d11 >> 16) * iw11, 14);
-                Iw[q] = (short)ival; Ixw[q] = (short)ixv; Iyw[q] = (short)iyv;
-                s11 += (long long)Ixw[q] * Ixw[q]; s12 += (long long)Ixw[q] * Iyw[q]; s22 += (long long)Iyw[q] * Iyw[q];
-            }
-        }
-        s11 = wave_sum_i64(s11); s12 = wave_sum_i64(s12); s22 = wave_sum_i64(s22);
-        const float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * 15 * 15);
-        if (minEig < 1e-3f || D < 1.1920929e-07f) { if (level == 0) st = 0; continue; }
-        D = 1.f / D;
-        float pdx = 0, pdy = 0;
-        DBG_T(11 + 3 * level);
-        for (int j = 0; j < 30; ++j) {
-#ifdef RVIO_DBG_CLOCKS
-            if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[26 + level] = j + 1;
-#endif
-            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
-            if (inx < -15 || inx >= w || iny < -15 || iny >= h) { if (level == 0) st = 0; break; }
-            int ox = inx - jx0, oy = iny - jy0;
-            if (ox < 0 || ox > KLT_JR - 17 || oy < 0 || oy > KLT_JR - 17) {   // window left the staged region: restage around it
-                jx0 = inx - 8; jy0 = iny - 8; ox = 8; oy = 8;
-                __syncthreads();
-                const int r = lane >> 1, c0 = (lane & 1) * 16;
-                const uint8_t* jrow = J + (size_t)reflect2(jy0 + r, h) * w;
-                unsigned pk[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    unsigned v = 0;
-#pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) v |= (unsigned)jrow[reflect2(jx0 + c0 + 4 * g + bb, w)] << (8 * bb);
-                    pk[g] = v;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) ((unsigned*)Jr)[(r * KLT_JR + c0) / 4 + g] = pk[g];
-                __syncthreads();
-            }
-            a = npx - inx; b = npy - iny;
-            iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));
-            iw01 = (int)rintf(a * (1.f - b) * (1 << 14));
-            iw10 = (int)rintf((1.f - a) * b * (1 << 14));
-            iw11 = (1 << 14) - iw00 - iw01 - iw10;
-            long long sb1 = 0, sb2 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (lane + 64 * q < 225) {
-                    const int o = (oy + wy_[q]) * KLT_JR + ox + wx_[q];
-                    const int diff = descale(Jr[o] * iw00 + Jr[o + 1] * iw01 + Jr[o + KLT_JR] * iw10 + Jr[o + KLT_JR + 1] * iw11, 14 - 5) - Iw[q];
-                    sb1 += (long long)diff * Ixw[q]; sb2 += (long long)diff * Iyw[q];
-                }
-            }
-            sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
-            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
-            const float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
-            npx += dx; npy += dy;
-            nx = npx + 7.f; ny = npy + 7.f;
-            if ((double)dx * dx + (double)dy * dy <= eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { nx -= dx * 0.5f; ny -= dy * 0.5f; break; }
-            pdx = dx; pdy = dy;
-        }
-        DBG_T(12 + 3 * level);
-        if (st && level == 0) {
-            const float fx = nx - 7.f, fy = ny - 7.f;
-            const int rx = (int)rintf(fx), ry = (int)rintf(fy);
-            if (rx < -15 || rx >= w || ry < -15 || ry >= h) st = 0;
-        }
-    }
-    if (lane == 0) { out[2 * f] = nx; out[2 * f + 1] = ny; status[f] = (unsigned char)st; }
-}
+// (the KLT kernel itself is klt_kernel3 in klt3.hip)
 
 // ------------------------------------------------------------------ undistort (cv::undistortPoints, 5 fixed iterations)
 __device__ __forceinline__ void undistort_pt(const DevCfg& c, float u, float v, float* ox, float* oy) {
