@@ -252,9 +252,17 @@ __global__ __launch_bounds__(NEIGH_T) void neigh_kernel(DetDev d) {
 #define DET_LDS_ST 32768      // candidate states kept in LDS (the rest in global memory)
 #define DET_LDS_TK 4096       // taken keys ranked from LDS
 // Priority rounds over the neighbour lists until every candidate is decided, then rank-by-counting: one workgroup.
+#define DET_CL_N 2048         // up to this many candidates the neighbour lists are packed into LDS as well
+#define DET_CL_CAP 24576      // ... if they hold at most this many entries in total
+#define GREEDY_LDS (DET_LDS_TK * 8 + DET_LDS_ST + DET_CL_CAP * 2 + (DET_CL_N + 4) * 4)
 __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
-    __shared__ unsigned char lst[DET_LDS_ST];
-    __shared__ unsigned long long tk[DET_LDS_TK];
+    extern __shared__ __align__(16) unsigned char gdyn[];
+    unsigned long long* tk = (unsigned long long*)gdyn;                         // [DET_LDS_TK]
+    unsigned char* lst = gdyn + DET_LDS_TK * 8;                                 // [DET_LDS_ST]
+    unsigned short* clist = (unsigned short*)(lst + DET_LDS_ST);                // [DET_CL_CAP]
+    int* coff = (int*)(clist + DET_CL_CAP);                                     // [DET_CL_N + 1]
+    __shared__ int s_w[16];
+    __shared__ int s_flag;
     const int W = d.W, tid = threadIdx.x;
     float md; int cell, gw, gh;
     det_geometry(d, &md, &cell, &gw, &gh);
@@ -267,6 +275,30 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
     const size_t cap = (size_t)cell * cell;
     DBG_T(56);
     for (int c = tid; c < n; c += GREEDY_T) ST_SET(c, 1);
+    // usual case: pack the (short) neighbour lists into LDS so that the rounds never leave the CU
+    bool packed = n <= DET_CL_N && n <= d.n_cap;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    if (packed) {
+        const int c0 = 2 * tid, c1 = 2 * tid + 1, lane = tid & 63, wv = tid >> 6;
+        const int m0 = c0 < n ? d.nb_cnt[c0] : 0, m1 = c1 < n ? d.nb_cnt[c1] : 0;
+        if (m0 < 0 || m1 < 0) s_flag = 1;                                       // an overflowed list: general path
+        const int sum = (m0 > 0 ? m0 : 0) + (m1 > 0 ? m1 : 0);
+        const int inc = wave_incl_scan(sum);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int w = 0; w < wv; ++w) base += s_w[w];
+        if (tid == GREEDY_T - 1 && base + sum > DET_CL_CAP) s_flag = 1;
+        __syncthreads();
+        packed = (s_flag == 0);
+        if (packed) {
+            if (c0 < n) { coff[c0] = base; const int* l = d.nb + (size_t)c0 * DET_NBCAP; for (int e = 0; e < m0; ++e) clist[base + e] = (unsigned short)l[e]; }
+            if (c1 < n) { coff[c1] = base + m0; const int* l = d.nb + (size_t)c1 * DET_NBCAP; for (int e = 0; e < m1; ++e) clist[base + m0 + e] = (unsigned short)l[e]; }
+            if (c0 == n - 1) coff[n] = base + m0;
+            if (c1 == n - 1) coff[n] = base + m0 + m1;
+        }
+    }
     __threadfence_block();
     __syncthreads();
     int pending, rounds = 0;
@@ -275,8 +307,11 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
         for (int c = tid; c < n; c += GREEDY_T) {
             if (ST_GET(c) != 1) continue;
             bool drop = false, wait = false;
-            const int m = c < d.n_cap ? d.nb_cnt[c] : -1;
-            if (m >= 0) {
+            const int m = packed ? -2 : (c < d.n_cap ? d.nb_cnt[c] : -1);
+            if (m == -2) {
+                const int o = coff[c], o1 = coff[c + 1];
+                for (int e = o; e < o1; ++e) { const unsigned char s2 = ls[clist[e]]; drop |= (s2 == 2); wait |= (s2 == 1); }
+            } else if (m >= 0) {
                 const int* list = d.nb + (size_t)c * DET_NBCAP;
                 for (int e = 0; e < m; ++e) { const unsigned char s2 = ST_GET(list[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
             } else {   // list overflow / beyond n_cap: scan the 3x3 cells of the global buckets

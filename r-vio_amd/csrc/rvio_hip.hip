@@ -585,6 +585,7 @@ static int detector_init(rvio_hip* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     q.spmask = mask;
     HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
+    HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, hipEventDisableTiming));
@@ -600,7 +601,7 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride) {
     hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det);
     hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det);
-    hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GREEDY_T), 0, h->stream_d, h->det);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det);
     hipLaunchKernelGGL(subpix_kernel, dim3(d.F), dim3(SP_T), 0, h->stream_d, img, stride, h->det);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
