@@ -143,8 +143,10 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         double lambda = 0.01, lastCost = INFINITY;
         if (valid) {
             for (int it = 0; it < 10; ++it) {
-                double sph, cph, sps, cps;
-                sincos(phi, &sph, &cph); sincos(psi, &sps, &cps);
+                // one sincos for both angles: even lanes take phi, odd lanes psi (every lane would compute the same pair anyway)
+                double sv, cv;
+                sincos((lane & 1) ? psi : phi, &sv, &cv);
+                const double sph = readlane_f64(sv, 0), cph = readlane_f64(cv, 0), sps = readlane_f64(sv, 1), cps = readlane_f64(cv, 1);
                 const d3 ep = mk3(cph * sps, sph, cph * cps);
                 const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
                 double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0, cost = 0;
@@ -178,10 +180,17 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                     g1 = (H0[1] * ri) * e0 + (H1[1] * ri) * e1;
                     g2 = (H0[2] * ri) * e0 + (H1[2] * ri) * e1;
                 }
-                cost = wave_sum(cost);
-                c00 = wave_sum(c00); c01 = wave_sum(c01); c02 = wave_sum(c02);
-                c11 = wave_sum(c11); c12 = wave_sum(c12); c22 = wave_sum(c22);
-                g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2);
+                if (L <= 16) {   // all observations sit in the first 16-lane row: same sums, no cross-row combine
+                    cost = row16_sum(cost);
+                    c00 = row16_sum(c00); c01 = row16_sum(c01); c02 = row16_sum(c02);
+                    c11 = row16_sum(c11); c12 = row16_sum(c12); c22 = row16_sum(c22);
+                    g0 = row16_sum(g0); g1 = row16_sum(g1); g2 = row16_sum(g2);
+                } else {
+                    cost = wave_sum(cost);
+                    c00 = wave_sum(c00); c01 = wave_sum(c01); c02 = wave_sum(c02);
+                    c11 = wave_sum(c11); c12 = wave_sum(c12); c22 = wave_sum(c22);
+                    g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2);
+                }
                 if (cost <= lastCost) {
                     // damped normal equations, SPD 3x3: Cholesky solve (reference: colPivHouseholderQr, Updater.cc:239)
                     // L D L^T (square-root free): 3 reciprocals instead of 3 sqrt + 9 divisions
@@ -406,24 +415,34 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
     DBG_T(38);
     // gamma = |r^T S^-1 r| by a square-root-free L D L^T of S with the residual row appended (reference:
     // colPivHouseholderQr().solve, Updater.cc:420).  Columns stay unscaled (S[i][k] = l_ik d_k), so the residual row
-    // carries w = L^-1 r and gamma = sum_k w_k^2 / d_k.  Wave 0 only, lane <-> row: no block barriers.
+    // carries w = L^-1 r and gamma = sum_k w_k^2 / d_k.  Thread <-> element (i, j) of the lower triangle (+ residual row):
+    // one rank-1 update step per barrier, every element touched once per step.
     double gam = 0;
-    if (wave0) {
+    {
         double gsum = 0;
-        const int i = lane;
+        const int tot = (rr + 1) * rr;
+        int ei[4], ej[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * T;
+            const int i = e / rr, j = e - i * rr;
+            const bool low = e < tot && j <= (i < rr ? i : rr - 1);
+            ei[q] = low ? i : -1; ej[q] = j;
+        }
         for (int k = 0; k < rr; ++k) {
             const double dk = S[k * lds_s + k];
             const double rd = 1.0 / (dk > 0 ? dk : 1e-300);
-            double fik = 0;
-            if (i > k && i <= rr) fik = S[i * lds_s + k] * rd;
-            if (i == rr) gsum += S[rr * lds_s + k] * fik;
-            const int jmax = (i < rr) ? i : rr - 1;
-            if (i > k && i <= rr)
-                for (int j = k + 1; j <= jmax; ++j) S[i * lds_s + j] -= fik * S[j * lds_s + k];
-            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) { const double w = S[rr * lds_s + k]; gsum += w * (w * rd); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ei[q] > k && ej[q] > k) S[ei[q] * lds_s + ej[q]] -= (S[ei[q] * lds_s + k] * rd) * S[ej[q] * lds_s + k];
+            for (int e = tid + 4 * T; e < tot; e += T) {     // long tracks on narrow workgroups
+                const int i = e / rr, j = e - i * rr;
+                if (i > k && j > k && j <= (i < rr ? i : rr - 1)) S[i * lds_s + j] -= (S[i * lds_s + k] * rd) * S[j * lds_s + k];
+            }
+            __syncthreads();
         }
-        gam = fabs(__shfl(gsum, rr, 64));
-        if (lane == 0) misc[8] = gam;
+        if (tid == 0) misc[8] = fabs(gsum);
     }
     DBG_T(39);
     __syncthreads();

@@ -165,6 +165,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_f64<0x121>(v);   // row_ror:1
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
+// sum over lanes 0..15 (the first DPP row); identical to wave_sum when lanes >= 16 hold zeros
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0x128>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x121>(v);
+    return readlane_f64(v, 0);
+}
 template <int CTRL>
 __device__ __forceinline__ long long dpp_i64(long long v) {
     int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);

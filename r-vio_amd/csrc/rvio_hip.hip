@@ -241,7 +241,8 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
         }
     }
     // launch geometry
-    h->feat_threads = (d.ldh <= 64) ? 64 : (d.ldh <= 128 ? 128 : 256);
+    h->feat_threads = (d.ldh <= 128) ? 128 : 256;
+    if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     if (h->feat_lds > 150 * 1024) {
         h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, false) * sizeof(double);

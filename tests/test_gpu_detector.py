@@ -46,6 +46,27 @@ def test_detector_bit_exact(gpu_required, name, eq):
     h.close()
 
 
+def test_detector_bit_exact_1080p(gpu_required):
+    """cfg D (1920x1080, 800 features): more grid cells and candidates than the in-LDS fast path takes -> the general
+    (global-memory) neighbour / selection path, s = 1 and s = 2"""
+    from rvio_amd import hip
+    cfg = abi.config_named("D", enable_equalizer=1)
+    seq = rv.synth.SynthSequence(cfg, duration=3.0)
+    h = hip.RvioHip(cfg)
+    imu = np.zeros(2, abi.IMU_DTYPE)
+    imu["dt"] = 0.005
+    for s, k in ((1, 50), (2, 51)):
+        im = seq.render(k)
+        h.track(im, imu, None)
+        seen = O.clahe(im)
+        xy, raw, eig = h.get_corners(want_eig=True)
+        assert np.array_equal(eig, O.min_eig(seen)), s
+        want_raw = O.gftt(seen, cfg.n_features, float(f32(cfg.qual_lvl)), float(f32(s) * f32(cfg.min_dist)))
+        assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw), (s, len(raw), len(want_raw))
+        assert np.array_equal(xy, O.detect(cfg, seen, s)), s
+    h.close()
+
+
 def test_tracker_sequence_with_device_detector_bit_exact(gpu_required):
     from rvio_amd import hip
     cfg = abi.config_named("B", enable_equalizer=1)
