@@ -147,6 +147,7 @@ def main():
         ev0.record()
     for i in range(1 + W, n_frames):
         frame(i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K frames (launch-rate bound if close to the total)
     with torch.cuda.stream(stream):
         ev1.record()
     h.sync()
@@ -173,7 +174,7 @@ def main():
                                % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off",
                                   "a caller-side list" if args.host_corners else "the device detector (GFTT + cornerSubPix)"),
                    "parallelism": "1 process/GPU; feature-sharded updater + 1 all-gather/frame" if world > 1 else "single GPU"},
-        "gpu_ms_per_step_events": gpu_ms / K,
+        "gpu_ms_per_step_events": gpu_ms / K, "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
     }
 

@@ -2,6 +2,7 @@
 // Single translation unit: the two kernel files are included so that one hipcc call
 // builds the whole library (frontend_kernels.hip switches FP contraction off for itself).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,7 @@ struct rvio_hip {
     hipStream_t stream = nullptr;     // filter stream (and the stream of every non-pipelined call)
     hipStream_t stream_t = nullptr;   // tracker stream of the pipelined whole-frame path
     hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
-    hipEvent_t evT[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};
+    hipEvent_t evT[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
     long frame_no = 0;
     bool piped = false;
     struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[2];
@@ -185,6 +186,7 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], hipEventDisableTiming));
     }
     const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
     DALLOC(h, h->meta, 1);
@@ -301,7 +303,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d) hipStreamDestroy(h->stream_d);
-    for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); }
+    for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
     if (h->stream_t) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -750,9 +752,9 @@ int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
     return propagate_dev(h, d_imu, m);
 }
 
-static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
+static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m, bool propagated = false) {
     h->img_count++;
-    int rc = propagate_dev(h, d_imu, m);
+    int rc = propagated ? RVIO_OK : propagate_dev(h, d_imu, m);
     if (rc != RVIO_OK) return rc;
     if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
         rc = rvio_hip_update_tracked(h);
@@ -763,24 +765,45 @@ static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
 // Pipelined: the tracker (pyramid, KLT, RANSAC, book-keeping) never reads the filter state, so frame k's front end runs
 // on its own stream while frame k-1's propagate/update/augment still occupy the filter stream.  The Tracker -> Updater
 // hand-over is double-buffered; two events per buffer order (a) update(k) after track(k), (b) track(k+2) after update(k).
-int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    if (!h) return RVIO_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+// PreIntegrator::propagate needs nothing from the tracker either: it is enqueued first and runs beside the front end.
+static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand, bool staged) {
     const int b = (int)(h->frame_no & 1);
     h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
     if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
     else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
+    if (m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    static const bool dbg_host = getenv("RVIO_DBG_HOST") != nullptr;
+    static double acc[5] = {0, 0, 0, 0, 0}; static long nacc = 0;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = dbg_host ? now() : 0;
+    if (staged) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));   // the IMU batch was copied on the tracker stream
+    int rc = propagate_dev(h, d_imu, m);                                     // filter stream, right behind augment/compose(k-1)
+    if (rc != RVIO_OK) return rc;
+    const double t1 = dbg_host ? now() : 0;
     h->ts = h->stream_t;
-    int rc = rvio_hip_track_dev(h, d_img, stride, d_imu, m, d_cand, n_cand);
+    rc = rvio_hip_track_dev(h, d_img, stride, d_imu, m, d_cand, n_cand);
     h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
+    const double t2 = dbg_host ? now() : 0;
     HIPCHK(h, hipEventRecord(h->evT[b], h->stream_t));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
-    rc = frame_tail_dev(h, d_imu, m);
+    const double t3 = dbg_host ? now() : 0;
+    rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
+    const double t4 = dbg_host ? now() : 0;
     HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
+    if (dbg_host) {
+        const double t5 = now();
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
+        if (++nacc % 100 == 0) { std::fprintf(stderr, "host us/frame: propagate %.1f track %.1f evT %.1f tail %.1f evF %.1f\n", acc[0] / 100, acc[1] / 100, acc[2] / 100, acc[3] / 100, acc[4] / 100); for (double& a : acc) a = 0; }
+    }
     h->frame_no++;
     return rc;
+}
+int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    if (!h || !d_img) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false);
 }
 // The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253 (a cv::Mat and the IMU list).
 // The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap
@@ -799,10 +822,11 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     const int b = (int)(h->frame_no & 1);
     if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
     else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->hb_img[b], h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream_t));
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
+    HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
+    HIPCHK(h, hipMemcpy2DAsync(h->hb_img[b], h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream_t));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
-    return rvio_hip_frame_dev(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc);
+    return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
