@@ -380,15 +380,12 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
 #define SP_T 256
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
 __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
-    __shared__ float patch[SP_PW * SP_PW];
-    __shared__ float smask[SP_WW * SP_WW];
     __shared__ unsigned char reg[SP_RS * SP_RS];
-    __shared__ double s_part[4][5];
+    __shared__ double s_part[2][4][5];        // by iteration parity: one barrier per iteration
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = d.counters[2];
     if (p >= n) return;
     const int W = d.W, H = d.H;
-    for (int e = tid; e < SP_WW * SP_WW; e += SP_T) smask[e] = d.spmask[e];
     const float tx = d.raw_xy[2 * p], ty = d.raw_xy[2 * p + 1];
     // the estimate may wander SP_MARG px from the start before a sample has to come from global memory again:
     // cache that neighbourhood (coordinates clamped at load time = the replicated border)
@@ -411,30 +408,44 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
     int iter = 0;
     double err = 0;
     do {
-        // getRectSubPix: 17x17 bilinear patch, replicated border
-        {
-            const float ox = cx - (float)(SP_PW - 1) * 0.5f, oy = cy - (float)(SP_PW - 1) * 0.5f;
-            const int ix = (int)floorf(ox), iy = (int)floorf(oy);
-            float a = ox - (float)ix;
-            const float b = oy - (float)iy;
-            a = fmaxf(a, 0.0001f);
-            const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
-            for (int e = tid; e < SP_PW * SP_PW; e += SP_T) {
-                const int i = e / SP_PW, j = e % SP_PW;
-                patch[e] = ((pix(ix + j, iy + i) * a11 + pix(ix + j + 1, iy + i) * a12) + pix(ix + j, iy + i + 1) * a21) + pix(ix + j + 1, iy + i + 1) * a22;
-            }
-        }
-        __syncthreads();
+        if (iter == 3) DBG_T(41);
+        // getRectSubPix: element (pi, pj) of the 17x17 bilinear patch (replicated border).  Every thread evaluates the four
+        // patch elements its window term needs itself (same expression as a stored patch would hold): no patch in LDS, no barrier.
+        const float ox = cx - (float)(SP_PW - 1) * 0.5f, oy = cy - (float)(SP_PW - 1) * 0.5f;
+        const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+        float fa = ox - (float)ix;
+        const float fb = oy - (float)iy;
+        fa = fmaxf(fa, 0.0001f);
+        const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
+        auto samp = [&](int pi, int pj) -> float {
+            const int x = ix + pj, y = iy + pi;
+            return ((pix(x, y) * a11 + pix(x + 1, y) * a12) + pix(x, y + 1) * a21) + pix(x + 1, y + 1) * a22;
+        };
+        if (iter == 3) DBG_T(42);
         double ra = 0, rb = 0, rc = 0, r1s = 0, r2s = 0;
         if (live) {
-            const float* sp = &patch[(wi + 1) * SP_PW + 1 + wj];
-            const double tgx = sp[1] - sp[-1];
-            const double tgy = sp[SP_PW] - sp[-SP_PW];
+            float sE, sW, sS, sN;                       // patch elements (wi+1, wj+2), (wi+1, wj), (wi+2, wj+1), (wi, wj+1)
+            const int bx = ix + wj - rx0, by = iy + wi - ry0;
+            if ((unsigned)bx <= (unsigned)(SP_RS - 4) && (unsigned)by <= (unsigned)(SP_RS - 4)) {
+                // the 4x4 pixel block behind the four elements lies in the cached neighbourhood: 12 plain LDS reads
+                const unsigned char* q = reg + by * SP_RS + bx;
+                const float p01 = q[1], p02 = q[2];
+                const float p10 = q[SP_RS], p11 = q[SP_RS + 1], p12 = q[SP_RS + 2], p13 = q[SP_RS + 3];
+                const float p20 = q[2 * SP_RS], p21 = q[2 * SP_RS + 1], p22 = q[2 * SP_RS + 2], p23 = q[2 * SP_RS + 3];
+                const float p31 = q[3 * SP_RS + 1], p32 = q[3 * SP_RS + 2];
+                sE = ((p12 * a11 + p13 * a12) + p22 * a21) + p23 * a22;
+                sW = ((p10 * a11 + p11 * a12) + p20 * a21) + p21 * a22;
+                sS = ((p21 * a11 + p22 * a12) + p31 * a21) + p32 * a22;
+                sN = ((p01 * a11 + p02 * a12) + p11 * a21) + p12 * a22;
+            } else { sE = samp(wi + 1, wj + 2); sW = samp(wi + 1, wj); sS = samp(wi + 2, wj + 1); sN = samp(wi, wj + 1); }
+            const double tgx = sE - sW;
+            const double tgy = sS - sN;
             const double gxx = tgx * tgx * wm, gxy = tgx * tgy * wm, gyy = tgy * tgy * wm;
             ra = gxx; rb = gxy; rc = gyy;
             r1s = gxx * px + gxy * py;
             r2s = gxy * px + gyy * py;
         }
+        if (iter == 3) DBG_T(43);
         // canonical order (oracle/detector.cpp): per window row a balanced tree over the 16 columns (j, j+8), (.., +4), (.., +2),
         // (.., +1) = four DPP row rotations; per wave (rows 4w..4w+3) (R0 + R1) + (R2 + R3); then (W0 + W1) + (W2 + W3)
         ra += dpp_f64<0x128>(ra); rb += dpp_f64<0x128>(rb); rc += dpp_f64<0x128>(rc); r1s += dpp_f64<0x128>(r1s); r2s += dpp_f64<0x128>(r2s);
@@ -447,14 +458,17 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
             const double w2 = (readlane_f64(rc, 0) + readlane_f64(rc, 16)) + (readlane_f64(rc, 32) + readlane_f64(rc, 48));
             const double w3 = (readlane_f64(r1s, 0) + readlane_f64(r1s, 16)) + (readlane_f64(r1s, 32) + readlane_f64(r1s, 48));
             const double w4 = (readlane_f64(r2s, 0) + readlane_f64(r2s, 16)) + (readlane_f64(r2s, 32) + readlane_f64(r2s, 48));
-            if (lane == 0) { s_part[wv][0] = w0; s_part[wv][1] = w1; s_part[wv][2] = w2; s_part[wv][3] = w3; s_part[wv][4] = w4; }
+            if (lane == 0) { double* sp = s_part[iter & 1][wv]; sp[0] = w0; sp[1] = w1; sp[2] = w2; sp[3] = w3; sp[4] = w4; }
         }
+        if (iter == 3) DBG_T(44);
         __syncthreads();
-        const double a = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
-        const double b = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
-        const double c = (s_part[0][2] + s_part[1][2]) + (s_part[2][2] + s_part[3][2]);
-        const double bb1 = (s_part[0][3] + s_part[1][3]) + (s_part[2][3] + s_part[3][3]);
-        const double bb2 = (s_part[0][4] + s_part[1][4]) + (s_part[2][4] + s_part[3][4]);
+        if (iter == 3) DBG_T(45);
+        const double (*sq)[5] = s_part[iter & 1];
+        const double a = (sq[0][0] + sq[1][0]) + (sq[2][0] + sq[3][0]);
+        const double b = (sq[0][1] + sq[1][1]) + (sq[2][1] + sq[3][1]);
+        const double c = (sq[0][2] + sq[1][2]) + (sq[2][2] + sq[3][2]);
+        const double bb1 = (sq[0][3] + sq[1][3]) + (sq[2][3] + sq[3][3]);
+        const double bb2 = (sq[0][4] + sq[1][4]) + (sq[2][4] + sq[3][4]);
         const double det = a * c - b * b;
         if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
         const double scale = 1.0 / det;
@@ -464,8 +478,11 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
         err = (double)(ex * ex + ey * ey);
         cx = nx; cy = ny;
         if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
-        __syncthreads();                                     // s_part / patch are rewritten by the next iteration
+        if (iter == 3) { DBG_T(46); DBG_T(47); }
     } while (++iter < 30 && err > eps);
+#ifdef RVIO_DBG_CLOCKS
+    if (p == 0 && tid == 0) g_dbg[48] = iter;
+#endif
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
     if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }
