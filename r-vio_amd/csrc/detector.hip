@@ -250,6 +250,39 @@ __global__ __launch_bounds__(NEIGH_T) void neigh_kernel(DetDev d) {
 
 #define GREEDY_T 1024
 #define DET_LDS_ST 32768      // candidate states kept in LDS (the rest in global memory)
+// One candidate of one round on the general path; returns drop | wait << 1.  m >= 0: neighbour list in global memory;
+// m < 0: list overflow / beyond n_cap -> scan the 3x3 cells of the global buckets.
+__device__ __noinline__ int greedy_general_step(const DetDev& d, int c, int m, unsigned char* lst, int cell, int gw, int gh, double md2) {
+    volatile unsigned char* ls = lst;
+    volatile unsigned char* gs = d.state;
+    const int W = d.W;
+    bool drop = false, wait = false;
+    auto st_get = [&](int ci) -> unsigned char { return ci < DET_LDS_ST ? ls[ci] : gs[ci]; };
+    if (m >= 0) {
+        const int* list = d.nb + (size_t)c * DET_NBCAP;
+        for (int e = 0; e < m; ++e) { const unsigned char s2 = st_get(list[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
+    } else {
+        const size_t cap = (size_t)cell * cell;
+        const unsigned long long key = d.cand[c];
+        const int idx = (int)(key & 0xffffffffull);
+        const int x = idx % W, y = idx / W, xc = x / cell, yc = y / cell;
+        const int x1 = xc > 0 ? xc - 1 : 0, y1 = yc > 0 ? yc - 1 : 0, x2 = xc + 1 < gw ? xc + 1 : gw - 1, y2 = yc + 1 < gh ? yc + 1 : gh - 1;
+        for (int yy = y1; yy <= y2; ++yy)
+            for (int xx = x1; xx <= x2; ++xx) {
+                const int cc = yy * gw + xx, cnt = d.cell_cnt[cc];
+                const unsigned long long* ent = d.cell_ent + (size_t)cc * cap;
+                const int* eci = d.cell_ci + (size_t)cc * cap;
+                for (int e = 0; e < cnt; ++e) {
+                    const unsigned long long k2 = ent[e];
+                    if (!(k2 > key)) continue;
+                    const int i2 = (int)(k2 & 0xffffffffull);
+                    const float ddx = (float)x - (float)(i2 % W), ddy = (float)y - (float)(i2 / W);
+                    if ((double)(ddx * ddx + ddy * ddy) < md2) { const unsigned char s2 = st_get(eci[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
+                }
+            }
+    }
+    return (drop ? 1 : 0) | (wait ? 2 : 0);
+}
 #define DET_LDS_TK 4096       // taken keys ranked from LDS
 // Priority rounds over the neighbour lists until every candidate is decided, then rank-by-counting: one workgroup.
 #define DET_CL_N 2048         // up to this many candidates the neighbour lists are packed into LDS as well
@@ -272,7 +305,6 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
     volatile unsigned char* gs = d.state;
 #define ST_GET(ci) ((ci) < DET_LDS_ST ? ls[(ci)] : gs[(ci)])
 #define ST_SET(ci, v) do { if ((ci) < DET_LDS_ST) ls[(ci)] = (v); else gs[(ci)] = (v); } while (0)
-    const size_t cap = (size_t)cell * cell;
     DBG_T(56);
     for (int c = tid; c < n; c += GREEDY_T) ST_SET(c, 1);
     // usual case: pack the (short) neighbour lists into LDS so that the rounds never leave the CU
@@ -293,67 +325,85 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
         __syncthreads();
         packed = (s_flag == 0);
         if (packed) {
-            if (c0 < n) { coff[c0] = base; const int* l = d.nb + (size_t)c0 * DET_NBCAP; for (int e = 0; e < m0; ++e) clist[base + e] = (unsigned short)l[e]; }
-            if (c1 < n) { coff[c1] = base + m0; const int* l = d.nb + (size_t)c1 * DET_NBCAP; for (int e = 0; e < m1; ++e) clist[base + m0 + e] = (unsigned short)l[e]; }
+            // 16 entries per trip, fetched as four 16-byte loads in flight together (a row holds DET_NBCAP = 64 ints, so reading
+            // past the list's end stays inside the row)
+            auto copy_list = [&](int c, int dst, int m) {
+                const int4* l4 = (const int4*)(d.nb + (size_t)c * DET_NBCAP);
+                for (int q = 0; q < m; q += 16) {
+                    const int4 v0 = l4[q / 4], v1 = l4[q / 4 + 1], v2 = l4[q / 4 + 2], v3 = l4[q / 4 + 3];
+                    const int v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (q + u < m) clist[dst + q + u] = (unsigned short)v[u];
+                }
+            };
+            if (c0 < n) { coff[c0] = base; copy_list(c0, base, m0); }
+            if (c1 < n) { coff[c1] = base + m0; copy_list(c1, base + m0, m1); }
             if (c0 == n - 1) coff[n] = base + m0;
             if (c1 == n - 1) coff[n] = base + m0 + m1;
         }
     }
     __threadfence_block();
     __syncthreads();
+    DBG_T(57);
     int pending, rounds = 0;
     do {
         pending = 0; ++rounds;
+        if (rounds == 1) DBG_T(10);
         for (int c = tid; c < n; c += GREEDY_T) {
             if (ST_GET(c) != 1) continue;
             bool drop = false, wait = false;
             const int m = packed ? -2 : (c < d.n_cap ? d.nb_cnt[c] : -1);
             if (m == -2) {
                 const int o = coff[c], o1 = coff[c + 1];
-                for (int e = o; e < o1; ++e) { const unsigned char s2 = ls[clist[e]]; drop |= (s2 == 2); wait |= (s2 == 1); }
-            } else if (m >= 0) {
-                const int* list = d.nb + (size_t)c * DET_NBCAP;
-                for (int e = 0; e < m; ++e) { const unsigned char s2 = ST_GET(list[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
-            } else {   // list overflow / beyond n_cap: scan the 3x3 cells of the global buckets
-                const unsigned long long key = d.cand[c];
-                const int idx = (int)(key & 0xffffffffull);
-                const int x = idx % W, y = idx / W, xc = x / cell, yc = y / cell;
-                const int x1 = xc > 0 ? xc - 1 : 0, y1 = yc > 0 ? yc - 1 : 0, x2 = xc + 1 < gw ? xc + 1 : gw - 1, y2 = yc + 1 < gh ? yc + 1 : gh - 1;
-                for (int yy = y1; yy <= y2; ++yy)
-                    for (int xx = x1; xx <= x2; ++xx) {
-                        const int cc = yy * gw + xx, cnt = d.cell_cnt[cc];
-                        const unsigned long long* ent = d.cell_ent + (size_t)cc * cap;
-                        const int* eci = d.cell_ci + (size_t)cc * cap;
-                        for (int e = 0; e < cnt; ++e) {
-                            const unsigned long long k2 = ent[e];
-                            if (!(k2 > key)) continue;
-                            const int i2 = (int)(k2 & 0xffffffffull);
-                            const float ddx = (float)x - (float)(i2 % W), ddy = (float)y - (float)(i2 / W);
-                            if ((double)(ddx * ddx + ddy * ddy) < md2) { const unsigned char s2 = ST_GET(eci[e]); drop |= (s2 == 2); wait |= (s2 == 1); }
-                        }
-                    }
+                for (int e = o; e < o1 && !drop; e += 8) {       // 8 neighbours per trip: indices first, then their states
+                    // unconditional loads (indices clamped to the list's last entry: re-reading it changes nothing), so that
+                    // the eight index reads and then the eight state reads are each in flight together.  Plain loads: a
+                    // stale state only delays a decision, and the barrier of the round forces a re-read.
+                    int id8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) id8[u] = (int)clist[min(e + u, o1 - 1)];
+                    unsigned char s8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s8[u] = lst[id8[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { drop |= (s8[u] == 2); wait |= (s8[u] == 1); }
+                }
+            } else {   // dense candidate sets: lists / cell buckets in global memory (out of line: keeps the usual path compact)
+                const int dw = greedy_general_step(d, c, m, lst, cell, gw, gh, md2);
+                drop = (dw & 1) != 0; wait = (dw & 2) != 0;
             }
+            if (rounds == 1) DBG_T(11);
             if (drop) ST_SET(c, 3);
             else if (!wait) ST_SET(c, 2);
             else pending = 1;
         }
+        if (rounds == 1) DBG_T(12);
         __threadfence_block();
         pending = __syncthreads_or(pending);
+        if (rounds == 1) DBG_T(13);
+        if (rounds == 2) DBG_T(14);
     } while (pending);
     DBG_T(59);
 #ifdef RVIO_DBG_CLOCKS
     if (tid == 0) { g_dbg[62] = n; g_dbg[63] = rounds; }
 #endif
     // taken candidates -> list; rank by counting; the strongest F leave in descending order
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    const bool small = n <= DET_LDS_TK;          // then the taken keys go straight to LDS
     for (int c = tid; c < n; c += GREEDY_T)
-        if (ST_GET(c) == 2) d.acc[atomicAdd(&d.counters[1], 1)] = d.cand[c];
+        if (ST_GET(c) == 2) {
+            const unsigned long long key = d.cand[c];
+            if (small) tk[atomicAdd(&s_flag, 1)] = key;
+            else d.acc[atomicAdd(&d.counters[1], 1)] = key;
+        }
 #undef ST_GET
 #undef ST_SET
     __threadfence_block();
     __syncthreads();
-    const int na = ((volatile int*)d.counters)[1];
-    const bool in_lds = na <= DET_LDS_TK;
-    if (in_lds) for (int a = tid; a < na; a += GREEDY_T) tk[a] = d.acc[a];
+    const int na = small ? s_flag : ((volatile int*)d.counters)[1];
+    const bool in_lds = small || na <= DET_LDS_TK;
+    if (!small && in_lds) for (int a = tid; a < na; a += GREEDY_T) tk[a] = d.acc[a];
     __syncthreads();
     for (int a = tid; a < na; a += GREEDY_T) {
         const unsigned long long key = in_lds ? tk[a] : d.acc[a];

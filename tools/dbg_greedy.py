@@ -20,5 +20,6 @@ for k in range(39, 39 + 30):
     h.sync()
     c = np.zeros(64, np.int64)
     h.L.rvio_hip_debug_clocks(h.h, c.ctypes.data_as(C.c_void_p))
-    print(k, "n", c[62], "rounds", c[63], "cycles: buckets %d lists %d rounds %d rank %d total %d" % (
-        c[57] - c[56], c[58] - c[57], c[59] - c[58], c[60] - c[59], c[60] - c[56]))
+    print(k, "n", c[62], "rounds", c[63], "cycles: init+pack %d rounds %d rank+out %d total %d" % (
+        c[57] - c[56], c[59] - c[57], c[60] - c[59], c[60] - c[56]),
+          "| round 1: t0 list %d, decide %d, barrier %d ; round 2 total %d" % (c[11] - c[10], c[12] - c[11], c[13] - c[12], c[14] - c[13]))
