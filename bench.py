@@ -261,17 +261,17 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     fl_solve = 2.0 * c6 * c6 * (c6 + 1)
     PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read live, so this is the committed
-    # rocprofv3 --pmc result (profiles/r01_d_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
+    # rocprofv3 --pmc result (profiles/r01_e_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")) as fh:
             e = [v for k, v in json.load(fh).items() if k.startswith("solve6_kernel")][0]
         traffic = 1024.0 * (e["fetch_kb_mean"] + e["write_kb_mean"])
     except (OSError, IndexError, KeyError, ValueError):
         pass
     res["roofline"] = {"bound": "mfma", "kernel": "solve6_kernel (W = (s2 I + A Pcc)^-1, one workgroup)",
                        "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
-                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r01_d_pmc_traffic.md)",
+                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r01_e_pmc_traffic.md)",
                        "avg_us": t_solve * 1e6,
                        "note": "latency bound: a %dx%d FP64 elimination on ONE CU with one barrier per column; a single 752x480 stream "
                                "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction" % (c6, c6 + 1)}
