@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-streams", action="store_true")
     ap.add_argument("--no-equalizer", action="store_true", help="Tracker.EnableEqualizer: 0 (skip CLAHE)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded-updater frame path (RCCL all-gather) even with one rank")
     ap.add_argument("--host-corners", action="store_true",
                     help="feed a caller-side corner list (projected landmarks) instead of running the device detector")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
@@ -95,8 +96,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # Tracker.EnableEqualizer: 1 in the stock config (config/rvio_euroc.yaml): CLAHE runs on every frame
@@ -123,22 +128,29 @@ def main():
     wi, ai, ni = seq.init_from_static(K0)
     h.initialize(wi, ai, ni)
 
-    gathered = None
-    if world > 1:
+    gathered, comm = None, None
+    if sharded:
+        if not os.environ.get("RVIO_TORCH_COLLECTIVE"):
+            from rvio_amd import rccl
+            comm = rccl.RcclComm(rank, world, dist, torch)
         nblk = (6 * (cfg.max_track_len - 1) + 1) ** 2
         gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda")
 
     def frame(i):
-        if world == 1:
+        if not sharded:
             h.frame_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
         else:
-            h.track_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
-            h.frame_tail_sharded(p_imu + i * imu_stride_b, int(imu_cnt[i]), rank, world, gathered, dist, DeviceArray, torch)
+            # pipelined like N=1; the all-gather is enqueued on the handle's filter stream (no host synchronisation per frame)
+            h.frame_sharded_piped(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b,
+                                  int(cand_cnt[i]), rank, world, gathered, dist, DeviceArray, torch, stream, force_collective=args.force_sharded, comm=comm)
 
     for i in range(1 + W):
         frame(i)
     h.sync()
     torch.cuda.synchronize()
+    if sharded:      # RCCL may have printed its version banner through C stdio: push it out now, the JSON line must come last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     if world > 1:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -198,10 +210,14 @@ def main():
                                       "informative rows (tests/test_truncation.py, DESIGN.md section 3)")
         out.pop("x_at_cpu_frames", None)
     h.close()
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if sharded:
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def _qfix(x):

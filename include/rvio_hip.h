@@ -196,6 +196,15 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
  * pinned buffers must stay valid until two further frames or rvio_hip_sync. */
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride,
                    const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
+/* The pipelined frame split open for callers that run the update themselves (the feature-sharded
+ * updater): frame_begin_dev enqueues PreIntegrator::propagate on the filter stream and the front
+ * end on its own streams and orders the filter stream after the front end; the caller then issues
+ * rvio_hip_frame_plan, the update (rvio_hip_update_local -> collective on rvio_hip_stream ->
+ * rvio_hip_update_global, or rvio_hip_update_tracked) and rvio_hip_augment_compose; frame_end
+ * closes the frame.  No host synchronisation anywhere. */
+int rvio_hip_frame_begin_dev(rvio_hip* h, const uint8_t* d_img, int stride,
+                             const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
+int rvio_hip_frame_end(rvio_hip* h);
 /* For callers that sequence the frame themselves (per-stage timing, the sharded updater):
  * frame_plan advances nImageCountAfterInit and reports MonoVIO's two data-independent
  * branches (System.cc:266 `nCloneStates > mnMinCloneStates`, System.cc:280

@@ -33,7 +33,7 @@ struct rvio_hip {
     hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
     hipEvent_t evT[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
     long frame_no = 0;
-    bool piped = false;
+    bool piped = false, in_frame = false;
     struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[2];
     std::string err;
     // filter state (double-buffered)
@@ -766,7 +766,9 @@ static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m, bool propag
 // on its own stream while frame k-1's propagate/update/augment still occupy the filter stream.  The Tracker -> Updater
 // hand-over is double-buffered; two events per buffer order (a) update(k) after track(k), (b) track(k+2) after update(k).
 // PreIntegrator::propagate needs nothing from the tracker either: it is enqueued first and runs beside the front end.
-static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand, bool staged) {
+static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand, bool staged,
+                          bool begin_only = false) {
+    if (h->in_frame) { h->err = "rvio_hip_frame_begin_dev without rvio_hip_frame_end"; return RVIO_ERR_INVALID; }
     const int b = (int)(h->frame_no & 1);
     h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
     if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
@@ -789,6 +791,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     HIPCHK(h, hipEventRecord(h->evT[b], h->stream_t));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
     const double t3 = dbg_host ? now() : 0;
+    if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
     const double t4 = dbg_host ? now() : 0;
     HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
@@ -804,6 +807,24 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     if (!h || !d_img) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false);
+}
+// The pipelined frame split open for callers that sequence the update themselves (the feature-sharded updater):
+//   frame_begin_dev   propagate on the filter stream, the front end on its streams, filter stream ordered after the front end
+//   ... rvio_hip_frame_plan, rvio_hip_update_local / collective / rvio_hip_update_global (or update_tracked), rvio_hip_augment_compose,
+//       all on the filter stream (rvio_hip_stream) ...
+//   frame_end         closes the frame (hand-over buffer released for frame k+2)
+int rvio_hip_frame_begin_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    if (!h || !d_img) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false, /*begin_only=*/true);
+}
+int rvio_hip_frame_end(rvio_hip* h) {
+    if (!h || !h->in_frame) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->evF[h->frame_no & 1], h->stream));
+    h->frame_no++;
+    h->in_frame = false;
+    return RVIO_OK;
 }
 // The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253 (a cv::Mat and the IMU list).
 // The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap

@@ -21,7 +21,7 @@ SYMBOLS = [
     "rvio_hip_frame", "rvio_hip_frame_dev", "rvio_hip_frame_points", "rvio_hip_get_frame_info", "rvio_hip_get_pose",
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
-    "rvio_hip_debug_time_kernel", "rvio_hip_get_corners",
+    "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
 ]
 
 _LIB = None
@@ -227,6 +227,36 @@ class RvioHip:
         with torch.cuda.stream(stream):
             evs[4].record()
         return do_update
+
+    def frame_begin_dev(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand):
+        self._ck(self.L.rvio_hip_frame_begin_dev(self.h, C.c_void_p(d_img_ptr), int(stride), C.c_void_p(d_imu_ptr), int(m),
+                                                 C.c_void_p(d_cand_ptr), int(n_cand)), "frame_begin_dev")
+
+    def frame_end(self):
+        self._ck(self.L.rvio_hip_frame_end(self.h), "frame_end")
+
+    def frame_sharded_piped(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand, rank, world, gathered, dist, DeviceArray, torch, stream,
+                            force_collective=False, comm=None):
+        """One pipelined frame with the feature-sharded updater, no host synchronisation: the front end of this
+        frame overlaps the previous frame's filter work; local [A|b] block -> ONE all-gather, enqueued behind the block kernel
+        because the handle's filter stream is torch's current stream -> replicated global update."""
+        with torch.cuda.stream(stream):
+            self.frame_begin_dev(d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand)
+            do_update, do_augment = self.frame_plan()
+            if do_update:
+                if world > 1 or force_collective:
+                    ptr, n = self.update_local_tracked(rank, world)
+                    if comm is not None:       # RCCL directly on the filter stream (rccl.py): plain stream order, nothing else
+                        comm.all_gather_f64(ptr, gathered.data_ptr(), n, self.stream())
+                    else:
+                        if getattr(self, "_local_key", None) != (ptr, n):  # the block lives in one fixed device buffer: wrap it once
+                            self._local_key, self._local = (ptr, n), torch.as_tensor(DeviceArray(ptr, n), device="cuda")
+                        dist.all_gather_into_tensor(gathered, self._local)
+                    self.update_global(gathered.data_ptr(), world)
+                else:
+                    self._ck(self.L.rvio_hip_update_tracked(self.h), "update_tracked")
+            self.augment_compose(do_augment)
+            self.frame_end()
 
     def frame_tail_sharded(self, d_imu_ptr, m, rank, world, gathered, dist, DeviceArray, torch):
         """Feature-sharded frame tail: local [A|b] block -> ONE all-gather -> replicated EKF update."""

@@ -107,6 +107,43 @@ def test_whole_frame_from_host_buffers(gpu_required, frames):
     assert S.state_delta(xa, xb) <= 1e-6
 
 
+def test_frame_begin_end_split_equals_frame_dev(gpu_required, frames):
+    """rvio_hip_frame_begin_dev / frame_plan / update / augment_compose / frame_end (what the sharded updater uses) gives the
+    same states, bit for bit, as rvio_hip_frame_dev; no host synchronisation between frames"""
+    from rvio_amd import hip
+    import torch
+    cfg, seq, ks, imgs = frames
+    w, a, n = seq.init_from_static(38)
+    res = []
+    for split in (False, True):
+        h = hip.RvioHip(cfg)
+        h.initialize(w, a, n)
+        keep = []
+        for k, img in zip(ks, imgs):
+            xy, vis = seq.project(k, noise=False)
+            cand, _ = seq.candidates(k, xy, vis)
+            imu = seq.imu_between(k)
+            d_img = torch.from_numpy(img).cuda()
+            d_imu = torch.from_numpy(imu.view(np.uint8)).cuda()
+            d_cand = torch.from_numpy(cand).cuda()
+            keep += [d_img, d_imu, d_cand]
+            torch.cuda.synchronize()
+            args = (d_img.data_ptr(), img.shape[1], d_imu.data_ptr(), len(imu), d_cand.data_ptr(), len(cand))
+            if split:
+                h.frame_begin_dev(*args)
+                do_update, do_augment = h.frame_plan()
+                if do_update:
+                    h.update_tracked()
+                h.augment_compose(do_augment)
+                h.frame_end()
+            else:
+                h.frame_dev(*args)
+        h.sync()
+        res.append(h.get_state())
+        h.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_whole_frame_with_images(gpu_required, frames):
     """System::MonoVIO body on images: HIP vs oracle states within 1e-6 over the sequence."""
     from rvio_amd import hip
