@@ -132,7 +132,15 @@ def main():
     if sharded:
         if not os.environ.get("RVIO_TORCH_COLLECTIVE"):
             from rvio_amd import rccl
-            comm = rccl.RcclComm(rank, world, dist, torch)
+            try:
+                comm = rccl.RcclComm(rank, world, dist, torch)
+            except (OSError, RuntimeError, AttributeError) as e:
+                print("rank %d: direct RCCL communicator unavailable (%s); using the process-group collective" % (rank, e), file=sys.stderr)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         nblk = (6 * (cfg.max_track_len - 1) + 1) ** 2
         gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda")
 
@@ -185,15 +193,24 @@ def main():
         "config": {"workload": "cfg%s: synthetic EuRoC-shaped %dx%d @20Hz, %d features, %d-clone window, IMU 200 Hz, single stream, equalizer %s, corners from %s"
                                % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off",
                                   "a caller-side list" if args.host_corners else "the device detector (GFTT + cornerSubPix)"),
-                   "parallelism": "1 process/GPU; feature-sharded updater + 1 all-gather/frame" if world > 1 else "single GPU"},
+                   "parallelism": ("1 process/GPU; feature-sharded updater + 1 all-gather/frame (%s)"
+                                   % ("ncclAllGather on the filter stream" if comm is not None else "torch.distributed")) if sharded else "single GPU"},
         "gpu_ms_per_step_events": gpu_ms / K, "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
     }
 
+    if rank == 0 and not args.no_latency:
+        # (also at N>1: the per-kernel roofline is a property of one GPU; the other ranks wait in the barrier below)
+        out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
+                                img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni, device=local_rank))
+        x_single = out.pop("x_final")
+        if sharded:   # the sharded updater against the same frames through the one-GPU updater (block sums in rank order: rounding only)
+            out["max_state_delta_sharded_vs_single_gpu"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(x_single))))
+        if world > 1:
+            out.pop("x_at_cpu_frames", None)
+    if world > 1:
+        dist.barrier()
     if rank == 0 and world == 1:
-        if not args.no_latency:
-            out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
-                                    img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni))
         if not args.no_streams:
             out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
                                                wi, ai, ni, n_frames, 1 + W, streams=args.streams, threads=args.stream_threads)
@@ -228,13 +245,14 @@ def _qfix(x):
     return x
 
 
-def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, k0, wi, ai, ni):
+def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, k0, wi, ai, ni,
+                 device=0):
     """Second, untimed-for-throughput pass on a fresh handle: per-stage device latencies with HIP events on the
     handle's stream (p50 EKF-update ms of the metric), the dominant kernel's roofline, and the state after
     `cpu_frames` frames for the parity figure."""
     from rvio_amd import hip
-    h = hip.RvioHip(cfg)
-    st = torch.cuda.ExternalStream(h.stream())
+    h = hip.RvioHip(cfg, device=device)
+    st = torch.cuda.ExternalStream(h.stream(), device=torch.device("cuda", device))
     h.initialize(wi, ai, ni)
     n = len(imgs)
     L = h.L
@@ -264,7 +282,7 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     res = {"latency_ms_p50": {k: float(np.median(v)) for k, v in lat.items() if v},
            "latency_ms_p95": {k: float(np.percentile(v, 95)) for k, v in lat.items() if v},
            "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
-           "x_at_cpu_frames": x_at}
+           "x_at_cpu_frames": x_at, "x_final": h.get_state()[0]}
     # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree)
     # Dominant kernel by device time: the solve kernel (in-place Gauss-Jordan of T = s2 I + A Pcc, c6 = 6n columns).
     # Algorithmic FP64 work per launch = c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8).

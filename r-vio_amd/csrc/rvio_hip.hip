@@ -400,9 +400,9 @@ static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
     return RVIO_OK;
 }
 int rvio_hip_propagate(rvio_hip* h, const rvio_imu* imu, int m) {
-    if (!h || !imu || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    if (!h || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     return propagate_dev(h, h->d_imu, m);
 }
 
@@ -669,11 +669,11 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
 }
 
 int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || !img || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = std::min(n_cand, h->dc.F);
     HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     if (nc > 0 && cand_xy) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
     return rvio_hip_track_dev(h, h->d_img, h->dc.W, h->d_imu, m, cand_xy ? h->d_cand : nullptr, cand_xy ? nc : 0);
 }
@@ -681,14 +681,14 @@ int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
 // direct-track mode: the caller supplies the KLT result
 int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
+    if (!h || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = std::min(n_cand, h->dc.F);
     if (n_pts > 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_in_xy, tracked_xy, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_in_st, status, n_pts, hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
+    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);
     h->use_det = false;   // no image in this mode
@@ -747,7 +747,7 @@ int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment) {
     return RVIO_OK;
 }
 int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
-    if (!h || !d_imu || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    if (!h || (!d_imu && m > 0) || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     return propagate_dev(h, d_imu, m);
 }
@@ -830,7 +830,7 @@ int rvio_hip_frame_end(rvio_hip* h) {
 // The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap
 // the previous frame's filter work like the tracker kernels do.
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || !img || !imu || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = cand_xy ? std::min(n_cand, h->dc.F) : 0;   // cand_xy == NULL: device detector
     if (!h->hb_img[0])

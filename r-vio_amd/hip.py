@@ -151,19 +151,27 @@ class RvioHip:
         cand = np.ascontiguousarray(cand, np.float32)
         return _p(cand, fp), len(cand), cand
 
+    @staticmethod
+    def _img(img):
+        """(array, row stride in bytes): a row-strided uint8 view is handed over as it is (cv::Mat::step), anything else is packed"""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(img, np.uint8)
+        return img, img.strides[0]
+
     def track(self, img, imu, cand=None):
-        img = np.ascontiguousarray(img, np.uint8)
+        img, stride = self._img(img)
         imu = np.ascontiguousarray(imu)
         cp, cn, _keep = self._cand(cand)
-        self._ck(self.L.rvio_hip_track(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
+        self._ck(self.L.rvio_hip_track(self.h, C.cast(img.ctypes.data, up), stride, imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
                                        cp, cn), "track")
 
     def frame(self, img, imu, cand=None):
         """whole MonoVIO body from host buffers (System.cc:253-367); cand=None: device detector"""
-        img = np.ascontiguousarray(img, np.uint8)
+        img, stride = self._img(img)
         imu = np.ascontiguousarray(imu)
         cp, cn, _keep = self._cand(cand)
-        self._ck(self.L.rvio_hip_frame(self.h, _p(img, up), img.shape[1], imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
+        self._ck(self.L.rvio_hip_frame(self.h, C.cast(img.ctypes.data, up), stride, imu.ctypes.data_as(C.POINTER(abi.rvio_imu)), len(imu),
                                        cp, cn), "frame")
 
     def get_corners(self, want_eig=False):

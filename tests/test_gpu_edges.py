@@ -1,0 +1,117 @@
+"""GPU parity at the edges of the path: images without a single corner (start-up and mid-sequence), an empty IMU batch, a row-strided
+image, an empty caller-side corner list.  The reference handles all of these with silent early-outs; the device must
+take the same ones: tracker tables bit-exact, filter states within 1e-6 of the oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+
+def _same_tracker(h, t, tag):
+    pa, ha = h.get_points()
+    pb, hb = t.get_points()
+    assert np.array_equal(pa, pb) and np.array_equal(ha, hb), tag
+    ta, la, ma = h.get_tracks()
+    tb, lb, mb = t.get_tracks()
+    assert np.array_equal(ta, tb) and np.array_equal(la, lb), tag
+    for f in range(len(la)):
+        assert np.array_equal(ma[f, : la[f]], mb[f, : lb[f]]), (tag, f)
+    return len(pa), len(la)
+
+
+@pytest.fixture(scope="module")
+def seqB():
+    cfg = abi.config_named("B")                          # stock settings: CLAHE on
+    seq = rv.synth.SynthSequence(cfg, duration=8.0)
+    ks = list(range(60, 72))
+    return cfg, seq, ks, [seq.render(k) for k in ks]
+
+
+@pytest.mark.parametrize("blank_at", [(0, 1), (5,), (4, 5, 6)])
+def test_cornerless_images(gpu_required, seqB, blank_at):
+    """uniform images: the detector finds nothing, KLT loses every point, RANSAC sees no pair, the update is skipped — at the first
+    image (the tracker must start later) and mid-sequence (every track ends at once, then the list refills)"""
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = seqB
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    t = s.tracker()
+    blank = np.full_like(imgs[0], 97)
+    fewest = 10 ** 9
+    worst = 0.0
+    for i, (k, img) in enumerate(zip(ks, imgs)):
+        im = blank if i in blank_at else img
+        imu = seq.imu_between(k)
+        s.frame(imu, None, img=im)
+        h.frame(im, imu)                                  # host buffers, device detector
+        h.sync()
+        n_pts, n_upd = _same_tracker(h, t, (blank_at, i))
+        fewest = min(fewest, n_pts)
+        xa, _ = h.get_state()
+        xb, _ = s.get_state()
+        assert np.all(np.isfinite(xa))
+        worst = max(worst, S.state_delta(xa, xb))
+    h.close()
+    assert fewest <= 6          # (a handful of points can survive ONE uniform image: flat patches match anywhere)
+    assert worst <= 1e-6, worst
+
+
+def test_empty_imu_batch(gpu_required, seqB):
+    """a frame that arrives with no IMU sample between it and the previous one (m = 0): propagate integrates nothing,
+    RANSAC's gyro rotation is the identity"""
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = seqB
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    t = s.tracker()
+    worst = 0.0
+    for i, (k, img) in enumerate(zip(ks, imgs)):
+        imu = seq.imu_between(k)
+        if i in (3, 7):
+            imu = imu[:0]
+        s.frame(imu, None, img=img)
+        h.frame(img, imu)
+        h.sync()
+        _same_tracker(h, t, i)
+        xa, Pa = h.get_state()
+        xb, Pb = s.get_state()
+        assert np.all(np.isfinite(xa)) and np.all(np.isfinite(Pa))
+        worst = max(worst, S.state_delta(xa, xb))
+    h.close()
+    assert worst <= 1e-6, worst
+
+
+def test_row_strided_image_and_empty_corner_list(gpu_required, seqB):
+    """cv::Mat::step > width (an ROI of a wider buffer) through rvio_hip_track / rvio_hip_frame; and a caller that passes a corner
+    list with no entry (n = 0, non-NULL): the feature list simply is not refilled"""
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = seqB
+    wide = np.zeros((cfg.height, cfg.width + 40), np.uint8)
+    h, h2 = hip.RvioHip(cfg), hip.RvioHip(cfg)
+    t = O.Tracker(cfg)
+    none = np.zeros((0, 2), np.float32)
+    for i, (k, img) in enumerate(zip(ks[:6], imgs)):
+        imu = seq.imu_between(k)
+        wide[:] = 255 - (i * 37) % 200                   # the padding must never be read
+        view = wide[:, 13:13 + cfg.width]
+        view[:] = img
+        cand = None if i < 3 else none                   # three frames with the device detector, then no refill
+        t.track(img, imu, cand)
+        h.track(view, imu, cand)
+        h2.track(img, imu, cand)
+        _same_tracker(h, t, i)
+        _same_tracker(h2, t, i)
+    h.close()
+    h2.close()
