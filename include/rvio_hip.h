@@ -211,6 +211,32 @@ int rvio_hip_frame_end(rvio_hip* h);
  * `nImageCountAfterInit > 1`); propagate_dev is rvio_hip_propagate on device-resident IMU. */
 int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment);
 int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m);
+
+/* --- batched filter ------------------------------------- */
+/* B independent filter instances (B robots / B replays of the same sensor rate) behind one
+ * handle: the filter state and the update scratch of instance i live in slab i, and every
+ * filter stage (PreIntegrator::propagate, Updater::update, augmentation/composition) is ONE
+ * launch with gridDim.z = B, i.e. the single-workgroup stages of one filter become B
+ * workgroups.  The arithmetic of an instance is the arithmetic of a plain handle, bit for bit.
+ * The reference runs one System per process (System.cc:38-41 globals); this is the multi-robot
+ * form of the same three calls.  A batch handle carries the filter only: the image entry points
+ * return RVIO_ERR_UNSUPPORTED; the window length is common to all instances (it depends on the
+ * frame count only, System.cc:266,280).  rvio_hip_set_state / rvio_hip_initialize give every
+ * instance the same state, rvio_hip_get_state reads instance 0. */
+int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, rvio_hip** out);
+int rvio_hip_batch_size(const rvio_hip* h);
+int rvio_hip_set_state_at(rvio_hip* h, int instance, const double* x, int xdim, const double* P, int d);
+int rvio_hip_get_state_at(rvio_hip* h, int instance, double* x, int* xdim, double* P, int* d);
+/* The body of System::MonoVIO after Tracker::track (System.cc:263-365: propagate, update if
+ * nCloneStates > mnMinCloneStates, augmentation + composition) on DEVICE-resident hand-over
+ * tables, for all B instances of the handle (B = 1 for a plain handle):
+ *   d_n_feat[B], d_types[B][Fu], d_len[B][Fu], d_meas[B][Fu][max_track_len][2]
+ * (Tracker::mvFeatTypesForUpdate / mvlFeatMeasForUpdate, Tracker.h:67-74, Fu = ceil(nFeatures/2));
+ * d_imu[B][imu_stride] samples, imu_stride = 0: one IMU batch shared by all instances.
+ * Track lengths must satisfy 2 <= len <= window length + 1 (what Tracker::track emits). */
+int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride, int m,
+                              const int32_t* d_n_feat, const unsigned char* d_types,
+                              const int32_t* d_len, const float* d_meas);
 /* same, direct-track mode, host inputs */
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand);

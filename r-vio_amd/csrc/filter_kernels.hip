@@ -43,8 +43,12 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
                                   double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                  double* pfinv_out, double* tm_global) {
+                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
     extern __shared__ __align__(16) double lds[];
+    x = zoff(x, bs); P = zoff(P, bs); Hstack = zoff(Hstack, bs); nrows_out = zoff(nrows_out, bs); acc_out = zoff(acc_out, bs);
+    ndof_out = zoff(ndof_out, bs); gamma_out = zoff(gamma_out, bs); pfinv_out = zoff(pfinv_out, bs);
+    if (tm_global) tm_global = zoff(tm_global, bs);
+    n_feat_ptr = zoff(n_feat_ptr, bin.n_feat); types = zoff(types, bin.types); lens = zoff(lens, bin.len); meas = zoff(meas, bin.meas);
     const int tid = threadIdx.x, T = blockDim.x, f = blockIdx.x;
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     // carve LDS
@@ -461,7 +465,8 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
 // is produced by gram_mfma_kernel (filter_kernels2.hip); the kernels below reduce it.
 // block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
-                                                          const int* nrows, double* block) {
+                                                          const int* nrows, double* block, size_t bs) {
+    partial = zoff(partial, bs); nrows = zoff(nrows, bs); block = zoff(block, bs);
     const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -503,7 +508,8 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
 //   A operand lane l : A[i = l&15][k = l>>4]      B operand lane l : B[k = l>>4][j = l&15]
 //   C/D      lane l : 4 values, row = (l>>4) + 4*r, col = l&15.
 // A = Ab (row-major, ld = ldh), B = Pcc = P[24:,24:] (column-major, ld = dmax), T row-major ld = ldh.
-__global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const double* Ab, const double* P, double* Tm) {
+__global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const double* Ab, const double* P, double* Tm, size_t bs) {
+    Ab = zoff(Ab, bs); P = zoff(P, bs); Tm = zoff(Tm, bs);
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     const double s2 = cfg.sigma_im * cfg.sigma_im;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -540,8 +546,9 @@ __global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const do
 // One workgroup (4 waves) per 16-row strip of the d rows.  K H = [0 | G];  (I - K H) P = P1.
 // LDS: Us[16][c6p], Gs[16][c6p] (row-major, c6p = c6 rounded up to 16, +1 pad).
 __global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double* P, const double* W, const double* Ab,
-                                                 double* U, double* G, double* P1) {
+                                                 double* U, double* G, double* P1, size_t bs) {
     extern __shared__ __align__(16) double sh[];
+    P = zoff(P, bs); W = zoff(W, bs); Ab = zoff(Ab, bs); U = zoff(U, bs); G = zoff(G, bs); P1 = zoff(P1, bs);
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
     const int lds = c6t * 16 + 1;
@@ -654,7 +661,8 @@ __device__ __forceinline__ d4 final_tile(const double* P1, const double* G, cons
     }
     return out;
 }
-__global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const double* P1, const double* G, const double* U, double* Pout) {
+__global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const double* P1, const double* G, const double* U, double* Pout, size_t bs) {
+    P1 = zoff(P1, bs); G = zoff(G, bs); U = zoff(U, bs); Pout = zoff(Pout, bs);
     __shared__ double tl[4][16][17];
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const double s2 = cfg.sigma_im * cfg.sigma_im;

@@ -24,7 +24,8 @@ __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
 struct Prop3Sample { double dR[9], up[3], uv[3], w[3], dt, Rk[9], vk[3], gk[3]; };
 
 __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
-                                                         double* __restrict__ P, const rvio_imu* __restrict__ imu, int m) {
+                                                         double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+    meta = zoff(meta, bs); x = zoff(x, bs); P = zoff(P, bs); imu = zoff(imu, imu_bs);
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
     __shared__ double Phi9[PROP3_CH][9][25];
@@ -202,7 +203,8 @@ __device__ __forceinline__ int aug_src2(int a, int n, int nmax, int do_aug) {
     return (cb < nmax - 1) ? a + 6 : 9 + off;
 }
 __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do_aug, const double* __restrict__ x, const double* __restrict__ P,
-                                                       double* __restrict__ x_out, double* __restrict__ P_out, double* __restrict__ pose_out) {
+                                                       double* __restrict__ x_out, double* __restrict__ P_out, double* __restrict__ pose_out, size_t bs) {
+    x = zoff(x, bs); P = zoff(P, bs); x_out = zoff(x_out, bs); P_out = zoff(P_out, bs); pose_out = zoff(pose_out, bs);
     __shared__ double Vk[24][25];
     __shared__ double P11[24][25];
     __shared__ double Tm[24][25];
@@ -301,8 +303,9 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
 #define GRAM2_FG 8
 #define GRAM2_RB 64
 __global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const double* __restrict__ Hstack, const int* __restrict__ nrows,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, size_t bs) {
     extern __shared__ __align__(16) double hs[];   // [GRAM2_RB][ldh + 1]
+    Hstack = zoff(Hstack, bs); nrows = zoff(nrows, bs); partial = zoff(partial, bs);
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max, lds = ldh + 1;
     const int g = blockIdx.x, p0 = blockIdx.y * 16;

@@ -46,6 +46,13 @@ struct FilterMeta {
 };
 
 // phase stamps for performance debugging (tools/dbg_clocks.py): DBG_T(i) records clock64() in slot i
+// Batched launches: gridDim.z = filter instances; every per-instance buffer of instance z lies `bs`
+// bytes behind instance 0's (one slab per instance, rvio_hip.hip).  bs = 0 and gridDim.z = 1 for a plain handle.
+template <typename T>
+__device__ __forceinline__ T* zoff(T* p, size_t bs) { return (T*)((char*)p + (size_t)blockIdx.z * bs); }
+// strides (bytes) of the per-instance inputs of a batched call: IMU samples and the Tracker -> Updater hand-over
+struct BatchIn { size_t imu, n_feat, types, len, meas; };
+
 __device__ long long g_dbg[64];
 #ifdef RVIO_DBG_CLOCKS
 #define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)

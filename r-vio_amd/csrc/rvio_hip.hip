@@ -73,6 +73,14 @@ struct rvio_hip {
     PyrDev pyr[2];
     int pyr_cur = 0;
     std::vector<void*> allocs;
+    // filter slab: the filter state, the update scratch and the Tracker -> Updater hand-over of ONE instance are carved from one
+    // slab; a batch handle (rvio_hip_create_batch) owns `batch` slabs back to back and launches every filter kernel with
+    // gridDim.z = batch (rvio_dev.h zoff)
+    char* slab = nullptr;
+    size_t slab_off = 0, slab_bytes = 0;
+    bool slab_mode = false;
+    int batch = 1;
+    BatchIn bin = {0, 0, 0, 0, 0};   // strides of the hand-over read by feat_build (slab_bytes for the handle's own buffers)
     int* rng = nullptr;
     int* cand_scratch = nullptr;
     rvio_frame_info* d_info = nullptr;
@@ -93,12 +101,22 @@ static int dalloc(rvio_hip* h, T** p, size_t n) {
     void* q = nullptr;
     size_t bytes = n * sizeof(T);
     if (bytes == 0) bytes = 16;
+    if (h->slab_mode) {   // bump allocation inside the filter slab (first pass, slab == nullptr: sizes only)
+        *p = h->slab ? (T*)(h->slab + h->slab_off) : nullptr;
+        h->slab_off += (bytes + 255) & ~(size_t)255;
+        return RVIO_OK;
+    }
     HIPCHK(h, hipMalloc(&q, bytes));
     HIPCHK(h, hipMemsetAsync(q, 0, bytes, h->stream));
     h->allocs.push_back(q);
     *p = (T*)q;
     return RVIO_OK;
 }
+// a batch handle (rvio_hip_create_batch) carries the filter only
+#define FRONT_END_ONLY(h)                                                                                              \
+    do {                                                                                                               \
+        if ((h)->batch > 1) { (h)->err = "not available on a batch handle (filter only)"; return RVIO_ERR_UNSUPPORTED; } \
+    } while (0)
 #define DALLOC(h, p, n)                               \
     do {                                              \
         int rc_ = dalloc((h), &(p), (n));             \
@@ -166,15 +184,40 @@ static void fill_devcfg(const rvio_config* c, DevCfg* d) {
     d->levels = lv;
 }
 
-int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
+// The per-instance filter buffers (state, update scratch, Tracker -> Updater hand-over, IMU staging): called twice — sizes, then pointers
+static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
+    const DevCfg& d = h->dc;
+    const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
+    TrackerDev& t = h->t;
+    DALLOC(h, h->meta, 1);
+    for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
+    DALLOC(h, h->Hstack, (size_t)d.Fu * d.rho_max * ldh);
+    DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
+    DALLOC(h, h->block, ldh * ldh);
+    DALLOC(h, h->Ab, ldh * ldh);
+    DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
+    DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
+    DALLOC(h, h->Pt1, PP);
+    DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
+    DALLOC(h, h->nrows, d.Fu); DALLOC(h, h->acc, d.Fu); DALLOC(h, h->ndof, d.Fu);
+    DALLOC(h, h->d_imu, RVIO_MAX_IMU);
+    DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
+    DALLOC(h, t.n_feat, 1); DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
+    if (need_tm_global) DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
+    if (need_Mg) DALLOC(h, h->Mg, ldh * 2 * ldh);
+    return RVIO_OK;
+}
+
+static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip** out) {
     if (!cfg || !out) return RVIO_ERR_INVALID;
     *out = nullptr;
     if (cfg->fisheye) return RVIO_ERR_UNSUPPORTED;
     if (cfg->max_track_len < 3 || cfg->max_track_len > RVIO_MAX_LEN || cfg->n_features < 2 || cfg->min_track_len < 2) return RVIO_ERR_INVALID;
+    if (batch < 1) return RVIO_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) return RVIO_ERR_NO_DEVICE;
     rvio_hip* h = new rvio_hip();
-    h->cfg = *cfg; h->device = device;
+    h->cfg = *cfg; h->device = device; h->batch = batch;
     fill_devcfg(cfg, &h->dc);
     const DevCfg& d = h->dc;
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
@@ -188,85 +231,87 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], hipEventDisableTiming));
     }
-    const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
-    DALLOC(h, h->meta, 1);
-    for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
-    DALLOC(h, h->Hstack, (size_t)d.Fu * d.rho_max * ldh);
+    const size_t ldh = d.ldh;
+    // launch geometry (decides two optional slab members)
     h->n_groups = (d.Fu + GRAM2_FG - 1) / GRAM2_FG;
-    DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
-    DALLOC(h, h->block, ldh * ldh);
-    DALLOC(h, h->Ab, ldh * ldh);
-    DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
-    DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
-    DALLOC(h, h->Pt1, PP);
-    DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
-    DALLOC(h, h->nrows, d.Fu); DALLOC(h, h->acc, d.Fu); DALLOC(h, h->ndof, d.Fu);
-    DALLOC(h, h->d_imu, RVIO_MAX_IMU);
-    DALLOC(h, h->d_cand, (size_t)2 * d.F);
-    DALLOC(h, h->d_img, (size_t)d.W * d.H);
-    if (cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
-        h->cl_tx = 5; h->cl_ty = 5;
-        int ew = d.W, eh = d.H;
-        if (d.W % h->cl_tx != 0 || d.H % h->cl_ty != 0) { ew = d.W + (h->cl_tx - d.W % h->cl_tx); eh = d.H + (h->cl_ty - d.H % h->cl_ty); }
-        h->cl_tw = ew / h->cl_tx; h->cl_th = eh / h->cl_ty;
-        const int area = h->cl_tw * h->cl_th;
-        h->cl_clip = std::max((int)(3.0 * area / 256), 1);
-        h->cl_scale = 255.0f / (float)area;
-        DALLOC(h, h->d_eq, (size_t)d.W * d.H);
-        DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
-    }
-    DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
-    DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
-    DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
-    // tracker
-    TrackerDev& t = h->t;
-    DALLOC(h, t.first, 1); DALLOC(h, t.n_pts, 1); DALLOC(h, t.n_feat, 1);
-    DALLOC(h, t.feats, (size_t)2 * d.F); DALLOC(h, t.un1, (size_t)2 * d.F); DALLOC(h, t.slot, d.F);
-    DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
-    DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
-    DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
-    DALLOC(h, t.cand_acc, d.F);
-    DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
-    DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
-    t.info = h->d_info;
-    h->tout[0] = {t.n_feat, t.types, t.len, t.meas};   // Tracker -> Updater hand-over, double-buffered for the pipelined path
-    DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
-    DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
-    { int one = 1; HIPCHK(h, hipMemcpyAsync(t.first, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); }
-    for (int b = 0; b < 2; ++b) {
-        int w = d.W, hg = d.H;
-        for (int l = 0; l < 4; ++l) {
-            uint8_t* im = nullptr; short* dx = nullptr;
-            if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
-            h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
-            w = (w + 1) / 2; hg = (hg + 1) / 2;
-        }
-    }
-    // launch geometry
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
     if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
+    bool need_tm_global = false;
     if (h->feat_lds > 150 * 1024) {
         h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, false) * sizeof(double);
-        DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
+        need_tm_global = true;
     }
     if (h->feat_lds > 160 * 1024) { h->err = "per-feature LDS footprint exceeds 160 KiB"; return RVIO_ERR_UNSUPPORTED; }
+    const size_t c6m = ldh - 1, NC = c6m + 1, ldm = NC | 1;
+    h->solve_lds = c6m * ldm * sizeof(double) + 1024;   // + slack: tail lanes of the last row read (never write) past the row
+    h->solve_use_lds = h->solve_lds <= 140 * 1024;
+    h->solve_nch = (NC <= 64) ? 1 : (NC <= 128 ? 2 : 3);
+    if (!h->solve_use_lds) h->solve_lds = 0;
+    // filter slab(s)
+    h->slab_mode = true; h->slab = nullptr; h->slab_off = 0;
+    { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    h->slab_bytes = h->slab_off;
+    {
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, h->slab_bytes * (size_t)batch));
+        HIPCHK(h, hipMemsetAsync(q, 0, h->slab_bytes * (size_t)batch, h->stream));
+        h->allocs.push_back(q);
+        h->slab = (char*)q; h->slab_off = 0;
+    }
+    { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    h->slab_mode = false;
+    h->bin = {0, h->slab_bytes, h->slab_bytes, h->slab_bytes, h->slab_bytes};
+    TrackerDev& t = h->t;
+    t.info = h->d_info;
+    h->tout[0] = {t.n_feat, t.types, t.len, t.meas};   // Tracker -> Updater hand-over, double-buffered for the pipelined path
+    if (batch == 1) {   // front end: a batch handle is filter-only (its callers hand the tracks over, rvio_hip_frame_tracks_dev)
+        DALLOC(h, h->d_cand, (size_t)2 * d.F);
+        DALLOC(h, h->d_img, (size_t)d.W * d.H);
+        if (cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
+            h->cl_tx = 5; h->cl_ty = 5;
+            int ew = d.W, eh = d.H;
+            if (d.W % h->cl_tx != 0 || d.H % h->cl_ty != 0) { ew = d.W + (h->cl_tx - d.W % h->cl_tx); eh = d.H + (h->cl_ty - d.H % h->cl_ty); }
+            h->cl_tw = ew / h->cl_tx; h->cl_th = eh / h->cl_ty;
+            const int area = h->cl_tw * h->cl_th;
+            h->cl_clip = std::max((int)(3.0 * area / 256), 1);
+            h->cl_scale = 255.0f / (float)area;
+            DALLOC(h, h->d_eq, (size_t)d.W * d.H);
+            DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
+        }
+        DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
+        DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
+        DALLOC(h, t.first, 1); DALLOC(h, t.n_pts, 1);
+        DALLOC(h, t.feats, (size_t)2 * d.F); DALLOC(h, t.un1, (size_t)2 * d.F); DALLOC(h, t.slot, d.F);
+        DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
+        DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
+        DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
+        DALLOC(h, t.cand_acc, d.F);
+        DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
+        DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
+        DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
+        { int one = 1; HIPCHK(h, hipMemcpyAsync(t.first, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); }
+        for (int b = 0; b < 2; ++b) {
+            int w = d.W, hg = d.H;
+            for (int l = 0; l < 4; ++l) {
+                uint8_t* im = nullptr; short* dx = nullptr;
+                if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
+                h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
+                w = (w + 1) / 2; hg = (hg + 1) / 2;
+            }
+        }
+    }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)((size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double))));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
-        const size_t c6m = ldh - 1, NC = c6m + 1, ldm = NC | 1;
-        h->solve_lds = c6m * ldm * sizeof(double) + 1024;   // + slack: tail lanes of the last row read (never write) past the row
-        h->solve_use_lds = h->solve_lds <= 140 * 1024;
-        h->solve_nch = (NC <= 64) ? 1 : (NC <= 128 ? 2 : 3);
         if (h->solve_use_lds) {
             HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
             HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
             HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
         }
-        else { h->solve_lds = 0; DALLOC(h, h->Mg, ldh * 2 * ldh); }
         {   // fully unrolled solve kernel: variants <column chunks, rows per wave> for c6 <= 126
             int rpw = 0, nch = 0, nw = 8;
             if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 8; }
@@ -289,9 +334,15 @@ int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) {
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
     }
+    if (batch > 1 && !h->solve5_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
+
+int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) { return create_impl(cfg, device, 1, out); }
+// B independent filter instances behind one handle: every filter stage is ONE launch with gridDim.z = B
+int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, rvio_hip** out) { return create_impl(cfg, device, n_instances, out); }
+int rvio_hip_batch_size(const rvio_hip* h) { return h ? h->batch : 0; }
 
 void rvio_hip_destroy(rvio_hip* h) {
     if (!h) return;
@@ -319,38 +370,47 @@ int rvio_hip_sync(rvio_hip* h) {
 }
 
 // ------------------------------------------------------------------ state
-int rvio_hip_set_state(rvio_hip* h, const double* x, int xdim, const double* P, int d) {
+static int set_state_range(rvio_hip* h, int lo, int hi, const double* x, int xdim, const double* P, int d) {
     if (!h || !x || !P) return RVIO_ERR_INVALID;
     const int n = (xdim - 26) / 7;
     if (xdim != 26 + 7 * n || d != 24 + 6 * n || n < 0 || n > h->dc.nmax) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemsetAsync(h->P[h->cur], 0, sizeof(double) * h->dc.dmax * h->dc.dmax, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->x[h->cur], x, sizeof(double) * xdim, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->P[h->cur], sizeof(double) * h->dc.dmax, P, sizeof(double) * d, sizeof(double) * d, d,
-                               hipMemcpyHostToDevice, h->stream));
     FilterMeta m; std::memset(&m, 0, sizeof m);
     m.n_clones = n; m.img_count = h->img_count;
-    HIPCHK(h, hipMemcpyAsync(h->meta, &m, sizeof m, hipMemcpyHostToDevice, h->stream));
+    for (int i = lo; i < hi; ++i) {
+        const size_t o = (size_t)i * h->slab_bytes;
+        double* Pi = (double*)((char*)h->P[h->cur] + o);
+        HIPCHK(h, hipMemsetAsync(Pi, 0, sizeof(double) * h->dc.dmax * h->dc.dmax, h->stream));
+        HIPCHK(h, hipMemcpyAsync((char*)h->x[h->cur] + o, x, sizeof(double) * xdim, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(Pi, sizeof(double) * h->dc.dmax, P, sizeof(double) * d, sizeof(double) * d, d, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync((char*)h->meta + o, &m, sizeof m, hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_clones_host = n;
     return RVIO_OK;
 }
+// (a batch handle: every instance receives the same state)
+int rvio_hip_set_state(rvio_hip* h, const double* x, int xdim, const double* P, int d) { return h ? set_state_range(h, 0, h->batch, x, xdim, P, d) : RVIO_ERR_INVALID; }
+// one instance of a batch handle; the window length is common to all instances (it depends on the frame count only)
+int rvio_hip_set_state_at(rvio_hip* h, int instance, const double* x, int xdim, const double* P, int d) {
+    if (!h || instance < 0 || instance >= h->batch || xdim != 26 + 7 * h->n_clones_host) return RVIO_ERR_INVALID;
+    return set_state_range(h, instance, instance + 1, x, xdim, P, d);
+}
 
-int rvio_hip_get_state(rvio_hip* h, double* x, int* xdim, double* P, int* d) {
-    if (!h) return RVIO_ERR_INVALID;
+int rvio_hip_get_state_at(rvio_hip* h, int instance, double* x, int* xdim, double* P, int* d) {
+    if (!h || instance < 0 || instance >= h->batch) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    FilterMeta m;
-    HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t o = (size_t)instance * h->slab_bytes;
     const int n = h->n_clones_host, dd = 24 + 6 * n, xd = 26 + 7 * n;
     if (xdim) *xdim = xd;
     if (d) *d = dd;
-    if (x) HIPCHK(h, hipMemcpyAsync(x, h->x[h->cur], sizeof(double) * xd, hipMemcpyDeviceToHost, h->stream));
-    if (P) HIPCHK(h, hipMemcpy2DAsync(P, sizeof(double) * dd, h->P[h->cur], sizeof(double) * h->dc.dmax, sizeof(double) * dd, dd,
+    if (x) HIPCHK(h, hipMemcpyAsync(x, (char*)h->x[h->cur] + o, sizeof(double) * xd, hipMemcpyDeviceToHost, h->stream));
+    if (P) HIPCHK(h, hipMemcpy2DAsync(P, sizeof(double) * dd, (char*)h->P[h->cur] + o, sizeof(double) * h->dc.dmax, sizeof(double) * dd, dd,
                                       hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
+int rvio_hip_get_state(rvio_hip* h, double* x, int* xdim, double* P, int* d) { return rvio_hip_get_state_at(h, 0, x, xdim, P, d); }
 
 // System::initialize (System.cc:115-170): runs once, on the host; result uploaded.
 int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n_imu) {
@@ -394,8 +454,9 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 }
 
 // ------------------------------------------------------------------ P1
-static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
-    hipLaunchKernelGGL(propagate_kernel3, dim3(1), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m);
+static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0) {   // imu_bs = 0: every instance integrates the same samples
+    hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
+                       h->slab_bytes, imu_bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -430,13 +491,15 @@ static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
 static int update_local_dev(rvio_hip* h, int rank, int world) {
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host;
-    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+    const size_t bs = h->slab_bytes;
+    const int B = h->batch;
+    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global);
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(h->n_groups, (6 * n + 15) / 16), dim3(256), (size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double), h->stream,
-                       d, n, h->Hstack, h->nrows, h->partial);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256))), dim3(256), 0, h->stream, d, n,
-                       h->partial, h->n_groups, h->nrows, h->block);
+                       h->tm_global, bs, h->bin);
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(h->n_groups, (6 * n + 15) / 16, B), dim3(256), (size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double), h->stream,
+                       d, n, h->Hstack, h->nrows, h->partial, bs);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), 0, h->stream, d, n,
+                       h->partial, h->n_groups, h->nrows, h->block, bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -445,15 +508,15 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     if (h->solve5_variant == 1)
-        hipLaunchKernelGGL((solve6_kernel<1, 8, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<1, 8, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 2)
-        hipLaunchKernelGGL((solve6_kernel<2, 12, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<2, 12, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 3)
-        hipLaunchKernelGGL((solve6_kernel<2, 16, 8>), dim3(1), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<2, 16, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 5)
-        hipLaunchKernelGGL((solve6_kernel<1, 4, 16>), dim3(1), dim3(1024), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<1, 4, 16>), dim3(1, 1, h->batch), dim3(1024), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 4)
-        hipLaunchKernelGGL((solve6_kernel<1, 16, 4>), dim3(1), dim3(256), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
+        hipLaunchKernelGGL((solve6_kernel<1, 16, 4>), dim3(1, 1, h->batch), dim3(256), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (!h->solve_use_lds)
         hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->Mg);
     else if (h->solve_nch == 1)
@@ -471,6 +534,9 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     double* Pc = h->P[h->cur];
     double* Pn = h->P[h->cur ^ 1];
     const double* Ab = d_blocks;
+    const size_t bs = h->slab_bytes;
+    const int B = h->batch;
+    if (B > 1 && (world > 1 || d_blocks != h->block)) { h->err = "a batch handle runs the unsharded updater only"; return RVIO_ERR_UNSUPPORTED; }
     if (world > 1) {   // sum the gathered [A|b] blocks in rank order
         const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
         hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, n, d_blocks, world, (size_t)(ldh * ldh), h->Ab);
@@ -480,12 +546,12 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
-    hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf);
+    hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     launch_solve(h, n, Ab);
     // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
-    hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+    hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn);
+    hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
     HIPCHK(h, hipGetLastError());
     h->cur ^= 1;
     return RVIO_OK;
@@ -500,6 +566,7 @@ int rvio_hip_update_tracked(rvio_hip* h) {
 }
 int rvio_hip_update(rvio_hip* h, const rvio_tracks* tracks) {
     if (!h) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = upload_tracks(h, tracks);
     if (rc != RVIO_OK) return rc;
@@ -543,7 +610,8 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const DevCfg& d = h->dc;
     const int c = h->cur, o = c ^ 1;
     const int cg = 1 + std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256));
-    hipLaunchKernelGGL(augcomp_kernel2, dim3(cg), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose);
+    hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
+                       h->slab_bytes);
     HIPCHK(h, hipGetLastError());
     h->cur = o;
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
@@ -653,6 +721,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
 
 int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped && h->ts == h->stream) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     int rc;
@@ -670,6 +739,7 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
 
 int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
     if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = std::min(n_cand, h->dc.F);
     HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream));
@@ -682,6 +752,7 @@ int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
 int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
     if (!h || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = std::min(n_cand, h->dc.F);
     if (n_pts > 0) {
@@ -697,6 +768,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
 
 int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int32_t* len, float* meas) {
     if (!h) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const DevCfg& d = h->dc;
@@ -715,6 +787,7 @@ int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int3
 
 int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len) {
     if (!h) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const DevCfg& d = h->dc;
@@ -762,6 +835,32 @@ static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m, bool propag
     }
     return augment_compose_dev(h, h->img_count > 1);      // System.cc:280
 }
+// The body of System::MonoVIO after Tracker::track (System.cc:263-365) on device-resident hand-over tables, for every instance
+// of the handle in ONE launch per stage: d_n_feat[B], d_types[B][Fu], d_len[B][Fu], d_meas[B][Fu][max_track_len][2] (the layout
+// of rvio_tracks with max_len = max_track_len), d_imu[B][imu_stride] (imu_stride = 0: one IMU batch shared by all instances).
+int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride, int m, const int32_t* d_n_feat, const unsigned char* d_types,
+                              const int32_t* d_len, const float* d_meas) {
+    if (!h || (!d_imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || imu_stride < 0 || (imu_stride > 0 && imu_stride < m)) return RVIO_ERR_INVALID;
+    if (!d_n_feat || !d_types || !d_len || !d_meas) return RVIO_ERR_INVALID;
+    if (h->piped || h->in_frame) { h->err = "rvio_hip_frame_tracks_dev on a handle that runs the pipelined image path"; return RVIO_ERR_INVALID; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const DevCfg& d = h->dc;
+    h->img_count++;
+    int rc = propagate_dev(h, d_imu, m, (size_t)imu_stride * sizeof(rvio_imu));
+    if (rc != RVIO_OK) return rc;
+    if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
+        const TrackerDev t0 = h->t;
+        const BatchIn b0 = h->bin;
+        h->t.n_feat = const_cast<int*>(d_n_feat); h->t.types = const_cast<unsigned char*>(d_types);
+        h->t.len = const_cast<int*>(d_len); h->t.meas = const_cast<float*>(d_meas);
+        h->bin = {0, sizeof(int32_t), (size_t)d.Fu, sizeof(int32_t) * (size_t)d.Fu, sizeof(float) * 2 * (size_t)d.Fu * d.max_len};
+        rc = rvio_hip_update_tracked(h);
+        h->t = t0; h->bin = b0;
+        if (rc != RVIO_OK) return rc;
+    }
+    return augment_compose_dev(h, h->img_count > 1);      // System.cc:280
+}
+
 // Pipelined: the tracker (pyramid, KLT, RANSAC, book-keeping) never reads the filter state, so frame k's front end runs
 // on its own stream while frame k-1's propagate/update/augment still occupy the filter stream.  The Tracker -> Updater
 // hand-over is double-buffered; two events per buffer order (a) update(k) after track(k), (b) track(k+2) after update(k).
@@ -805,6 +904,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
 }
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     if (!h || !d_img) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false);
 }
@@ -815,6 +915,7 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
 //   frame_end         closes the frame (hand-over buffer released for frame k+2)
 int rvio_hip_frame_begin_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     if (!h || !d_img) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false, /*begin_only=*/true);
 }
@@ -831,6 +932,7 @@ int rvio_hip_frame_end(rvio_hip* h) {
 // the previous frame's filter work like the tracker kernels do.
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
     if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int nc = cand_xy ? std::min(n_cand, h->dc.F) : 0;   // cand_xy == NULL: device detector
     if (!h->hb_img[0])
@@ -888,6 +990,7 @@ extern "C" {
 // before cornerSubPix, and the min-eigenvalue map (each pointer may be NULL)
 int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, float* eig) {
     if (!h) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     if (!h->det_ready) { h->err = "the device detector has not run (pass a NULL corner list to track/frame)"; return RVIO_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream_d));
@@ -902,6 +1005,7 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
 // pyramid level `level` of the most recent image: u8 image (w*h) and int16 (dx,dy) derivative (w*h*2)
 int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uint8_t* img, int16_t* dxy) {
     if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     const PyrDev& p = h->pyr[h->pyr_cur];
@@ -916,6 +1020,7 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
 // raw vFeatsTracked of the last track() call (n entries = mnFeatsToTrack that entered the call)
 int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     if (!h || n < 0 || n > h->dc.F) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
@@ -940,11 +1045,13 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         if (which == 0) {
             launch_solve(h, n, h->block);
         } else if (which == 1) {
+            if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status);
         } else {
-            hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global);
+            hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
+                               h->slab_bytes, h->bin);
         }
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));

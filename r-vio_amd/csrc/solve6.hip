@@ -28,7 +28,8 @@ __device__ __forceinline__ unsigned umax32(unsigned a, unsigned b) { return a > 
 template <int NCH, int RPW, int NW>
 __global__ __launch_bounds__(64 * NW) void solve6_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Tg,
                                                          const double* __restrict__ Ab, const double* __restrict__ x, const double* __restrict__ P,
-                                                         double* __restrict__ Wout, double* __restrict__ x_out) {
+                                                         double* __restrict__ Wout, double* __restrict__ x_out, size_t bs) {
+    meta = zoff(meta, bs); Tg = zoff(Tg, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
     static_assert(NW == 4 || NW == 8 || NW == 16, "wave count");
     static_assert(RPW <= 16, "the per-wave pivot search reduces one DPP row");
     extern __shared__ __align__(16) double M[];

@@ -22,6 +22,7 @@ SYMBOLS = [
     "rvio_hip_update_local", "rvio_hip_update_global", "rvio_hip_get_update_diag",
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
+    "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
 ]
 
 _LIB = None
@@ -57,11 +58,16 @@ def _p(a, t):
 class RvioHip:
     """One filter instance on one GPU (mirrors the System-owned stage objects, System.h:89-92)."""
 
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=0, batch=None):
+        """batch=B: B independent filter instances behind one handle (rvio_hip_create_batch; filter only)"""
         self.L = load()
         self.cfg = cfg
         self.h = C.c_void_p()
-        rc = self.L.rvio_hip_create(C.byref(cfg), int(device), C.byref(self.h))
+        self.batch = 1 if batch is None else int(batch)
+        if batch is None:
+            rc = self.L.rvio_hip_create(C.byref(cfg), int(device), C.byref(self.h))
+        else:
+            rc = self.L.rvio_hip_create_batch(C.byref(cfg), int(device), int(batch), C.byref(self.h))
         if rc != 0:
             msg = self.L.rvio_hip_last_error(self.h).decode() if self.h else ""
             if self.h:
@@ -104,6 +110,23 @@ class RvioHip:
         xd, d = C.c_int(0), C.c_int(0)
         self._ck(self.L.rvio_hip_get_state(self.h, _p(xb, dp), C.byref(xd), _p(Pb, dp), C.byref(d)), "get_state")
         return xb[: xd.value].copy(), Pb[: d.value ** 2].reshape(d.value, d.value, order="F").copy()
+
+    def set_state_at(self, i, x, P):
+        x = np.ascontiguousarray(x, float)
+        Pf = np.asfortranarray(P, dtype=float)
+        self._ck(self.L.rvio_hip_set_state_at(self.h, int(i), _p(x, dp), len(x), Pf.ctypes.data_as(dp), P.shape[0]), "set_state_at")
+
+    def get_state_at(self, i):
+        xb = np.zeros(26 + 7 * (self.nmax + 1))
+        Pb = np.zeros((24 + 6 * (self.nmax + 1)) ** 2)
+        xd, d = C.c_int(0), C.c_int(0)
+        self._ck(self.L.rvio_hip_get_state_at(self.h, int(i), _p(xb, dp), C.byref(xd), _p(Pb, dp), C.byref(d)), "get_state_at")
+        return xb[: xd.value].copy(), Pb[: d.value ** 2].reshape(d.value, d.value, order="F").copy()
+
+    def frame_tracks_dev(self, d_imu_ptr, imu_stride, m, d_n_feat_ptr, d_types_ptr, d_len_ptr, d_meas_ptr):
+        """MonoVIO body after the tracker on device-resident hand-over tables, all instances in one launch per stage"""
+        self._ck(self.L.rvio_hip_frame_tracks_dev(self.h, C.c_void_p(d_imu_ptr), int(imu_stride), int(m), C.c_void_p(d_n_feat_ptr),
+                                                  C.c_void_p(d_types_ptr), C.c_void_p(d_len_ptr), C.c_void_p(d_meas_ptr)), "frame_tracks_dev")
 
     def initialize(self, w, a, n_imu):
         w = np.ascontiguousarray(w, float)

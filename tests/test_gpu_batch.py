@@ -1,0 +1,101 @@
+"""Batched filter (rvio_hip_create_batch / rvio_hip_frame_tracks_dev): B instances advanced by one launch
+per stage must equal, BIT FOR BIT, B plain handles fed the same inputs through the per-stage calls — and therefore the oracle
+within the filter tolerance."""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+
+def pack_inputs(cfg, recs_f):
+    """one frame of B instances -> the device layout of rvio_hip_frame_tracks_dev"""
+    B, Fu, ML = len(recs_f), abi.fu(cfg), cfg.max_track_len
+    n_feat = np.zeros(B, np.int32)
+    types = np.zeros((B, Fu), np.uint8)
+    lens = np.zeros((B, Fu), np.int32)
+    meas = np.zeros((B, Fu, ML, 2), np.float32)
+    m = len(recs_f[0]["inp"]["imu"])
+    imu = np.zeros((B, m), dtype=recs_f[0]["inp"]["imu"].dtype)
+    for i, r in enumerate(recs_f):
+        n = len(r["lens"])
+        n_feat[i] = n
+        types[i, :n], lens[i, :n], meas[i, :n] = r["types"], r["lens"], r["meas"]
+        assert len(r["inp"]["imu"]) == m
+        imu[i] = r["inp"]["imu"]
+    return n_feat, types, lens, meas, imu, m
+
+
+@pytest.fixture(scope="module")
+def recs3():
+    cfg = abi.config_named("B", enable_equalizer=0)
+    return cfg, [S.record_sequence(cfg, n_frames=26, seed=s)[1] for s in (0, 1, 2)]
+
+
+@pytest.mark.parametrize("shared_imu", [False, True])
+def test_batch_equals_plain_handles_bit_for_bit(gpu_required, recs3, shared_imu):
+    from rvio_amd import hip
+    import torch
+    cfg, recs = recs3
+    B = len(recs)
+    hb = hip.RvioHip(cfg, batch=B)
+    hs = [hip.RvioHip(cfg) for _ in range(B)]
+    hb.set_state(recs[0][0]["x0"], recs[0][0]["P0"])
+    for i in range(B):
+        hb.set_state_at(i, recs[i][0]["x0"], recs[i][0]["P0"])
+        hs[i].set_state(recs[i][0]["x0"], recs[i][0]["P0"])
+    n_upd = 0
+    for f in range(len(recs[0])):
+        rf = [recs[i][f] for i in range(B)]
+        n_feat, types, lens, meas, imu, m = pack_inputs(cfg, rf)
+        if shared_imu:
+            imu[:] = imu[0]
+        d = [torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda() for a in (imu, n_feat, types, lens, meas)]
+        torch.cuda.synchronize()
+        hb.frame_tracks_dev(d[0].data_ptr(), 0 if shared_imu else m, m, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr())
+        for i in range(B):
+            do_update, do_augment = hs[i].frame_plan()
+            hs[i].propagate(imu[i])
+            if do_update:
+                hs[i].update(rf[i]["types"], rf[i]["lens"], rf[i]["meas"])
+                n_upd += 1
+            hs[i].augment_compose(do_augment)
+        hb.sync()
+        for i in range(B):
+            xa, Pa = hb.get_state_at(i)
+            xb, Pb = hs[i].get_state()
+            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), (f, i)
+            if not shared_imu:      # the recorded oracle states belong to the recorded IMU
+                assert S.state_delta(xa, rf[i]["x3"]) <= 1e-9, (f, i)
+    assert n_upd > 20
+    xa, _ = hb.get_state()
+    assert np.array_equal(xa, hb.get_state_at(0)[0])
+    hb.close()
+    for h in hs:
+        h.close()
+
+
+def test_frame_tracks_dev_on_a_plain_handle_and_front_end_refused_on_a_batch(gpu_required, recs3):
+    from rvio_amd import hip
+    import torch
+    cfg, recs = recs3
+    h1, h2 = hip.RvioHip(cfg), hip.RvioHip(cfg, batch=2)
+    h1.set_state(recs[1][0]["x0"], recs[1][0]["P0"])
+    for f in range(12):
+        r = recs[1][f]
+        n_feat, types, lens, meas, imu, m = pack_inputs(cfg, [r])
+        d = [torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda() for a in (imu, n_feat, types, lens, meas)]
+        torch.cuda.synchronize()
+        h1.frame_tracks_dev(d[0].data_ptr(), 0, m, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr())
+        h1.sync()
+        assert S.state_delta(h1.get_state()[0], r["x3"]) <= 1e-9, f
+    with pytest.raises(hip.RvioHipError):
+        h2.track(np.zeros((cfg.height, cfg.width), np.uint8), recs[0][0]["inp"]["imu"])
+    with pytest.raises(hip.RvioHipError):
+        h2.update(recs[0][5]["types"], recs[0][5]["lens"], recs[0][5]["meas"])
+    assert h2.L.rvio_hip_batch_size(h2.h) == 2 and h1.L.rvio_hip_batch_size(h1.h) == 1
+    h1.close()
+    h2.close()
