@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded-updater frame path (RCCL all-gather) even with one rank")
     ap.add_argument("--host-corners", action="store_true",
                     help="feed a caller-side corner list (projected landmarks) instead of running the device detector")
+    ap.add_argument("--batch", default="1,16,256,2048", help="instance counts of the batched-filter leg (SURVEY.md 8d (ii)); '' skips it")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     ap.add_argument("--stream-threads", type=int, default=1, help="host threads issuing the launches of the aggregate-throughput leg")
     args = ap.parse_args()
@@ -215,6 +216,8 @@ def main():
             out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
                                                wi, ai, ni, n_frames, 1 + W, streams=args.streams, threads=args.stream_threads)
             out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
+        if args.batch:
+            out["batched_filter"] = batched_filter_leg(cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
             out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
             if xs_cpu is not None and "x_at_cpu_frames" in out:
@@ -383,6 +386,100 @@ def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni,
     return {"value": (n - n_warm) / el, "unit": "frames/s",
             "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + (0 if cand_arr is None else cand_arr[0].nbytes)),
             "note": "pageable host memory, hipMemcpyAsync on the tracker stream"}
+
+
+def filter_flops(cfg, n, lens, types, m):
+    """W_filter of SURVEY.md 8d for one frame: the reference's FP64 work (gate, nullspace, Givens compression, EKF, propagate) for
+    the tracks actually handed over (rho_f = 2 L_f - 3 rows per feature, type '2' contributes its first ceil(L/2) observations)"""
+    c6, d = 6 * n, 24 + 6 * n
+    w = m * 6.0 * 24 ** 3
+    if n <= cfg.min_track_len - 1:
+        return w
+    M = 0
+    for L, t in zip(lens, types):
+        Le = (int(L) + 1) // 2 if t == ord("2") else int(L)
+        rho = max(2 * Le - 3, 0)
+        M += rho
+        w += 2.0 * rho * c6 ** 2 + 2.0 * rho ** 2 * c6 + (4.0 / 3.0) * rho ** 3
+    r = min(M, c6)
+    w += 3.0 * M * c6 ** 2
+    w += 2.0 * r * d * d + 2.0 * r * r * d + 2.0 * d * d * r + 2.0 * r ** 3 + 2.0 * d * r * r + 2.0 * d * d * r + 4.0 * d ** 3 + 2.0 * d * d * r
+    return w
+
+
+def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=40):
+    """B independent filter instances advanced by ONE launch per stage (rvio_hip_create_batch).  The hand-over
+    tables come from `seeds` direct-track sequences (different landmark/noise seeds) run through plain handles first; instance b
+    replays sequence b mod seeds.  Reports filter-frames/s and the FP64 rate against W_filter of the tracks actually processed."""
+    from rvio_amd import hip
+    Fu, ML = abi.fu(cfg), cfg.max_track_len
+    nf = n_warm + n_timed
+    k0 = K0
+    tabs, inits, flops = [], [], np.zeros(nf)
+    for sd in range(seeds):
+        seq = rv.synth.SynthSequence(cfg, duration=(k0 + nf + 3) / 20.0 + 1.0, seed=sd)
+        wi, ai, ni = seq.init_from_static(k0)
+        h = hip.RvioHip(cfg)
+        h.initialize(wi, ai, ni)
+        inits.append(h.get_state())
+        drv = rv.synth.DirectTrackDriver(seq)
+        n_feat = np.zeros(nf, np.int32)
+        types = np.zeros((nf, Fu), np.uint8)
+        lens = np.zeros((nf, Fu), np.int32)
+        meas = np.zeros((nf, Fu, ML, 2), np.float32)
+        imus = []
+        for f in range(nf):
+            inp = drv.inputs(k0 + 1 + f)
+            ncl = min(max(f - 1, 0), ML - 1)           # window length when this frame's update runs (first augmentation: 2nd frame)
+            h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+            t, l, me = h.get_tracks()
+            drv.after(h.get_points()[0])
+            n_feat[f] = len(l)
+            types[f, : len(l)], lens[f, : len(l)], meas[f, : len(l)] = t, l, me
+            imus.append(inp["imu"])
+            flops[f] += filter_flops(cfg, ncl, l, t, len(inp["imu"])) / seeds
+        h.close()
+        m = min(len(i) for i in imus)
+        tabs.append((n_feat, types, lens, meas, np.stack([i[:m] for i in imus]), m))
+    m = min(t[5] for t in tabs)
+    w_frame = float(np.mean(flops[n_warm:]))
+    PEAK_F64 = 78.6
+    res = []
+    for B in sizes:
+        idx = np.arange(B) % seeds
+        # [frame][instance] tables, resident in HBM before the timed region
+        d_nf = torch.from_numpy(np.stack([tabs[i][0] for i in idx], 1).copy()).cuda()
+        d_ty = torch.from_numpy(np.stack([tabs[i][1] for i in idx], 1).copy()).cuda()
+        d_ln = torch.from_numpy(np.stack([tabs[i][2] for i in idx], 1).copy()).cuda()
+        d_me = torch.from_numpy(np.stack([tabs[i][3] for i in idx], 1).copy()).cuda()
+        imu_h = np.stack([tabs[i][4][:, :m] for i in idx], 1).copy()            # [frame][instance][m]
+        d_im = torch.from_numpy(imu_h.view(np.uint8).reshape(nf, B, -1)).cuda()
+        h = hip.RvioHip(cfg, batch=B)
+        h.set_state(*inits[0])
+        for b in range(B):
+            if idx[b] != 0:
+                h.set_state_at(b, *inits[idx[b]])
+        torch.cuda.synchronize()
+
+        def frame(f):
+            h.frame_tracks_dev(d_im[f].data_ptr(), m, m, d_nf[f].data_ptr(), d_ty[f].data_ptr(), d_ln[f].data_ptr(), d_me[f].data_ptr())
+        for f in range(n_warm):
+            frame(f)
+        h.sync()
+        t0 = time.perf_counter()
+        for f in range(n_warm, nf):
+            frame(f)
+        h.sync()
+        el = time.perf_counter() - t0
+        x_last = h.get_state_at(B - 1)[0]
+        h.close()
+        del d_nf, d_ty, d_ln, d_me, d_im
+        tfl = w_frame * B * n_timed / el / 1e12
+        res.append({"instances": B, "ms_per_batched_frame": 1e3 * el / n_timed, "filter_frames_per_s": B * n_timed / el,
+                    "achieved_tflops_fp64": tfl, "frac_fp64_peak": tfl / PEAK_F64, "finite": bool(np.all(np.isfinite(x_last)))})
+    return {"workload": "cfg%s filter only (propagate + update + augment/compose), direct-track hand-over tables of %d seeded sequences, "
+                        "%d frames timed after %d, one launch per stage for all instances" % (name, seeds, n_timed, n_warm),
+            "algorithmic_mflop_per_filter_frame": w_frame / 1e6, "peak_tflops_fp64": PEAK_F64, "sizes": res}
 
 
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):

@@ -67,6 +67,10 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
     double* S = p;
     // ---- one batch of global reads: feature header, its observations, the clone poses
     const int n_feat = *n_feat_ptr;
+    if (f >= n_feat || (f % shard_world) != shard_rank) {   // empty slot / another rank's feature: leave before touching anything else
+        if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
+        return;
+    }
     const unsigned char type = types[f];
     const int L = lens[f];
     const float* mz = meas + (size_t)f * cfg.max_len * 2;
@@ -74,10 +78,6 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
     const int lane = tid & 63;
     if (lane < ML) { mxv = mz[2 * lane]; myv = mz[2 * lane + 1]; }
     for (int e = tid; e < 7 * n; e += T) xcl[e] = x[26 + e];
-    if (f >= n_feat || (f % shard_world) != shard_rank) {
-        if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
-        return;
-    }
     const bool wave0 = tid < 64;
     const int nPh = L - 1;
     const double sig = cfg.sigma_im, sig2 = sig * sig;
@@ -463,16 +463,29 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
 // =============================================================== U7 compression, information form (reduction stage)
 // partial[g][p][q] = sum over the rows of feature group g of H[row][p] * H[row][q], q = 0..c6 (column c6 is the residual -> b),
 // is produced by gram_mfma_kernel (filter_kernels2.hip); the kernels below reduce it.
+// feature groups of the Gram stage (gram_mfma_kernel in filter_kernels2.hip): GRAM2_FG consecutive feature slots
+#define GRAM2_FG 8
+#define GRAM_MAX_GROUPS 256
+__device__ __forceinline__ int gram_group_rows(const int* nrows, int g, int Fu) {
+    int o = 0;
+#pragma unroll
+    for (int ff = 0; ff < GRAM2_FG; ++ff) { const int f = g * GRAM2_FG + ff; o += (f < Fu) ? nrows[f] : 0; }
+    return o;
+}
 // block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
                                                           const int* nrows, double* block, size_t bs) {
     partial = zoff(partial, bs); nrows = zoff(nrows, bs); block = zoff(block, bs);
     const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
+    // groups without a stacked row were not written by gram_mfma_kernel (they would add +0.0): skip them
+    __shared__ unsigned char s_ne[GRAM_MAX_GROUPS];
+    for (int g = threadIdx.x; g < n_groups; g += 256) s_ne[g] = gram_group_rows(nrows, g, cfg.Fu) > 0;
+    __syncthreads();
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
         double acc = 0;
-        if (q <= c6) for (int g = 0; g < n_groups; ++g) acc += partial[(size_t)g * ldh * ldh + e];
+        if (q <= c6) for (int g = 0; g < n_groups; ++g) if (s_ne[g]) acc += partial[(size_t)g * ldh * ldh + e];
         block[e] = acc;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {

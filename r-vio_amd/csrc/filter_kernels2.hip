@@ -300,7 +300,6 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
 // grid = (groups of GRAM2_FG features, 16-row tiles of p); 4 waves, wave w owns the 16-column q-tiles w, w+4, w+8.
 // Rows are staged through LDS 32 at a time (coalesced), then v_mfma_f64_16x16x4_f64 with
 //   A[i = p][k = row] = H[row][p0+i],  B[k = row][j = q] = H[row][q].
-#define GRAM2_FG 8
 #define GRAM2_RB 64
 __global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const double* __restrict__ Hstack, const int* __restrict__ nrows,
                                                         double* __restrict__ partial, size_t bs) {
@@ -322,6 +321,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const
     }
     __syncthreads();
     const int R = s_off[GRAM2_FG];
+    if (R == 0) return;   // nothing stacked in this group: gram_reduce_kernel skips it as well (same test)
     for (int r0 = 0; r0 < R; r0 += GRAM2_RB) {
         if (r0 > 0) __syncthreads();
         // stage GRAM2_RB rows: wave w takes rows w, w+4, ...; lanes walk the columns (coalesced, no div/mod)

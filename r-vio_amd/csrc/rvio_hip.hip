@@ -234,11 +234,13 @@ static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip**
     const size_t ldh = d.ldh;
     // launch geometry (decides two optional slab members)
     h->n_groups = (d.Fu + GRAM2_FG - 1) / GRAM2_FG;
+    if (h->n_groups > GRAM_MAX_GROUPS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
     if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     bool need_tm_global = false;
-    if (h->feat_lds > 150 * 1024) {
+    // (a batch handle keeps T in global memory as well: a third less LDS per feature workgroup = 8 instead of 5 resident per CU)
+    if (h->feat_lds > 150 * 1024 || (batch > 1 && !getenv("RVIO_BATCH_TM_LDS"))) {
         h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, false) * sizeof(double);
         need_tm_global = true;
     }
