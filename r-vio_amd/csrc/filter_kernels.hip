@@ -45,11 +45,12 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                                   double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
     extern __shared__ __align__(16) double lds[];
-    x = zoff(x, bs); P = zoff(P, bs); Hstack = zoff(Hstack, bs); nrows_out = zoff(nrows_out, bs); acc_out = zoff(acc_out, bs);
-    ndof_out = zoff(ndof_out, bs); gamma_out = zoff(gamma_out, bs); pfinv_out = zoff(pfinv_out, bs);
-    if (tm_global) tm_global = zoff(tm_global, bs);
-    n_feat_ptr = zoff(n_feat_ptr, bin.n_feat); types = zoff(types, bin.types); lens = zoff(lens, bin.len); meas = zoff(meas, bin.meas);
-    const int tid = threadIdx.x, T = blockDim.x, f = blockIdx.x;
+    const BatchIdx bi = batch_plain();
+    x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Hstack = zoffi(Hstack, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
+    ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
+    if (tm_global) tm_global = zoffi(tm_global, bs, bi.z);
+    n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, bi.z); types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z); meas = zoffi(meas, bin.meas, bi.z);
+    const int tid = threadIdx.x, T = blockDim.x, f = bi.x;
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     // carve LDS
     const int ML = cfg.max_len, M2max = 2 * ML, rhomax = 2 * ML - 2;
@@ -475,20 +476,21 @@ __device__ __forceinline__ int gram_group_rows(const int* nrows, int g, int Fu) 
 // block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
                                                           const int* nrows, double* block, size_t bs) {
-    partial = zoff(partial, bs); nrows = zoff(nrows, bs); block = zoff(block, bs);
+    const BatchIdx bi = batch_plain();
+    partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z);
     const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
     // groups without a stacked row were not written by gram_mfma_kernel (they would add +0.0): skip them
     __shared__ unsigned char s_ne[GRAM_MAX_GROUPS];
     for (int g = threadIdx.x; g < n_groups; g += 256) s_ne[g] = gram_group_rows(nrows, g, cfg.Fu) > 0;
     __syncthreads();
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    for (int e = bi.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
         double acc = 0;
         if (q <= c6) for (int g = 0; g < n_groups; ++g) if (s_ne[g]) acc += partial[(size_t)g * ldh * ldh + e];
         block[e] = acc;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (bi.x == 0 && threadIdx.x < 64) {
         int good = 0, rows = 0;
         for (int f = threadIdx.x; f < cfg.Fu; f += 64) { const int r = nrows[f]; if (r > 0) { good++; rows += r; } }
         good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows);
@@ -522,11 +524,12 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
 //   C/D      lane l : 4 values, row = (l>>4) + 4*r, col = l&15.
 // A = Ab (row-major, ld = ldh), B = Pcc = P[24:,24:] (column-major, ld = dmax), T row-major ld = ldh.
 __global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const double* Ab, const double* P, double* Tm, size_t bs) {
-    Ab = zoff(Ab, bs); P = zoff(P, bs); Tm = zoff(Tm, bs);
+    const BatchIdx bi = batch_remap();
+    Ab = zoffi(Ab, bs, bi.z); P = zoffi(P, bs, bi.z); Tm = zoffi(Tm, bs, bi.z);
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     const double s2 = cfg.sigma_im * cfg.sigma_im;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+    const int i0 = bi.y * 32 + (wave >> 1) * 16, j0 = bi.x * 32 + (wave & 1) * 16;
     if (i0 >= c6 || j0 >= c6) return;
     const int li = lane & 15, lk = lane >> 4;
     const int ai = i0 + li, bj = j0 + li;
@@ -561,13 +564,14 @@ __global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const do
 __global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double* P, const double* W, const double* Ab,
                                                  double* U, double* G, double* P1, size_t bs) {
     extern __shared__ __align__(16) double sh[];
-    P = zoff(P, bs); W = zoff(W, bs); Ab = zoff(Ab, bs); U = zoff(U, bs); G = zoff(G, bs); P1 = zoff(P1, bs);
+    const BatchIdx bi = batch_remap();
+    P = zoffi(P, bs, bi.z); W = zoffi(W, bs, bi.z); Ab = zoffi(Ab, bs, bi.z); U = zoffi(U, bs, bi.z); G = zoffi(G, bs, bi.z); P1 = zoffi(P1, bs, bi.z);
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
     const int lds = c6t * 16 + 1;
     double* Us = sh; double* Gs = sh + 16 * lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const int i0 = blockIdx.x * 16;
+    const int i0 = bi.x * 16;
     if (i0 >= d) return;
     const int ai = i0 + li;
     const bool aok = ai < d;
@@ -675,13 +679,14 @@ __device__ __forceinline__ d4 final_tile(const double* P1, const double* G, cons
     return out;
 }
 __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const double* P1, const double* G, const double* U, double* Pout, size_t bs) {
-    P1 = zoff(P1, bs); G = zoff(G, bs); U = zoff(U, bs); Pout = zoff(Pout, bs);
+    const BatchIdx bi = batch_remap();
+    P1 = zoffi(P1, bs, bi.z); G = zoffi(G, bs, bi.z); U = zoffi(U, bs, bi.z); Pout = zoffi(Pout, bs, bi.z);
     __shared__ double tl[4][16][17];
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const double s2 = cfg.sigma_im * cfg.sigma_im;
     const int nt = (d + 15) / 16, npair = nt * (nt + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const int pr = blockIdx.x * 4 + wave;
+    const int pr = bi.x * 4 + wave;
     if (pr >= npair) return;
     int I = 0, rem = pr;
     while (rem >= nt - I) { rem -= nt - I; ++I; }

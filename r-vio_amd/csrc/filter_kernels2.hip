@@ -304,10 +304,11 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
 __global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const double* __restrict__ Hstack, const int* __restrict__ nrows,
                                                         double* __restrict__ partial, size_t bs) {
     extern __shared__ __align__(16) double hs[];   // [GRAM2_RB][ldh + 1]
-    Hstack = zoff(Hstack, bs); nrows = zoff(nrows, bs); partial = zoff(partial, bs);
+    const BatchIdx bi = batch_plain();
+    Hstack = zoffi(Hstack, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); partial = zoffi(partial, bs, bi.z);
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max, lds = ldh + 1;
-    const int g = blockIdx.x, p0 = blockIdx.y * 16;
+    const int g = bi.x, p0 = bi.y * 16;
     if (p0 >= c6) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int ntile = (c6 + 1 + 15) / 16;

@@ -50,6 +50,24 @@ struct FilterMeta {
 // bytes behind instance 0's (one slab per instance, rvio_hip.hip).  bs = 0 and gridDim.z = 1 for a plain handle.
 template <typename T>
 __device__ __forceinline__ T* zoff(T* p, size_t bs) { return (T*)((char*)p + (size_t)blockIdx.z * bs); }
+template <typename T>
+__device__ __forceinline__ T* zoffi(T* p, size_t bs, int z) { return (T*)((char*)p + (size_t)z * bs); }
+// XCD-aware (x, y, instance) of a workgroup of a batched launch.  The dispatcher is observed to place linear block b on XCD b % 8
+// (a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch"): the remap gives every workgroup of one instance the same
+// b % 8, so the strips / tiles / features of an instance share one XCD's L2 instead of fetching their common operands eight
+// times.  Bijective when gridDim.z is a multiple of 8; identity otherwise (and for a plain handle, gridDim.z = 1).
+struct BatchIdx { int x, y, z; };
+__device__ __forceinline__ BatchIdx batch_remap() {
+    const unsigned X = gridDim.x, Y = gridDim.y, B = gridDim.z;
+    if (B & 7u) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const unsigned w = blockIdx.x + X * (blockIdx.y + Y * blockIdx.z);
+    const unsigned xcd = w & 7u, slot = w >> 3, per = X * Y;
+    const unsigned inner = slot % per, grp = slot / per;
+    return {(int)(inner % X), (int)(inner / X), (int)(grp * 8u + xcd)};
+}
+// (measured, B = 2048: the remap pays for ug / final / gemm_T — few workgroups per instance sharing W, A, Pc, G, U — and costs
+// 8-12 % for feat_build / gram_mfma, whose active workgroups are the first few of 100 / 13 slots: those keep the plain order)
+__device__ __forceinline__ BatchIdx batch_plain() { return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z}; }
 // strides (bytes) of the per-instance inputs of a batched call: IMU samples and the Tracker -> Updater hand-over
 struct BatchIn { size_t imu, n_feat, types, len, meas; };
 
