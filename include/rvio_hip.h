@@ -24,6 +24,7 @@
 #ifndef RVIO_HIP_H
 #define RVIO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -212,18 +213,21 @@ int rvio_hip_frame_end(rvio_hip* h);
 int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment);
 int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m);
 
-/* --- batched filter ------------------------------------- */
-/* B independent filter instances (B robots / B replays of the same sensor rate) behind one
- * handle: the filter state and the update scratch of instance i live in slab i, and every
- * filter stage (PreIntegrator::propagate, Updater::update, augmentation/composition) is ONE
- * launch with gridDim.z = B, i.e. the single-workgroup stages of one filter become B
- * workgroups.  The arithmetic of an instance is the arithmetic of a plain handle, bit for bit.
- * The reference runs one System per process (System.cc:38-41 globals); this is the multi-robot
- * form of the same three calls.  A batch handle carries the filter only: the image entry points
- * return RVIO_ERR_UNSUPPORTED; the window length is common to all instances (it depends on the
- * frame count only, System.cc:266,280).  rvio_hip_set_state / rvio_hip_initialize give every
- * instance the same state, rvio_hip_get_state reads instance 0. */
-int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, rvio_hip** out);
+/* --- batched instances ---------------------------------- */
+/* B independent instances (B robots / B replays of the same sensor rate) behind one handle:
+ * every buffer of instance i lives in slab i, and every stage is ONE launch with
+ * gridDim.z = B, i.e. the single-workgroup stages of one filter become B workgroups.  The
+ * arithmetic of an instance is the arithmetic of a plain handle, bit for bit.  The reference
+ * runs one System per process (System.cc:38-41 globals); this is the multi-robot form of the
+ * same calls.  front_end = 0: the filter only (PreIntegrator::propagate, Updater::update,
+ * augmentation/composition; driven by rvio_hip_frame_tracks_dev); front_end = 1: Tracker::track
+ * as well (CLAHE, DetectWithSubPix, KLT, RANSAC, book-keeping; driven by
+ * rvio_hip_frame_batch_dev).  The single-instance entry points return RVIO_ERR_UNSUPPORTED on
+ * a batch handle; the window length is common to all instances (it depends on the frame count
+ * only, System.cc:266,280).  rvio_hip_set_state / rvio_hip_initialize give every instance the
+ * same state, rvio_hip_get_state reads instance 0. */
+int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, int front_end,
+                          rvio_hip** out);
 int rvio_hip_batch_size(const rvio_hip* h);
 int rvio_hip_set_state_at(rvio_hip* h, int instance, const double* x, int xdim, const double* P, int d);
 int rvio_hip_get_state_at(rvio_hip* h, int instance, double* x, int* xdim, double* P, int* d);
@@ -237,6 +241,11 @@ int rvio_hip_get_state_at(rvio_hip* h, int instance, double* x, int* xdim, doubl
 int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride, int m,
                               const int32_t* d_n_feat, const unsigned char* d_types,
                               const int32_t* d_len, const float* d_meas);
+/* One camera frame of every instance (the whole timed body of System::MonoVIO, System.cc:253-367,
+ * pipelined like rvio_hip_frame_dev): d_imgs = B mono8 images, `img_stride` bytes apart, rows
+ * `stride` bytes apart; d_imu[B][imu_stride] (0: shared).  Corners come from the device detector. */
+int rvio_hip_frame_batch_dev(rvio_hip* h, const uint8_t* d_imgs, int stride, size_t img_stride,
+                             const rvio_imu* d_imu, int imu_stride, int m);
 /* same, direct-track mode, host inputs */
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand);

@@ -9,7 +9,8 @@
 
 #define CLAHE_LUT_T 1024
 __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
-                                                                int clip_limit, float lut_scale, uint8_t* __restrict__ lut) {
+                                                                int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); lut = zoff(lut, bs);
     __shared__ int hist[16][256];
     __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* _
 
 #define CLAHE_MAX_TILES 64
 __global__ __launch_bounds__(256) void clahe_interp_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tiles_y,
-                                                           float inv_tw, float inv_th, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst) {
+                                                           float inv_tw, float inv_th, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst,
+                                                           size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); lut = zoff(lut, bs); dst = zoff(dst, bs);
     __shared__ uint32_t s_lut[CLAHE_MAX_TILES * 64];
     const int tid = threadIdx.x;
     const int nwords = tiles_x * tiles_y * 64;

@@ -42,13 +42,20 @@ struct DetDev {
     int max_cells;
 };
 
+// batched launches: every buffer of instance z lies z * bs bytes behind instance 0's (the cornerSubPix window is shared)
+__device__ __forceinline__ void det_shift(DetDev& d, size_t off) {
+    zmove(d.first, off); zmove(d.eig, off); zmove(d.maxkey, off); zmove(d.counters, off); zmove(d.cell_cnt, off); zmove(d.cell_ent, off);
+    zmove(d.cell_ci, off); zmove(d.nb, off); zmove(d.nb_cnt, off); zmove(d.cand, off); zmove(d.acc, off); zmove(d.state, off);
+    zmove(d.raw_xy, off); zmove(d.xy, off);
+}
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : (b ^ 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
 
 #define DET_TW 64
 #define DET_TH 8
 #define DET_T (DET_TW * DET_TH)
-__global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
+__global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     __shared__ float sdx[DET_TH + 2][DET_TW + 2], sdy[DET_TH + 2][DET_TW + 2];
     __shared__ int s_max[DET_TH];
     const int W = d.W, H = d.H;
@@ -123,7 +130,8 @@ __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* ce
     *gw = (d.W + *cell - 1) / *cell; *gh = (d.H + *cell - 1) / *cell;
 }
 
-__global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d) {
+__global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
+    det_shift(d, (size_t)blockIdx.z * bs);
     const int W = d.W, H = d.H;
     const int x = blockIdx.x * DET_TW + (threadIdx.x & 63), y = blockIdx.y * DET_TH + (threadIdx.x >> 6);
     if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) return;
@@ -158,7 +166,8 @@ __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d) {
 // one of them is taken, taken when all of them are dropped.  OpenCV searches the 3x3 grid cells around the candidate.
 // Up to DET_FAST_N candidates every workgroup rebuilds compact cell buckets in its LDS (a few microseconds) and walks
 // them; denser candidate sets walk the global buckets nms_kernel filled.  Lists go to d.nb (global, L2 resident).
-__global__ __launch_bounds__(NEIGH_T) void neigh_kernel(DetDev d) {
+__global__ __launch_bounds__(NEIGH_T) void neigh_kernel(DetDev d, size_t bs) {
+    det_shift(d, (size_t)blockIdx.z * bs);
     extern __shared__ __align__(16) unsigned char ndyn[];
     __shared__ int s_w[16];
     const int W = d.W, tid = threadIdx.x;
@@ -288,7 +297,8 @@ __device__ __noinline__ int greedy_general_step(const DetDev& d, int c, int m, u
 #define DET_CL_N 2048         // up to this many candidates the neighbour lists are packed into LDS as well
 #define DET_CL_CAP 24576      // ... if they hold at most this many entries in total
 #define GREEDY_LDS (DET_LDS_TK * 8 + DET_LDS_ST + DET_CL_CAP * 2 + (DET_CL_N + 4) * 4)
-__global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
+__global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
+    det_shift(d, (size_t)blockIdx.z * bs);
     extern __shared__ __align__(16) unsigned char gdyn[];
     unsigned long long* tk = (unsigned long long*)gdyn;                         // [DET_LDS_TK]
     unsigned char* lst = gdyn + DET_LDS_TK * 8;                                 // [DET_LDS_ST]
@@ -429,7 +439,8 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d) {
 #define SP_RS (SP_PW + 1 + 2 * SP_MARG)
 #define SP_T 256
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
-__global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d) {
+__global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     __shared__ unsigned char reg[SP_RS * SP_RS];
     __shared__ double s_part[2][4][5];        // by iteration parity: one barrier per iteration
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -35,3 +35,18 @@ struct TrackerDev {
     float* meas;            // [Fu][max_len][2]
     rvio_frame_info* info;
 };
+
+// Batched launches (gridDim.z = instances, rvio_dev.h): every member of these views lies in the instance's slab
+#ifdef __HIPCC__
+template <typename T>
+__device__ __forceinline__ void zmove(T*& p, size_t off) { if (p) p = (T*)((char*)p + off); }
+__device__ __forceinline__ void pyr_shift(PyrDev& p, size_t off) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { zmove(p.img[l], off); zmove(p.dxy[l], off); }
+}
+__device__ __forceinline__ void tracker_shift(TrackerDev& t, size_t off) {
+    zmove(t.first, off); zmove(t.n_pts, off); zmove(t.feats, off); zmove(t.un1, off); zmove(t.slot, off); zmove(t.hist, off); zmove(t.hist_len, off);
+    zmove(t.tracked, off); zmove(t.un2, off); zmove(t.status, off); zmove(t.tmp_feats, off); zmove(t.tmp_un, off); zmove(t.tmp_slot, off);
+    zmove(t.cand_acc, off); zmove(t.cell_pts, off); zmove(t.n_feat, off); zmove(t.types, off); zmove(t.len, off); zmove(t.meas, off); zmove(t.info, off);
+}
+#endif

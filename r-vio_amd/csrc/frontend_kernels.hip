@@ -28,7 +28,8 @@ __device__ __forceinline__ int reflect2(int i, int n) { return reflect1(reflect1
 // ([1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (v+128)>>8).
 __global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restrict__ src, int w, int h, int stride,
                                                         uint8_t* __restrict__ copy_dst, short* __restrict__ dxy,
-                                                        uint8_t* __restrict__ down, int dw, int dh) {
+                                                        uint8_t* __restrict__ down, int dw, int dh, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); if (copy_dst) copy_dst = zoff(copy_dst, bs); dxy = zoff(dxy, bs); if (down) down = zoff(down, bs);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
@@ -147,10 +148,12 @@ __device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  /
 // Dynamic LDS: cand[F] ints + used[F] bytes.
 __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
                                                      unsigned char* status, const rvio_imu* imu, int m, int* rng,
-                                                     rvio_frame_info* info) {
+                                                     rvio_frame_info* info, size_t bs, size_t imu_bs) {
     extern __shared__ __align__(16) unsigned char dsh[];
     __shared__ int s_w[4];
     __shared__ int pairs[16][2];
+    n_pts_ptr = zoff(n_pts_ptr, bs); tracked = zoff(tracked, bs); un1 = zoff(un1, bs); un2 = zoff(un2, bs); status = zoff(status, bs);
+    imu = zoff(imu, imu_bs); rng = zoff(rng, bs); info = zoff(info, bs);
     __shared__ double hyp[16][9];
     __shared__ double dRs[RVIO_MAX_IMU][9];
     __shared__ int cnt[16];
@@ -256,8 +259,9 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // Dynamic LDS: tfs[F] float2 (new feature order), cds[F] float2 (candidates), cid_t[F] / cid_c[F] short (grid cell
 // of each tracked point / candidate, -1 = outside), cellp[4][F] float2 (per-wave ChessGrid cell).
 // n_cand_dev != NULL: the corner count lives on the device (device detector), n_cand is ignored.
-__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev) {
+__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs) {
     extern __shared__ __align__(16) unsigned char dsh[];
+    tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
     float2* tfs = (float2*)dsh;

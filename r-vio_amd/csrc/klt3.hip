@@ -41,7 +41,9 @@ __device__ __forceinline__ void klt3_stage_j(uint8_t* Jr, const uint8_t* __restr
 }
 
 __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int levels, const int* __restrict__ n_pts_ptr,
-                                                  const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status) {
+                                                  const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status, size_t bs) {
+    pyr_shift(prev, (size_t)blockIdx.z * bs); pyr_shift(next, (size_t)blockIdx.z * bs);
+    n_pts_ptr = zoff(n_pts_ptr, bs); pts = zoff(pts, bs); out = zoff(out, bs); status = zoff(status, bs);
     __shared__ uint8_t Ip[4][16 * 16];
     __shared__ int dIp[4][16 * 16];
     __shared__ uint8_t Jr[4][KLT3_JR * KLT3_JR];

@@ -80,6 +80,9 @@ struct rvio_hip {
     size_t slab_off = 0, slab_bytes = 0;
     bool slab_mode = false;
     int batch = 1;
+    bool front_end = true;           // a batch handle may carry the filter only
+    bool det_in_slab = false;        // batch handle with front end: the detector's buffers are slab members too
+    size_t img_bs = 0, imu_bs = 0;   // instance strides (bytes) of the image / IMU batch of the call in progress
     BatchIn bin = {0, 0, 0, 0, 0};   // strides of the hand-over read by feat_build (slab_bytes for the handle's own buffers)
     int* rng = nullptr;
     int* cand_scratch = nullptr;
@@ -112,10 +115,10 @@ static int dalloc(rvio_hip* h, T** p, size_t n) {
     *p = (T*)q;
     return RVIO_OK;
 }
-// a batch handle (rvio_hip_create_batch) carries the filter only
+// entry points that address ONE instance's front end (a batch handle is driven by rvio_hip_frame_batch_dev / _frame_tracks_dev)
 #define FRONT_END_ONLY(h)                                                                                              \
     do {                                                                                                               \
-        if ((h)->batch > 1) { (h)->err = "not available on a batch handle (filter only)"; return RVIO_ERR_UNSUPPORTED; } \
+        if ((h)->batch > 1) { (h)->err = "single-instance entry point called on a batch handle"; return RVIO_ERR_UNSUPPORTED; } \
     } while (0)
 #define DALLOC(h, p, n)                               \
     do {                                              \
@@ -208,7 +211,43 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     return RVIO_OK;
 }
 
-static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip** out) {
+static int detector_alloc(rvio_hip* h);
+static int detector_check(rvio_hip* h);
+// The per-instance front-end buffers (staging, CLAHE, tracker tables, two pyramids; the detector's for a batch handle)
+static int alloc_frontend_slab(rvio_hip* h) {
+    const DevCfg& d = h->dc;
+    TrackerDev& t = h->t;
+    DALLOC(h, h->d_cand, (size_t)2 * d.F);
+    DALLOC(h, h->d_img, (size_t)d.W * d.H);
+    if (h->cfg.enable_equalizer) {
+        DALLOC(h, h->d_eq, (size_t)d.W * d.H);
+        DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
+    }
+    DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
+    DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
+    DALLOC(h, t.first, 1); DALLOC(h, t.n_pts, 1);
+    DALLOC(h, t.feats, (size_t)2 * d.F); DALLOC(h, t.un1, (size_t)2 * d.F); DALLOC(h, t.slot, d.F);
+    DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
+    DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
+    DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
+    DALLOC(h, t.cand_acc, d.F);
+    DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
+    DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
+    DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
+    for (int b = 0; b < 2; ++b) {
+        int w = d.W, hg = d.H;
+        for (int l = 0; l < 4; ++l) {
+            uint8_t* im = nullptr; short* dx = nullptr;
+            if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
+            h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
+            w = (w + 1) / 2; hg = (hg + 1) / 2;
+        }
+    }
+    if (h->det_in_slab) return detector_alloc(h);
+    return RVIO_OK;
+}
+
+static int create_impl(const rvio_config* cfg, int device, int batch, bool front_end, rvio_hip** out) {
     if (!cfg || !out) return RVIO_ERR_INVALID;
     *out = nullptr;
     if (cfg->fisheye) return RVIO_ERR_UNSUPPORTED;
@@ -218,6 +257,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip**
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) return RVIO_ERR_NO_DEVICE;
     rvio_hip* h = new rvio_hip();
     h->cfg = *cfg; h->device = device; h->batch = batch;
+    h->front_end = front_end; h->det_in_slab = front_end && batch > 1;
     fill_devcfg(cfg, &h->dc);
     const DevCfg& d = h->dc;
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
@@ -250,9 +290,20 @@ static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip**
     h->solve_use_lds = h->solve_lds <= 140 * 1024;
     h->solve_nch = (NC <= 64) ? 1 : (NC <= 128 ? 2 : 3);
     if (!h->solve_use_lds) h->solve_lds = 0;
-    // filter slab(s)
+    if (front_end && cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
+        h->cl_tx = 5; h->cl_ty = 5;
+        int ew = d.W, eh = d.H;
+        if (d.W % h->cl_tx != 0 || d.H % h->cl_ty != 0) { ew = d.W + (h->cl_tx - d.W % h->cl_tx); eh = d.H + (h->cl_ty - d.H % h->cl_ty); }
+        h->cl_tw = ew / h->cl_tx; h->cl_th = eh / h->cl_ty;
+        const int area = h->cl_tw * h->cl_th;
+        h->cl_clip = std::max((int)(3.0 * area / 256), 1);
+        h->cl_scale = 255.0f / (float)area;
+    }
+    if (h->det_in_slab) { int rc = detector_check(h); if (rc != RVIO_OK) return rc; }
+    // instance slab(s)
     h->slab_mode = true; h->slab = nullptr; h->slab_off = 0;
     { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    if (front_end) { int rc = alloc_frontend_slab(h); if (rc != RVIO_OK) return rc; }
     h->slab_bytes = h->slab_off;
     {
         void* q = nullptr;
@@ -262,46 +313,16 @@ static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip**
         h->slab = (char*)q; h->slab_off = 0;
     }
     { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    if (front_end) { int rc = alloc_frontend_slab(h); if (rc != RVIO_OK) return rc; }
     h->slab_mode = false;
     h->bin = {0, h->slab_bytes, h->slab_bytes, h->slab_bytes, h->slab_bytes};
     TrackerDev& t = h->t;
     t.info = h->d_info;
     h->tout[0] = {t.n_feat, t.types, t.len, t.meas};   // Tracker -> Updater hand-over, double-buffered for the pipelined path
-    if (batch == 1) {   // front end: a batch handle is filter-only (its callers hand the tracks over, rvio_hip_frame_tracks_dev)
-        DALLOC(h, h->d_cand, (size_t)2 * d.F);
-        DALLOC(h, h->d_img, (size_t)d.W * d.H);
-        if (cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
-            h->cl_tx = 5; h->cl_ty = 5;
-            int ew = d.W, eh = d.H;
-            if (d.W % h->cl_tx != 0 || d.H % h->cl_ty != 0) { ew = d.W + (h->cl_tx - d.W % h->cl_tx); eh = d.H + (h->cl_ty - d.H % h->cl_ty); }
-            h->cl_tw = ew / h->cl_tx; h->cl_th = eh / h->cl_ty;
-            const int area = h->cl_tw * h->cl_th;
-            h->cl_clip = std::max((int)(3.0 * area / 256), 1);
-            h->cl_scale = 255.0f / (float)area;
-            DALLOC(h, h->d_eq, (size_t)d.W * d.H);
-            DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
-        }
-        DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
-        DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
-        DALLOC(h, t.first, 1); DALLOC(h, t.n_pts, 1);
-        DALLOC(h, t.feats, (size_t)2 * d.F); DALLOC(h, t.un1, (size_t)2 * d.F); DALLOC(h, t.slot, d.F);
-        DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
-        DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
-        DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
-        DALLOC(h, t.cand_acc, d.F);
-        DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
-        DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
-        DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
-        { int one = 1; HIPCHK(h, hipMemcpyAsync(t.first, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); }
-        for (int b = 0; b < 2; ++b) {
-            int w = d.W, hg = d.H;
-            for (int l = 0; l < 4; ++l) {
-                uint8_t* im = nullptr; short* dx = nullptr;
-                if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
-                h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
-                w = (w + 1) / 2; hg = (hg + 1) / 2;
-            }
-        }
+    if (front_end) {   // mbIsTheFirstImage = true in every instance
+        std::vector<int> ones((size_t)batch, 1);
+        HIPCHK(h, hipMemcpy2DAsync(t.first, h->slab_bytes, ones.data(), sizeof(int), sizeof(int), (size_t)batch, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -341,9 +362,12 @@ static int create_impl(const rvio_config* cfg, int device, int batch, rvio_hip**
     return RVIO_OK;
 }
 
-int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) { return create_impl(cfg, device, 1, out); }
-// B independent filter instances behind one handle: every filter stage is ONE launch with gridDim.z = B
-int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, rvio_hip** out) { return create_impl(cfg, device, n_instances, out); }
+int rvio_hip_create(const rvio_config* cfg, int device, rvio_hip** out) { return create_impl(cfg, device, 1, true, out); }
+// B independent instances behind one handle: every stage is ONE launch with gridDim.z = B.
+// front_end = 0: filter only (rvio_hip_frame_tracks_dev); 1: with CLAHE / detector / KLT / RANSAC / book-keeping (rvio_hip_frame_batch_dev)
+int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, int front_end, rvio_hip** out) {
+    return create_impl(cfg, device, n_instances, front_end != 0, out);
+}
 int rvio_hip_batch_size(const rvio_hip* h) { return h ? h->batch : 0; }
 
 void rvio_hip_destroy(rvio_hip* h) {
@@ -626,13 +650,16 @@ int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
 }
 
 // ------------------------------------------------------------------ T7 detector (device), allocated on first use
-static int detector_init(rvio_hip* h) {
-    if (h->det_ready) return RVIO_OK;
+static int detector_check(rvio_hip* h) {
+    const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist);
+    if (cell1 < 1) { h->err = "Tracker.nMinDist < 1 is not supported by the device detector"; return RVIO_ERR_UNSUPPORTED; }
+    if ((int)std::floor(.5 * h->cfg.min_dist) != SP_WIN) { h->err = "device cornerSubPix is built for floor(nMinDist/2) == 7"; return RVIO_ERR_UNSUPPORTED; }
+    return RVIO_OK;
+}
+static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a slab)
     const DevCfg& d = h->dc;
     DetDev& q = h->det;
     const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist), cell2 = (int)std::nearbyint((double)(2.f * h->cfg.min_dist));
-    if (cell1 < 1) { h->err = "Tracker.nMinDist < 1 is not supported by the device detector"; return RVIO_ERR_UNSUPPORTED; }
-    if ((int)std::floor(.5 * h->cfg.min_dist) != SP_WIN) { h->err = "device cornerSubPix is built for floor(nMinDist/2) == 7"; return RVIO_ERR_UNSUPPORTED; }
     const size_t npx = (size_t)d.W * d.H;
     q.W = d.W; q.H = d.H; q.F = d.F; q.min_dist = h->cfg.min_dist; q.quality = (double)h->cfg.qual_lvl;
     q.max_cells = ((d.W + cell1 - 1) / cell1) * ((d.H + cell1 - 1) / cell1);
@@ -645,6 +672,15 @@ static int detector_init(rvio_hip* h) {
     DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, q.xy, (size_t)2 * d.F);
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)SP_WW * SP_WW);
+    q.spmask = mask;
+    return RVIO_OK;
+}
+static int detector_init(rvio_hip* h) {
+    if (h->det_ready) return RVIO_OK;
+    int rc = detector_check(h);
+    if (rc != RVIO_OK) return rc;
+    if (!h->det_in_slab && (rc = detector_alloc(h)) != RVIO_OK) return rc;
+    DetDev& q = h->det;
     // cornerSubPix window (cornersubpix.cpp): float expf on the host, so that device and oracle share glibc's values
     float hm[SP_WW * SP_WW];
     for (int i = 0; i < SP_WW; ++i) {
@@ -652,11 +688,11 @@ static int detector_init(rvio_hip* h) {
         const float vy = std::exp(-y * y);
         for (int j = 0; j < SP_WW; ++j) { const float x = (float)(j - SP_WIN) / (float)SP_WIN; hm[i * SP_WW + j] = (float)(vy * std::exp(-x * x)); }
     }
-    const int minkey = (int)0x80000000;
-    HIPCHK(h, hipMemcpyAsync(mask, hm, sizeof hm, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(q.maxkey, &minkey, sizeof minkey, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm, sizeof hm, hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
+    std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
+    HIPCHK(h, hipMemcpy2DAsync(q.maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
+                               hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    q.spmask = mask;
     HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
     HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
@@ -666,16 +702,18 @@ static int detector_init(rvio_hip* h) {
     return RVIO_OK;
 }
 // forks from the tracker stream (the image `img` is complete there), runs beside pyramid/KLT/RANSAC, joined before book-keeping
-static int detect_dev(rvio_hip* h, const uint8_t* img, int stride) {
+static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs) {
     const DevCfg& d = h->dc;
+    const size_t bs = h->slab_bytes;
+    const unsigned B = (unsigned)h->batch;
     HIPCHK(h, hipEventRecord(h->evD0, h->ts));
     HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
-    const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH);
-    hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det);
-    hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det);
-    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det);
-    hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det);
-    hipLaunchKernelGGL(subpix_kernel, dim3(d.F), dim3(SP_T), 0, h->stream_d, img, stride, h->det);
+    const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
+    hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+    hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
+    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
+    hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
     return RVIO_OK;
@@ -685,24 +723,27 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride) {
 static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int b) {
     const DevCfg& d = h->dc;
     PyrDev& p = h->pyr[b];
+    const size_t bs = h->slab_bytes;
+    const unsigned B = (unsigned)h->batch;
+    size_t src_bs = h->img_bs;       // the caller's images: instance stride of the call in progress
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
-        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
-                           h->cl_clip, h->cl_scale, h->d_lut);
-        hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                           1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq);
-        d_img = h->d_eq; stride = d.W;
+        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
+                           h->cl_clip, h->cl_scale, h->d_lut, src_bs, bs);
+        hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+                           1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
+        d_img = h->d_eq; stride = d.W; src_bs = bs;
     }
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
-        const int rc = detect_dev(h, d_img, stride);
+        const int rc = detect_dev(h, d_img, stride, src_bs);
         if (rc != RVIO_OK) return rc;
     }
     // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
     for (int l = 0; l < d.levels; ++l) {
         const bool last = (l + 1 == d.levels);
         const uint8_t* src = (l == 0) ? d_img : p.img[l];
-        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
+        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
                            (l == 0) ? stride : p.w[l], (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
-                           last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1]);
+                           last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], (l == 0) ? src_bs : bs, bs);
     }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -710,20 +751,20 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
 
 // everything after Tracker.cc:246; status/tracked already on the device
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    hipLaunchKernelGGL(ransac_kernel, dim3(1), dim3(256), (size_t)5 * h->dc.F + 16, h->ts, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
-                       h->t.status, d_imu, m, h->rng, h->d_info);
+    const size_t bs = h->slab_bytes;
+    const unsigned B = (unsigned)h->batch;
+    hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->ts, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
+                       h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
     if (h->use_det) {   // join the detector stream: its corner list replaces the caller's
         HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, (const float*)h->det.xy, 0, (const int*)(h->det.counters + 2));
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->ts, h->dc, h->t, (const float*)h->det.xy, 0, (const int*)(h->det.counters + 2), bs);
     } else
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr);
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
 
-int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
-    FRONT_END_ONLY(h);
+static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     HIPCHK(h, hipSetDevice(h->device));
     if (h->piped && h->ts == h->stream) HIPCHK(h, hipStreamSynchronize(h->stream_t));
     int rc;
@@ -732,11 +773,16 @@ int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
-    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F), dim3(64), 0, h->ts, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
-                       h->t.tracked, h->t.status);
+    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->ts, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+                       h->t.tracked, h->t.status, h->slab_bytes);
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
     return rc;
+}
+int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
+    if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
+    return track_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand);
 }
 
 int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
@@ -763,7 +809,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
     }
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);
+    hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);   // (single instance only)
     h->use_det = false;   // no image in this mode
     return post_klt_dev(h, h->d_imu, m, h->d_cand, nc);
 }
@@ -881,11 +927,11 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg_host ? now() : 0;
     if (staged) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));   // the IMU batch was copied on the tracker stream
-    int rc = propagate_dev(h, d_imu, m);                                     // filter stream, right behind augment/compose(k-1)
+    int rc = propagate_dev(h, d_imu, m, h->imu_bs);                          // filter stream, right behind augment/compose(k-1)
     if (rc != RVIO_OK) return rc;
     const double t1 = dbg_host ? now() : 0;
     h->ts = h->stream_t;
-    rc = rvio_hip_track_dev(h, d_img, stride, d_imu, m, d_cand, n_cand);
+    rc = track_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand);
     h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
     const double t2 = dbg_host ? now() : 0;
@@ -909,6 +955,19 @@ int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
     return frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false);
+}
+// One camera frame of EVERY instance of a batch handle created with its front end: d_imgs[B] (instance stride img_stride bytes,
+// row stride `stride`), d_imu[B][imu_stride] (0: shared).  Same pipelined body as rvio_hip_frame_dev, every launch with gridDim.z = B;
+// corners always come from the device detector.
+int rvio_hip_frame_batch_dev(rvio_hip* h, const uint8_t* d_imgs, int stride, size_t img_stride, const rvio_imu* d_imu, int imu_stride, int m) {
+    if (!h || !d_imgs || (!d_imu && m > 0) || imu_stride < 0 || (imu_stride > 0 && imu_stride < m) || stride < h->dc.W) return RVIO_ERR_INVALID;
+    if (!h->front_end) { h->err = "this batch handle was created without its front end"; return RVIO_ERR_UNSUPPORTED; }
+    if (h->batch > 1 && img_stride < (size_t)stride * h->dc.H) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->img_bs = img_stride; h->imu_bs = (size_t)imu_stride * sizeof(rvio_imu);
+    const int rc = frame_dev_impl(h, d_imgs, stride, d_imu, m, nullptr, 0, false);
+    h->img_bs = 0; h->imu_bs = 0;
+    return rc;
 }
 // The pipelined frame split open for callers that sequence the update themselves (the feature-sharded updater):
 //   frame_begin_dev   propagate on the filter stream, the front end on its streams, filter stream ordered after the front end
@@ -1049,7 +1108,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         } else if (which == 1) {
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
-                               h->t.tracked, h->t.status);
+                               h->t.tracked, h->t.status, (size_t)0);
         } else {
             hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
     "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
+    "rvio_hip_frame_batch_dev",
 ]
 
 _LIB = None
@@ -58,8 +59,8 @@ def _p(a, t):
 class RvioHip:
     """One filter instance on one GPU (mirrors the System-owned stage objects, System.h:89-92)."""
 
-    def __init__(self, cfg, device=0, batch=None):
-        """batch=B: B independent filter instances behind one handle (rvio_hip_create_batch; filter only)"""
+    def __init__(self, cfg, device=0, batch=None, front_end=False):
+        """batch=B: B independent instances behind one handle (rvio_hip_create_batch); front_end: with the tracker, else filter only"""
         self.L = load()
         self.cfg = cfg
         self.h = C.c_void_p()
@@ -67,7 +68,7 @@ class RvioHip:
         if batch is None:
             rc = self.L.rvio_hip_create(C.byref(cfg), int(device), C.byref(self.h))
         else:
-            rc = self.L.rvio_hip_create_batch(C.byref(cfg), int(device), int(batch), C.byref(self.h))
+            rc = self.L.rvio_hip_create_batch(C.byref(cfg), int(device), int(batch), int(bool(front_end)), C.byref(self.h))
         if rc != 0:
             msg = self.L.rvio_hip_last_error(self.h).decode() if self.h else ""
             if self.h:
@@ -127,6 +128,11 @@ class RvioHip:
         """MonoVIO body after the tracker on device-resident hand-over tables, all instances in one launch per stage"""
         self._ck(self.L.rvio_hip_frame_tracks_dev(self.h, C.c_void_p(d_imu_ptr), int(imu_stride), int(m), C.c_void_p(d_n_feat_ptr),
                                                   C.c_void_p(d_types_ptr), C.c_void_p(d_len_ptr), C.c_void_p(d_meas_ptr)), "frame_tracks_dev")
+
+    def frame_batch_dev(self, d_imgs_ptr, stride, img_stride, d_imu_ptr, imu_stride, m):
+        """one camera frame of every instance of a batch handle with front end (device detector)"""
+        self._ck(self.L.rvio_hip_frame_batch_dev(self.h, C.c_void_p(d_imgs_ptr), int(stride), C.c_size_t(int(img_stride)), C.c_void_p(d_imu_ptr),
+                                                 int(imu_stride), int(m)), "frame_batch_dev")
 
     def initialize(self, w, a, n_imu):
         w = np.ascontiguousarray(w, float)

@@ -99,3 +99,47 @@ def test_frame_tracks_dev_on_a_plain_handle_and_front_end_refused_on_a_batch(gpu
     assert h2.L.rvio_hip_batch_size(h2.h) == 2 and h1.L.rvio_hip_batch_size(h1.h) == 1
     h1.close()
     h2.close()
+
+
+def test_batch_with_front_end_equals_plain_handles_bit_for_bit(gpu_required):
+    """rvio_hip_frame_batch_dev: B camera streams (different scenes) through CLAHE, detector, KLT, RANSAC, book-keeping and the filter
+    in one launch per stage — every instance must end in exactly the state of a plain handle fed its own stream"""
+    from rvio_amd import hip
+    import torch
+    cfg = abi.config_named("B")                     # stock: CLAHE on, corners from the device detector
+    B, n_frames, k0 = 3, 12, 60
+    seqs = [rv.synth.SynthSequence(cfg, duration=8.0, seed=s) for s in range(B)]
+    imgs = np.stack([[q.render(k0 + f) for q in seqs] for f in range(n_frames)])          # [frame][instance][H][W]
+    imus = [[q.imu_between(k0 + f) for q in seqs] for f in range(n_frames)]
+    hb = hip.RvioHip(cfg, batch=B, front_end=True)
+    hs = [hip.RvioHip(cfg) for _ in range(B)]
+    for i, q in enumerate(seqs):
+        w, a, n = q.init_from_static(38)
+        hs[i].initialize(w, a, n)
+        if i == 0:
+            hb.initialize(w, a, n)
+        hb.set_state_at(i, *hs[i].get_state())
+    keep = []
+    for f in range(n_frames):
+        m = len(imus[f][0])
+        assert all(len(u) == m for u in imus[f])
+        imu = np.stack(imus[f])
+        d_img = torch.from_numpy(imgs[f]).cuda()
+        d_imu = torch.from_numpy(imu.view(np.uint8).reshape(B, -1)).cuda()
+        keep += [d_img, d_imu]
+        torch.cuda.synchronize()
+        hb.frame_batch_dev(d_img.data_ptr(), cfg.width, cfg.width * cfg.height, d_imu.data_ptr(), m, m)
+        for i in range(B):
+            hs[i].frame_dev(d_img[i].data_ptr(), cfg.width, d_imu[i].data_ptr(), m, 0, 0)
+    hb.sync()
+    n_upd = 0
+    for i in range(B):
+        hs[i].sync()
+        xa, Pa = hb.get_state_at(i)
+        xb, Pb = hs[i].get_state()
+        assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), i
+        n_upd += hs[i].frame_info()["updated"]
+    assert not np.array_equal(hb.get_state_at(0)[0], hb.get_state_at(1)[0])      # the streams really differ
+    hb.close()
+    for h in hs:
+        h.close()
