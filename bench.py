@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--host-corners", action="store_true",
                     help="feed a caller-side corner list (projected landmarks) instead of running the device detector")
     ap.add_argument("--batch", default="1,16,256,2048", help="instance counts of the batched-filter leg (SURVEY.md 8d (ii)); '' skips it")
+    ap.add_argument("--batch-streams", default="1,16,128", help="instance counts of the batched camera-stream leg (whole frame, B streams per launch); '' skips it")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     ap.add_argument("--stream-threads", type=int, default=1, help="host threads issuing the launches of the aggregate-throughput leg")
     args = ap.parse_args()
@@ -216,6 +217,8 @@ def main():
             out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
                                                wi, ai, ni, n_frames, 1 + W, streams=args.streams, threads=args.stream_threads)
             out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
+        if args.batch_streams:
+            out["batched_streams"] = batched_streams_leg(cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
         if args.batch:
             out["batched_filter"] = batched_filter_leg(cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
@@ -480,6 +483,80 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
     return {"workload": "cfg%s filter only (propagate + update + augment/compose), direct-track hand-over tables of %d seeded sequences, "
                         "%d frames timed after %d, one launch per stage for all instances" % (name, seeds, n_timed, n_warm),
             "algorithmic_mflop_per_filter_frame": w_frame / 1e6, "peak_tflops_fp64": PEAK_F64, "sizes": res}
+
+
+def batched_streams_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=12, n_timed=30):
+    """The WHOLE frame (CLAHE, detector, KLT, RANSAC, book-keeping, propagate, update, augment/compose) for B camera streams in one
+    launch per stage (rvio_hip_create_batch with front end, rvio_hip_frame_batch_dev).  `seeds` differently seeded scenes are
+    rendered on the host; stream b replays scene b mod seeds.  Images and IMU batches are resident in HBM before the timed region."""
+    from rvio_amd import hip
+    nf = 1 + n_warm + n_timed
+    scenes = [build_inputs(cfg, nf, seed=sd) for sd in range(seeds)]
+    m = int(min(sc[3].min() for sc in scenes))
+    inits = []
+    for sc in scenes:
+        h = hip.RvioHip(cfg)
+        h.initialize(*sc[0].init_from_static(K0))
+        inits.append(h.get_state())
+        h.close()
+    d_img_s = [torch.from_numpy(sc[1]).cuda() for sc in scenes]                                   # [seed][frame][H][W]
+    d_imu_s = [torch.from_numpy(np.ascontiguousarray(sc[2][:, :m]).view(np.uint8).reshape(nf, -1)).cuda() for sc in scenes]
+    npx = cfg.width * cfg.height
+    it_l = 10
+    by_klt = npx * (1 + 2 * (1 / 4 + 1 / 16 + 1 / 64)) + cfg.n_features * 4 * (16 * 16 * 5) + cfg.n_features * 4 * it_l * 16 * 16   # B_klt, SURVEY.md 8d
+    res = []
+    for B in sizes:
+        idx = np.arange(B) % seeds
+        h = hip.RvioHip(cfg, batch=B, front_end=True)
+        h.set_state(*inits[0])
+        for b in range(B):
+            if idx[b] != 0:
+                h.set_state_at(b, *inits[idx[b]])
+        img_buf = torch.empty((2, B, cfg.height, cfg.width), dtype=torch.uint8, device="cuda")      # double-buffered frame of B streams
+        imu_buf = torch.empty((2, B, d_imu_s[0].shape[1]), dtype=torch.uint8, device="cuda")
+        sel = torch.from_numpy(idx).cuda()
+        stack_img = torch.stack(d_img_s)                                                            # [seed][frame][H][W]
+        stack_imu = torch.stack(d_imu_s)
+
+        def stage(f):          # gather this frame's B images / IMU batches (device-side copy, OUTSIDE the timed region: see below)
+            img_buf[f & 1].copy_(stack_img[sel, f])
+            imu_buf[f & 1].copy_(stack_imu[sel, f])
+        # all frames are staged up front so that the timed region contains the library's work only
+        frames_img = torch.empty((nf, B, cfg.height, cfg.width), dtype=torch.uint8, device="cuda") if B * nf * npx < 24e9 else None
+        if frames_img is not None:
+            frames_imu = torch.empty((nf, B, d_imu_s[0].shape[1]), dtype=torch.uint8, device="cuda")
+            for f in range(nf):
+                frames_img[f].copy_(stack_img[sel, f])
+                frames_imu[f].copy_(stack_imu[sel, f])
+        torch.cuda.synchronize()
+
+        def frame(f):
+            if frames_img is None:
+                stage(f)
+                torch.cuda.synchronize()
+                ip, up_ = img_buf[f & 1].data_ptr(), imu_buf[f & 1].data_ptr()
+            else:
+                ip, up_ = frames_img[f].data_ptr(), frames_imu[f].data_ptr()
+            h.frame_batch_dev(ip, cfg.width, npx, up_, m, m)
+        for f in range(1 + n_warm):
+            frame(f)
+        h.sync()
+        t0 = time.perf_counter()
+        for f in range(1 + n_warm, nf):
+            frame(f)
+        h.sync()
+        el = time.perf_counter() - t0
+        x_last = h.get_state_at(B - 1)[0]
+        info = h.frame_info()
+        h.close()
+        del frames_img, img_buf, imu_buf, stack_img, stack_imu
+        fps = B * n_timed / el
+        res.append({"streams": B, "ms_per_batched_frame": 1e3 * el / n_timed, "frames_per_s": fps,
+                    "klt_chain_algorithmic_GBps": by_klt * fps / 1e9, "frac_hbm_peak": by_klt * fps / 1e9 / 8000.0,
+                    "staged_up_front": True, "finite": bool(np.all(np.isfinite(x_last))), "updated_last_frame": int(info["updated"])})
+    return {"workload": "cfg%s whole frame (stock: CLAHE + device detector), %d seeded scenes, stream b replays scene b mod %d, %d frames timed after %d, "
+                        "one launch per stage for all streams" % (name, seeds, seeds, n_timed, 1 + n_warm),
+            "algorithmic_MB_per_frame_klt_chain": by_klt / 1e6, "sizes": res}
 
 
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):

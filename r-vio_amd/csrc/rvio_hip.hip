@@ -80,6 +80,7 @@ struct rvio_hip {
     size_t slab_off = 0, slab_bytes = 0;
     bool slab_mode = false;
     int batch = 1;
+    bool one_stream = false;
     bool front_end = true;           // a batch handle may carry the filter only
     bool det_in_slab = false;        // batch handle with front end: the detector's buffers are slab members too
     size_t img_bs = 0, imu_bs = 0;   // instance strides (bytes) of the image / IMU batch of the call in progress
@@ -264,7 +265,9 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     *out = h;   // returned even on allocation failure so last_error is readable
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
+    h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
+    if (h->one_stream) h->stream_t = h->stream;
+    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
     h->ts = h->stream;
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], hipEventDisableTiming));
@@ -379,9 +382,9 @@ void rvio_hip_destroy(rvio_hip* h) {
     for (void* p : h->allocs) hipFree(p);
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
-    if (h->stream_d) hipStreamDestroy(h->stream_d);
+    if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
     for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
-    if (h->stream_t) hipStreamDestroy(h->stream_t);
+    if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -695,7 +698,8 @@ static int detector_init(rvio_hip* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
     HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
+    if (h->one_stream) h->stream_d = h->stream;
+    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, hipEventDisableTiming));
     h->det_ready = true;
