@@ -123,6 +123,90 @@ __global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict
     }
 }
 
+// Throughput form (batched launches): a 64 x 32 tile per workgroup, the raw pixels staged once in LDS (one byte load per pixel
+// instead of eight per gradient), four rows per thread.  Same gradient / covariance / eigenvalue expressions, same outputs.
+#define DET_R4 4
+__global__ __launch_bounds__(DET_T) void mineig_kernel4(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    constexpr int TH = DET_TH * DET_R4, RW = DET_TW + 4, RH = TH + 4;
+    __shared__ unsigned char raw[RH][RW];
+    __shared__ float sdx[TH + 2][DET_TW + 2], sdy[TH + 2][DET_TW + 2];
+    __shared__ int s_max[DET_TH];
+    const int W = d.W, H = d.H;
+    const int tid = threadIdx.x, x0 = blockIdx.x * DET_TW, y0 = blockIdx.y * TH;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int i = tid; i < d.max_cells; i += DET_T) d.cell_cnt[i] = 0;
+        if (tid < 3) d.counters[tid] = 0;
+    }
+    // raw[tr][tc] = pixel (y0 - 2 + tr, x0 - 2 + tc) wherever that lies in the image (other cells are never addressed)
+    for (int e = tid; e < RH * RW; e += DET_T) {
+        const int tr = e / RW, tc = e % RW;
+        const int yy = min(max(y0 - 2 + tr, 0), H - 1), xx = min(max(x0 - 2 + tc, 0), W - 1);
+        raw[tr][tc] = src[(size_t)yy * stride + xx];
+    }
+    __syncthreads();
+    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+    const float k1 = (float)scale, k0 = (float)(2.0 * scale);
+    for (int e = tid; e < (DET_TW + 2) * (TH + 2); e += DET_T) {
+        const int ly = e / (DET_TW + 2), lx = e % (DET_TW + 2);
+        float dxv = 0.f, dyv = 0.f;
+        if (y0 + ly - 1 < H + 1 && x0 + lx - 1 < W + 1) {
+            const int gy = reflect1(y0 + ly - 1, H), gx = reflect1(x0 + lx - 1, W);
+            const unsigned char* r0 = raw[reflect1(gy - 1, H) - y0 + 2];
+            const unsigned char* r1 = raw[gy - y0 + 2];
+            const unsigned char* r2 = raw[reflect1(gy + 1, H) - y0 + 2];
+            const int xl = reflect1(gx - 1, W) - x0 + 2, xc = gx - x0 + 2, xr = reflect1(gx + 1, W) - x0 + 2;
+            const float a00 = r0[xl], a01 = r0[xc], a02 = r0[xr], a10 = r1[xl], a12 = r1[xr], a20 = r2[xl], a21 = r2[xc], a22 = r2[xr];
+            const float rr0 = a02 - a00, rr1 = a12 - a10, rr2 = a22 - a20;
+            dxv = k0 * rr1 + k1 * (rr0 + rr2);
+            const float q0 = k0 * a01 + k1 * (a00 + a02);
+            const float q2 = k0 * a21 + k1 * (a20 + a22);
+            dyv = q2 - q0;
+        }
+        sdx[ly][lx] = dxv; sdy[ly][lx] = dyv;
+    }
+    __syncthreads();
+    const int lx = tid & 63, x = x0 + lx;
+    int key = (int)0x80000000;
+#pragma unroll
+    for (int rr = 0; rr < DET_R4; ++rr) {
+        const int ly = (tid >> 6) + DET_TH * rr, y = y0 + ly;
+        if (x < W && y < H) {
+            float cov[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double col[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double v[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float gx = sdx[ly + i][lx + j], gy = sdy[ly + i][lx + j];
+                        const float p = (k == 0) ? gx * gx : (k == 1 ? gx * gy : gy * gy);
+                        v[i] = (double)p;
+                    }
+                    col[j] = (v[0] + v[1]) + v[2];
+                }
+                cov[k] = (float)((col[0] + col[1]) + col[2]);
+            }
+            const float a = cov[0] * 0.5f, b = cov[1], c = cov[2] * 0.5f;
+            const float ev = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            d.eig[(size_t)y * W + x] = ev;
+            const int k2 = f2ord(ev);
+            key = k2 > key ? k2 : key;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
+    if ((tid & 63) == 0) s_max[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+        int m = s_max[0];
+        for (int k = 1; k < DET_TH; ++k) m = s_max[k] > m ? s_max[k] : m;
+        atomicMax(d.maxkey, m);
+    }
+}
+
 __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* cell, int* gw, int* gh) {
     const float s = (*d.first) ? 1.f : 2.f;
     *md = s * d.min_dist;                                    // s*mnMinDistance (int * float)
@@ -546,4 +630,117 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
 #endif
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
     if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+}
+
+// Throughput form (batched launches): ONE wave per corner, four corners per workgroup, no workgroup barrier inside the iteration.
+// Lane (i, q) = (lane / 4, lane % 4) evaluates the four window terms (i, q), (i, q + 4), (i, q + 8), (i, q + 12) of window row i, so
+// the first two levels of the canonical column tree — (j, j + 8), then (.., + 4) — are additions inside the lane, the last two
+// — (.., + 2), (.., + 1) — two quad permutes; rows combine as (R0 + R1) + (R2 + R3) per row quartet (row rotations by 4 and 8
+// lanes inside a 16-lane DPP row = one quartet), quartets as (W0 + W1) + (W2 + W3).  The same tree as subpix_kernel and the
+// oracle, hence identical results, at about half the instructions and a quarter of the wave slots per corner.
+__global__ __launch_bounds__(SP_T) void subpix_kernel1(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    __shared__ unsigned char regs[4][SP_RS * SP_RS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    const int n = d.counters[2];
+    const bool act = p < n;
+    const int W = d.W, H = d.H;
+    unsigned char* reg = regs[wv];
+    float tx = 0.f, ty = 0.f;
+    int rx0 = 0, ry0 = 0;
+    if (act) {
+        tx = d.raw_xy[2 * p]; ty = d.raw_xy[2 * p + 1];
+        rx0 = (int)tx - (SP_PW - 1) / 2 - SP_MARG; ry0 = (int)ty - (SP_PW - 1) / 2 - SP_MARG;
+        for (int e = lane; e < SP_RS * SP_RS; e += 64) {
+            const int j = e / SP_RS, i = e % SP_RS;
+            reg[e] = src[(size_t)min(max(ry0 + j, 0), H - 1) * stride + min(max(rx0 + i, 0), W - 1)];
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    auto pix = [&](int x, int y) -> float {
+        const int i = x - rx0, j = y - ry0;
+        if ((unsigned)i < (unsigned)SP_RS && (unsigned)j < (unsigned)SP_RS) return (float)reg[j * SP_RS + i];
+        return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)];
+    };
+    const int wi = lane >> 2, q4 = lane & 3;
+    double wm[4], px[4];
+    bool live[4];
+    const double py = wi - SP_WIN;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int wj = q4 + 4 * k;
+        live[k] = wi < SP_WW && wj < SP_WW;
+        wm[k] = live[k] ? (double)d.spmask[wi * SP_WW + wj] : 0.0;
+        px[k] = wj - SP_WIN;
+    }
+    float cx = tx, cy = ty;
+    const double eps = 1e-2 * 1e-2;
+    int iter = 0;
+    double err = 0;
+    do {
+        const float ox = cx - (float)(SP_PW - 1) * 0.5f, oy = cy - (float)(SP_PW - 1) * 0.5f;
+        const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+        float fa = ox - (float)ix;
+        const float fb = oy - (float)iy;
+        fa = fmaxf(fa, 0.0001f);
+        const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
+        auto samp = [&](int pi, int pj) -> float {
+            const int x = ix + pj, y = iy + pi;
+            return ((pix(x, y) * a11 + pix(x + 1, y) * a12) + pix(x, y + 1) * a21) + pix(x + 1, y + 1) * a22;
+        };
+        double t[4][5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wj = q4 + 4 * k;
+            double ra = 0, rb = 0, rc = 0, r1s = 0, r2s = 0;
+            if (live[k]) {
+                float sE, sW, sS, sN;
+                const int bx = ix + wj - rx0, by = iy + wi - ry0;
+                if ((unsigned)bx <= (unsigned)(SP_RS - 4) && (unsigned)by <= (unsigned)(SP_RS - 4)) {
+                    const unsigned char* g = reg + by * SP_RS + bx;
+                    const float p01 = g[1], p02 = g[2];
+                    const float p10 = g[SP_RS], p11 = g[SP_RS + 1], p12 = g[SP_RS + 2], p13 = g[SP_RS + 3];
+                    const float p20 = g[2 * SP_RS], p21 = g[2 * SP_RS + 1], p22 = g[2 * SP_RS + 2], p23 = g[2 * SP_RS + 3];
+                    const float p31 = g[3 * SP_RS + 1], p32 = g[3 * SP_RS + 2];
+                    sE = ((p12 * a11 + p13 * a12) + p22 * a21) + p23 * a22;
+                    sW = ((p10 * a11 + p11 * a12) + p20 * a21) + p21 * a22;
+                    sS = ((p21 * a11 + p22 * a12) + p31 * a21) + p32 * a22;
+                    sN = ((p01 * a11 + p02 * a12) + p11 * a21) + p12 * a22;
+                } else { sE = samp(wi + 1, wj + 2); sW = samp(wi + 1, wj); sS = samp(wi + 2, wj + 1); sN = samp(wi, wj + 1); }
+                const double tgx = sE - sW;
+                const double tgy = sS - sN;
+                const double gxx = tgx * tgx * wm[k], gxy = tgx * tgy * wm[k], gyy = tgy * tgy * wm[k];
+                ra = gxx; rb = gxy; rc = gyy;
+                r1s = gxx * px[k] + gxy * py;
+                r2s = gxy * px[k] + gyy * py;
+            }
+            t[k][0] = ra; t[k][1] = rb; t[k][2] = rc; t[k][3] = r1s; t[k][4] = r2s;
+        }
+        double sm[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            // columns: (j, j+8) and (.., +4) inside the lane; (.., +2), (.., +1) across the quad
+            double v = (t[0][c] + t[2][c]) + (t[1][c] + t[3][c]);
+            v += dpp_f64<0x4e>(v);      // quad_perm [2,3,0,1]
+            v += dpp_f64<0xb1>(v);      // quad_perm [1,0,3,2]
+            // rows of a quartet sit 4 lanes apart inside one 16-lane DPP row: (R0 + R1) + (R2 + R3)
+            v += dpp_f64<0x12c>(v);     // row_ror:12 (lane i <- lane i + 4): lane 0: R0 + R1, lane 8: R2 + R3
+            v += dpp_f64<0x128>(v);     // row_ror:8   lane 0 of the row: (R0 + R1) + (R2 + R3)
+            sm[c] = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+        }
+        const double a = sm[0], b = sm[1], c = sm[2], bb1 = sm[3], bb2 = sm[4];
+        const double det = a * c - b * b;
+        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+        const double scale = 1.0 / det;
+        const float nx = (float)(cx + c * scale * bb1 - b * scale * bb2);
+        const float ny = (float)(cy - b * scale * bb1 + a * scale * bb2);
+        const float ex = nx - cx, ey = ny - cy;
+        err = (double)(ex * ex + ey * ey);
+        cx = nx; cy = ny;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
+    } while (++iter < 30 && err > eps);
+    if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
+    if (lane == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }

@@ -55,6 +55,66 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restric
     }
 }
 
+// Throughput form of the same level (batched launches: many images per launch, the load/store instruction count is what
+// limits): one thread = 4 horizontally adjacent pixels, rows read as aligned 32-bit words.  Requires w % 4 == 0,
+// stride % 4 == 0 and 4-byte aligned rows (the host checks); identical integer arithmetic, identical output.
+__device__ __forceinline__ int pyr_dx(int a0, int b0, int c0, int a2, int b2, int c2) { return ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10); }
+__global__ __launch_bounds__(256) void pyr_level_kernel4(const uint8_t* __restrict__ src, int w, int h, int stride,
+                                                         uint8_t* __restrict__ copy_dst, short* __restrict__ dxy,
+                                                         uint8_t* __restrict__ down, int dw, int dh, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); if (copy_dst) copy_dst = zoff(copy_dst, bs); dxy = zoff(dxy, bs); if (down) down = zoff(down, bs);
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    const int xl = x > 0 ? x - 1 : 1, xr = x + 4 < w ? x + 4 : w - 2;      // reflect-101 neighbours of the 4-pixel run
+    const uint8_t *r0 = src + (size_t)ym * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yp * stride;
+    const uint32_t wa = *(const uint32_t*)(r0 + x), wb = *(const uint32_t*)(r1 + x), wc = *(const uint32_t*)(r2 + x);
+    int a[6], b[6], c[6];
+    a[0] = r0[xl]; b[0] = r1[xl]; c[0] = r2[xl]; a[5] = r0[xr]; b[5] = r1[xr]; c[5] = r2[xr];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k + 1] = (wa >> (8 * k)) & 255; b[k + 1] = (wb >> (8 * k)) & 255; c[k + 1] = (wc >> (8 * k)) & 255; }
+    int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dxv = pyr_dx(a[k], b[k], c[k], a[k + 2], b[k + 2], c[k + 2]);
+        const int dyv = ((c[k + 2] - a[k + 2]) + (c[k] - a[k])) * 3 + (c[k + 1] - a[k + 1]) * 10;
+        o[k] = (dxv & 0xffff) | (dyv << 16);
+    }
+    *(int4*)((int*)dxy + (size_t)y * w + x) = make_int4(o[0], o[1], o[2], o[3]);
+    if (copy_dst) *(uint32_t*)(copy_dst + (size_t)y * w + x) = wb;
+    if (down && x < dw && y < dh) {
+        // pyrDown pixels (x..x+3, y): source columns 2x-2 .. 2x+8, rows 2y-2 .. 2y+2
+        const bool inner = x > 0 && 2 * x + 8 < w;       // no reflection in x: three aligned words + one byte per row
+        int v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t* sr = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
+            int e[11];
+            if (inner) {
+                const uint32_t u0 = *(const uint32_t*)(sr + 2 * x - 4), u1 = *(const uint32_t*)(sr + 2 * x), u2 = *(const uint32_t*)(sr + 2 * x + 4);
+                e[0] = (u0 >> 16) & 255; e[1] = u0 >> 24;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { e[2 + q] = (u1 >> (8 * q)) & 255; e[6 + q] = (u2 >> (8 * q)) & 255; }
+                e[10] = sr[2 * x + 8];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 11; ++q) e[q] = sr[reflect101(2 * x - 2 + q, w)];
+            }
+            const int wk = (k == 0 || k == 4) ? 1 : ((k == 2) ? 6 : 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += wk * (e[2 * q + 2] * 6 + (e[2 * q + 1] + e[2 * q + 3]) * 4 + e[2 * q] + e[2 * q + 4]);
+        }
+        uint8_t* dr = down + (size_t)y * dw + x;
+        if (x + 3 < dw && (dw & 3) == 0) {
+            *(uint32_t*)dr = (uint32_t)(((v[0] + 128) >> 8) & 255) | ((uint32_t)(((v[1] + 128) >> 8) & 255) << 8) |
+                             ((uint32_t)(((v[2] + 128) >> 8) & 255) << 16) | ((uint32_t)(((v[3] + 128) >> 8) & 255) << 24);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (x + q < dw) dr[q] = (uint8_t)((v[q] + 128) >> 8);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ KLT
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 

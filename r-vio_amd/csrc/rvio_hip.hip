@@ -81,6 +81,7 @@ struct rvio_hip {
     bool slab_mode = false;
     int batch = 1;
     bool one_stream = false;
+    bool wide_px = false;            // throughput forms of the image kernels (several pixels per thread): batch handles of >= 8 instances
     bool front_end = true;           // a batch handle may carry the filter only
     bool det_in_slab = false;        // batch handle with front end: the detector's buffers are slab members too
     size_t img_bs = 0, imu_bs = 0;   // instance strides (bytes) of the image / IMU batch of the call in progress
@@ -259,6 +260,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     rvio_hip* h = new rvio_hip();
     h->cfg = *cfg; h->device = device; h->batch = batch;
     h->front_end = front_end; h->det_in_slab = front_end && batch > 1;
+    h->wide_px = batch >= 8;
+    if (const char* e = getenv("RVIO_WIDE_PX")) h->wide_px = atoi(e) != 0;   // A/B timing and tests (the two forms must agree bit for bit)
     fill_devcfg(cfg, &h->dc);
     const DevCfg& d = h->dc;
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
@@ -713,11 +716,17 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     HIPCHK(h, hipEventRecord(h->evD0, h->ts));
     HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
-    hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+    if (h->wide_px)
+        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+    else
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
-    hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+    if (h->wide_px)
+        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+    else
+        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
     return RVIO_OK;
@@ -733,8 +742,12 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, h->d_lut, src_bs, bs);
-        hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                           1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
+        if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
+            hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
+        else
+            hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
         d_img = h->d_eq; stride = d.W; src_bs = bs;
     }
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
@@ -745,9 +758,18 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     for (int l = 0; l < d.levels; ++l) {
         const bool last = (l + 1 == d.levels);
         const uint8_t* src = (l == 0) ? d_img : p.img[l];
-        hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
-                           (l == 0) ? stride : p.w[l], (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
-                           last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], (l == 0) ? src_bs : bs, bs);
+        const int sst = (l == 0) ? stride : p.w[l];
+        const size_t sbs = (l == 0) ? src_bs : bs;
+        // many images per launch: the 4-pixels-per-thread form (word-aligned rows required); one image: the 1-pixel form (lower latency)
+        const bool wide = h->wide_px && p.w[l] % 4 == 0 && sst % 4 == 0 && ((uintptr_t)src & 3) == 0 && sbs % 4 == 0;
+        if (wide)
+            hipLaunchKernelGGL(pyr_level_kernel4, dim3((p.w[l] / 4 + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
+                               sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
+                               last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
+        else
+            hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
+                               sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
+                               last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
     }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
