@@ -241,6 +241,43 @@ __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     d.cell_ci[slot] = ci;
 }
 
+// Throughput form (batched launches): one thread = 4 adjacent pixels read as one float4; nearly all of them fail the threshold,
+// so what is left per pixel is a quarter of a load.  Same test, same candidate records (their order in `cand` is as unordered
+// as before: it is an atomic append).  Requires W % 4 == 0.
+__global__ __launch_bounds__(DET_T) void nms_kernel4(DetDev d, size_t bs) {
+    det_shift(d, (size_t)blockIdx.z * bs);
+    const int W = d.W, H = d.H;
+    const int x4 = (blockIdx.x * DET_TW + (threadIdx.x & 63)) * 4, y = blockIdx.y * DET_TH + (threadIdx.x >> 6);
+    if (x4 >= W || y < 1 || y >= H - 1) return;
+    const float mx = ord2f(*d.maxkey);
+    const float thr = (float)((double)mx * d.quality);
+    const float4 q = *(const float4*)(d.eig + (size_t)y * W + x4);
+    const float vv[4] = {q.x, q.y, q.z, q.w};
+    float md = 0.f; int cell = 0, gw = 0, gh = 0;
+    bool geo = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x4 + k;
+        const float v = vv[k];
+        if (x < 1 || x >= W - 1 || !(v > thr) || v == 0.f) continue;
+        const float* e = d.eig + (size_t)y * W + x;
+        float m = v;
+        m = fmaxf(m, e[-W - 1]); m = fmaxf(m, e[-W]); m = fmaxf(m, e[-W + 1]);
+        m = fmaxf(m, e[-1]);     m = fmaxf(m, e[1]);
+        m = fmaxf(m, e[W - 1]);  m = fmaxf(m, e[W]);  m = fmaxf(m, e[W + 1]);
+        if (v != m) continue;
+        if (!geo) { det_geometry(d, &md, &cell, &gw, &gh); geo = true; }
+        const int idx = y * W + x;
+        const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)idx;
+        const int ci = atomicAdd(&d.counters[0], 1);
+        d.cand[ci] = key;
+        const int c = (y / cell) * gw + (x / cell);
+        const size_t slot = (size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1);
+        d.cell_ent[slot] = key;
+        d.cell_ci[slot] = ci;
+    }
+}
+
 #define NEIGH_T 1024
 #define NEIGH_BLOCKS 8
 // LDS of neigh_kernel's bucket build: keys 8 B, packed xy 4, cell 2, slot 2, order 2 per candidate + cell starts

@@ -720,7 +720,10 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     else
         hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
-    hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
+    if (h->wide_px && d.W % 4 == 0)
+        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->stream_d, h->det, bs);
+    else
+        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
     if (h->wide_px)
