@@ -210,6 +210,33 @@ def main():
             out["max_state_delta_sharded_vs_single_gpu"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(x_single))))
         if world > 1:
             out.pop("x_at_cpu_frames", None)
+    if sharded and not args.no_streams:
+        # beside the sharded figure: every rank ALSO runs the same K frames as an independent camera stream on its own handle (N cameras
+        # on N GPUs, no collective) — the weak-scaling counterpart of `value`, reported in its own object
+        h2 = hip.RvioHip(cfg, device=local_rank)
+        h2.initialize(wi, ai, ni)
+
+        def frame2(i):
+            h2.frame_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
+        for i in range(1 + W):
+            frame2(i)
+        h2.sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(1 + W, n_frames):
+            frame2(i)
+        h2.sync()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        h2.close()
+        out["independent_streams"] = {"value": world * K / el2, "unit": "frames/s", "scaling": "weak",
+                                      "note": "one camera stream per GPU, no collective; `value` above is ONE stream with its updater sharded over the GPUs"}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:

@@ -726,7 +726,8 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
-    if (h->wide_px)
+    static const bool sp1 = getenv("RVIO_SUBPIX1") != nullptr;   // A/B timing only
+    if (h->wide_px || sp1)
         hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     else
         hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
