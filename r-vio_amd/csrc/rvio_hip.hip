@@ -286,7 +286,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     bool need_tm_global = false;
     // (a batch handle keeps T in global memory as well: a third less LDS per feature workgroup = 8 instead of 5 resident per CU)
-    if (h->feat_lds > 150 * 1024 || (batch > 1 && !getenv("RVIO_BATCH_TM_LDS"))) {
+    if (h->feat_lds > 150 * 1024 || batch > 1) {
         h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, false) * sizeof(double);
         need_tm_global = true;
     }
@@ -346,8 +346,6 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 8; }
             else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 12; }
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
-            if (h->solve5_variant == 1 && getenv("RVIO_SOLVE_4WAVES")) { h->solve5_variant = 4; rpw = 16; nw = 4; }   // A/B timing only
-            if (h->solve5_variant == 1 && getenv("RVIO_SOLVE_16WAVES")) { h->solve5_variant = 5; rpw = 4; nw = 16; }   // A/B timing only
             if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
             if (h->solve5_variant) {
                 h->solve5_lds = (size_t)(nw * rpw) * (64 * nch + 1) * sizeof(double);
@@ -355,8 +353,6 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 12, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             }
         }
         const size_t c6t = (c6m + 15) / 16;
@@ -545,10 +541,6 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         hipLaunchKernelGGL((solve6_kernel<2, 12, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 3)
         hipLaunchKernelGGL((solve6_kernel<2, 16, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
-    else if (h->solve5_variant == 5)
-        hipLaunchKernelGGL((solve6_kernel<1, 4, 16>), dim3(1, 1, h->batch), dim3(1024), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
-    else if (h->solve5_variant == 4)
-        hipLaunchKernelGGL((solve6_kernel<1, 16, 4>), dim3(1, 1, h->batch), dim3(256), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (!h->solve_use_lds)
         hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->Mg);
     else if (h->solve_nch == 1)
@@ -726,8 +718,7 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
-    static const bool sp1 = getenv("RVIO_SUBPIX1") != nullptr;   // A/B timing only
-    if (h->wide_px || sp1)
+    if (h->wide_px)
         hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
     else
         hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);

@@ -101,16 +101,30 @@ def test_frame_tracks_dev_on_a_plain_handle_and_front_end_refused_on_a_batch(gpu
     h2.close()
 
 
-def test_batch_with_front_end_equals_plain_handles_bit_for_bit(gpu_required):
+@pytest.fixture(scope="module")
+def scenes3():
+    cfg = abi.config_named("B")                     # stock: CLAHE on, corners from the device detector
+    n_frames, k0 = 12, 60
+    seqs = [rv.synth.SynthSequence(cfg, duration=8.0, seed=s) for s in range(3)]
+    imgs = [[q.render(k0 + f) for q in seqs] for f in range(n_frames)]                     # [frame][scene][H][W]
+    imus = [[q.imu_between(k0 + f) for q in seqs] for f in range(n_frames)]
+    return cfg, seqs, imgs, imus
+
+
+@pytest.mark.parametrize("B", [3, 8])
+def test_batch_with_front_end_equals_plain_handles_bit_for_bit(gpu_required, scenes3, B):
     """rvio_hip_frame_batch_dev: B camera streams (different scenes) through CLAHE, detector, KLT, RANSAC, book-keeping and the filter
-    in one launch per stage — every instance must end in exactly the state of a plain handle fed its own stream"""
+    in one launch per stage — every instance must end in exactly the state of a plain handle fed its own stream.  B = 8 selects the
+    throughput forms of the image kernels (4 pixels per thread, one wave per corner): they must give the same bits as the 1-pixel forms
+    the plain handles run."""
     from rvio_amd import hip
     import torch
-    cfg = abi.config_named("B")                     # stock: CLAHE on, corners from the device detector
-    B, n_frames, k0 = 3, 12, 60
-    seqs = [rv.synth.SynthSequence(cfg, duration=8.0, seed=s) for s in range(B)]
-    imgs = np.stack([[q.render(k0 + f) for q in seqs] for f in range(n_frames)])          # [frame][instance][H][W]
-    imus = [[q.imu_between(k0 + f) for q in seqs] for f in range(n_frames)]
+    cfg, seqs3, imgs3, imus3 = scenes3
+    n_frames = len(imgs3)
+    pick = [b % 3 for b in range(B)]
+    seqs = [seqs3[k] for k in pick]
+    imgs = np.stack([[imgs3[f][k] for k in pick] for f in range(n_frames)])              # [frame][instance][H][W]
+    imus = [[imus3[f][k] for k in pick] for f in range(n_frames)]
     hb = hip.RvioHip(cfg, batch=B, front_end=True)
     hs = [hip.RvioHip(cfg) for _ in range(B)]
     for i, q in enumerate(seqs):
