@@ -170,7 +170,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
  * rvio_hip_frame_dev) accepts cand_xy == NULL: the library then runs
  * FeatureDetector::DetectWithSubPix (FeatureDetector.cc:55-75: goodFeaturesToTrack with
  * s*nMinDist, s = 1 on the first image / 2 on refills, + cornerSubPix) on the device, on the image
- * the tracker sees (after CLAHE), on its own stream beside pyramid/KLT/RANSAC.  A non-NULL list
+ * the tracker sees (after CLAHE), concurrently with pyramid/KLT/RANSAC (two streams).  A non-NULL list
  * replaces the detector (caller-side detection).  rvio_hip_get_corners copies the device
  * detector's last result out: refined corners, the corners before cornerSubPix and the
  * min-eigenvalue map (W*H floats); each pointer may be NULL. */

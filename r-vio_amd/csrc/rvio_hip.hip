@@ -58,7 +58,8 @@ struct rvio_hip {
     uint8_t* d_img = nullptr;
     DetDev det = {};                              // device detector (T7), allocated on first use
     bool det_ready = false, use_det = false;
-    hipStream_t stream_d = nullptr;               // detector stream: forks from / joins the tracker stream
+    hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
+    hipStream_t side = nullptr;                   // stream of pyramid / KLT / RANSAC of the call in progress (stream_d beside the detector, else ts)
     hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
     rvio_imu* hb_imu[2] = {nullptr, nullptr};
@@ -614,7 +615,7 @@ int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
 int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -700,30 +701,28 @@ static int detector_init(rvio_hip* h) {
     h->det_ready = true;
     return RVIO_OK;
 }
-// forks from the tracker stream (the image `img` is complete there), runs beside pyramid/KLT/RANSAC, joined before book-keeping
+// FeatureDetector::DetectWithSubPix on the tracker stream itself: it is the LONGEST chain of the front end (~130 us against ~90 us of
+// pyramid + KLT + RANSAC), so the shorter chain is the one that forks to the side stream and pays the cross-stream hops
 static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs) {
     const DevCfg& d = h->dc;
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
-    HIPCHK(h, hipEventRecord(h->evD0, h->ts));
-    HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
     if (h->wide_px)
-        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->ts, img, stride, h->det, src_bs, bs);
     else
-        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->ts, img, stride, h->det, src_bs, bs);
     if (h->wide_px && d.W % 4 == 0)
-        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->stream_d, h->det, bs);
+        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->ts, h->det, bs);
     else
-        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->stream_d, h->det, bs);
-    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->stream_d, h->det, bs);
-    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->stream_d, h->det, bs);
+        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->ts, h->det, bs);
+    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->ts, h->det, bs);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->ts, h->det, bs);
     if (h->wide_px)
-        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->ts, img, stride, h->det, src_bs, bs);
     else
-        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->stream_d, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->ts, img, stride, h->det, src_bs, bs);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->evD1, h->stream_d));
     return RVIO_OK;
 }
 
@@ -745,7 +744,12 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
                                1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
         d_img = h->d_eq; stride = d.W; src_bs = bs;
     }
+    h->side = h->ts;
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
+        // fork: pyramid / KLT / RANSAC go to the side stream (the image is complete on ts here), the detector stays on ts
+        HIPCHK(h, hipEventRecord(h->evD0, h->ts));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
+        h->side = h->stream_d;
         const int rc = detect_dev(h, d_img, stride, src_bs);
         if (rc != RVIO_OK) return rc;
     }
@@ -758,11 +762,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         // many images per launch: the 4-pixels-per-thread form (word-aligned rows required); one image: the 1-pixel form (lower latency)
         const bool wide = h->wide_px && p.w[l] % 4 == 0 && sst % 4 == 0 && ((uintptr_t)src & 3) == 0 && sbs % 4 == 0;
         if (wide)
-            hipLaunchKernelGGL(pyr_level_kernel4, dim3((p.w[l] / 4 + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
+            hipLaunchKernelGGL(pyr_level_kernel4, dim3((p.w[l] / 4 + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->side, src, p.w[l], p.h[l],
                                sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
                                last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
         else
-            hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->ts, src, p.w[l], p.h[l],
+            hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->side, src, p.w[l], p.h[l],
                                sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
                                last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
     }
@@ -774,9 +778,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
-    hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->ts, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
+    hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
-    if (h->use_det) {   // join the detector stream: its corner list replaces the caller's
+    if (h->use_det) {   // join the side stream (long finished when the detector is); the detector's corner list replaces the caller's
+        HIPCHK(h, hipEventRecord(h->evD1, h->side));
         HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
         hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->ts, h->dc, h->t, (const float*)h->det.xy, 0, (const int*)(h->det.counters + 2), bs);
     } else
@@ -794,7 +799,7 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
-    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->ts, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
                        h->t.tracked, h->t.status, h->slab_bytes);
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
@@ -832,6 +837,7 @@ int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned c
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->d_cand, cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(load_points_kernel, dim3(8), dim3(256), 0, h->stream, h->t.n_pts, h->d_in_xy, h->d_in_st, h->t.tracked, h->t.status);   // (single instance only)
     h->use_det = false;   // no image in this mode
+    h->side = h->ts;
     return post_klt_dev(h, h->d_imu, m, h->d_cand, nc);
 }
 
@@ -839,7 +845,7 @@ int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int3
     if (!h) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     const DevCfg& d = h->dc;
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
@@ -858,7 +864,7 @@ int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* his
     if (!h) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     const DevCfg& d = h->dc;
     int np = 0;
     HIPCHK(h, hipMemcpyAsync(&np, h->t.n_pts, sizeof np, hipMemcpyDeviceToHost, h->stream));
@@ -1044,7 +1050,7 @@ int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned c
 int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     if (!h || !info) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     FilterMeta m;
     HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
@@ -1076,6 +1082,8 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     if (!h->det_ready) { h->err = "the device detector has not run (pass a NULL corner list to track/frame)"; return RVIO_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream_d));
+    HIPCHK(h, hipStreamSynchronize(h->stream_t));   // the detector runs on the tracker stream of the call that used it
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     int cnt[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpy(cnt, h->det.counters, sizeof cnt, hipMemcpyDeviceToHost));
     if (n) *n = cnt[2];
@@ -1089,7 +1097,7 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
     if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     const PyrDev& p = h->pyr[h->pyr_cur];
     if (w) *w = p.w[level];
     if (hgt) *hgt = p.h[level];
@@ -1104,7 +1112,7 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     if (!h || n < 0 || n > h->dc.F) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     if (n > 0 && un_xy) HIPCHK(h, hipMemcpyAsync(un_xy, h->t.un2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
