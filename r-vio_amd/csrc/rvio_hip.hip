@@ -93,6 +93,10 @@ struct rvio_hip {
     double* d_pose = nullptr;
 };
 
+// The handle's events only order kernels of ONE device across its streams and are never inspected by the host (the host waits with
+// hipStreamSynchronize): no timing, and no system-scope fence when they are recorded — that fence writes the dirty L2 lines of the
+// recording queue back before the NEXT kernel of that queue may start (measured: a 35 us hole in the tracker stream per frame)
+static const unsigned kEvFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 #define HIPCHK(h, call)                                                                          \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
