@@ -41,6 +41,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RvioHipError("librvio_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(no CPU fallback exists for the product path)")
+        try:
+            import torch  # noqa: F401  when torch is used in the same process its bundled HIP runtime has to be loaded first
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rvio_hip_last_error.restype = C.c_char_p
         L.rvio_hip_last_error.argtypes = [C.c_void_p]
