@@ -231,6 +231,9 @@ int rvio_hip_create_batch(const rvio_config* cfg, int device, int n_instances, i
 int rvio_hip_batch_size(const rvio_hip* h);
 int rvio_hip_set_state_at(rvio_hip* h, int instance, const double* x, int xdim, const double* P, int d);
 int rvio_hip_get_state_at(rvio_hip* h, int instance, double* x, int* xdim, double* P, int* d);
+/* rvio_hip_get_tracker_points of one instance (batch handle with front end): Tracker::mvFeatsToTrack
+ * and the length of each feature's tracking history. */
+int rvio_hip_get_tracker_points_at(rvio_hip* h, int instance, int32_t* n, float* xy, int32_t* hist_len);
 /* The body of System::MonoVIO after Tracker::track (System.cc:263-365: propagate, update if
  * nCloneStates > mnMinCloneStates, augmentation + composition) on DEVICE-resident hand-over
  * tables, for all B instances of the handle (B = 1 for a plain handle):

@@ -864,28 +864,35 @@ int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int3
     return RVIO_OK;
 }
 
-int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len) {
-    if (!h) return RVIO_ERR_INVALID;
-    FRONT_END_ONLY(h);
+// mvFeatsToTrack and the length of each feature's tracking history, of one instance
+int rvio_hip_get_tracker_points_at(rvio_hip* h, int instance, int32_t* n, float* xy, int32_t* hist_len) {
+    if (!h || instance < 0 || instance >= h->batch) return RVIO_ERR_INVALID;
+    if (!h->front_end) { h->err = "this batch handle was created without its front end"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipSetDevice(h->device));
     { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
     const DevCfg& d = h->dc;
+    const size_t o = (size_t)instance * h->slab_bytes;
     int np = 0;
-    HIPCHK(h, hipMemcpyAsync(&np, h->t.n_pts, sizeof np, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&np, (char*)h->t.n_pts + o, sizeof np, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n) *n = np;
     if (np > 0) {
-        if (xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.feats, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, h->stream));
+        if (xy) HIPCHK(h, hipMemcpyAsync(xy, (char*)h->t.feats + o, sizeof(float) * 2 * np, hipMemcpyDeviceToHost, h->stream));
         if (hist_len) {
             std::vector<int> slot(np), hl(d.F);
-            HIPCHK(h, hipMemcpyAsync(slot.data(), h->t.slot, sizeof(int) * np, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(hl.data(), h->t.hist_len, sizeof(int) * d.F, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(slot.data(), (char*)h->t.slot + o, sizeof(int) * np, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(hl.data(), (char*)h->t.hist_len + o, sizeof(int) * d.F, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             for (int i = 0; i < np; ++i) hist_len[i] = hl[slot[i]];
         }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
+}
+int rvio_hip_get_tracker_points(rvio_hip* h, int32_t* n, float* xy, int32_t* hist_len) {
+    if (!h) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
+    return rvio_hip_get_tracker_points_at(h, 0, n, xy, hist_len);
 }
 
 // ------------------------------------------------------------------ whole frame (System.cc:253-367)

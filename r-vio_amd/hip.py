@@ -23,7 +23,7 @@ SYMBOLS = [
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
     "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
-    "rvio_hip_frame_batch_dev",
+    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at",
 ]
 
 _LIB = None
@@ -318,6 +318,13 @@ class RvioHip:
         n = C.c_int32(0)
         self._ck(self.L.rvio_hip_get_tracks(self.h, C.byref(n), _p(types, up), _p(lens, ip), _p(meas, fp)), "get_tracks")
         return types[: n.value].copy(), lens[: n.value].copy(), meas[: n.value].copy()
+
+    def get_points_at(self, i):
+        F = self.cfg.n_features
+        xy, hl = np.zeros((F, 2), np.float32), np.zeros(F, np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.rvio_hip_get_tracker_points_at(self.h, int(i), C.byref(n), _p(xy, fp), _p(hl, ip)), "get_tracker_points_at")
+        return xy[: n.value].copy(), hl[: n.value].copy()
 
     def get_points(self):
         F = self.cfg.n_features

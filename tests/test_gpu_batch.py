@@ -153,7 +153,63 @@ def test_batch_with_front_end_equals_plain_handles_bit_for_bit(gpu_required, sce
         xb, Pb = hs[i].get_state()
         assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), i
         n_upd += hs[i].frame_info()["updated"]
+        pa, la = hb.get_points_at(i)
+        pb, lb = hs[i].get_points()
+        assert np.array_equal(pa, pb) and np.array_equal(la, lb), i
     assert not np.array_equal(hb.get_state_at(0)[0], hb.get_state_at(1)[0])      # the streams really differ
+    hb.close()
+    for h in hs:
+        h.close()
+
+
+@pytest.mark.parametrize("case", ["odd-750x481", "D-1920x1080"])
+def test_batch_front_end_other_image_sizes(gpu_required, case):
+    """the throughput forms need word-aligned rows: a width that is not a multiple of 4 must fall back to the 1-pixel forms kernel by
+    kernel (750 x 481: also a CLAHE grid that needs padding), and 1920 x 1080 / 800 features takes the detector's general path —
+    both bit-identical to plain handles"""
+    from rvio_amd import hip
+    import torch
+    if case.startswith("odd"):
+        cfg = abi.config_named("B", width=750, height=481)
+        n_frames = 5
+    else:
+        cfg = abi.config_named("D")
+        n_frames = 3
+    B, k0 = 8, 60
+    seqs2 = [rv.synth.SynthSequence(cfg, duration=5.0, seed=s) for s in range(2)]
+    imgs2 = [[q.render(k0 + f) for q in seqs2] for f in range(n_frames)]
+    imus2 = [[q.imu_between(k0 + f) for q in seqs2] for f in range(n_frames)]
+    pick = [b % 2 for b in range(B)]
+    hb = hip.RvioHip(cfg, batch=B, front_end=True)
+    hs = [hip.RvioHip(cfg) for _ in range(2)]
+    for i, q in enumerate(seqs2):
+        w, a, n = q.init_from_static(38)
+        hs[i].initialize(w, a, n)
+        if i == 0:
+            hb.initialize(w, a, n)
+    for b in range(B):
+        hb.set_state_at(b, *hs[pick[b]].get_state())
+    keep = []
+    for f in range(n_frames):
+        m = len(imus2[f][0])
+        assert len(imus2[f][1]) == m
+        d_img = torch.from_numpy(np.stack([imgs2[f][k] for k in pick])).cuda()
+        d_imu = torch.from_numpy(np.stack([imus2[f][k] for k in pick]).view(np.uint8).reshape(B, -1)).cuda()
+        keep += [d_img, d_imu]
+        torch.cuda.synchronize()
+        hb.frame_batch_dev(d_img.data_ptr(), cfg.width, cfg.width * cfg.height, d_imu.data_ptr(), m, m)
+        for i in range(2):
+            hs[i].frame_dev(d_img[i].data_ptr(), cfg.width, d_imu[i].data_ptr(), m, 0, 0)
+    hb.sync()
+    for i in range(2):
+        hs[i].sync()
+    for b in range(B):
+        xa, Pa = hb.get_state_at(b)
+        xb, Pb = hs[pick[b]].get_state()
+        assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), (case, b)
+        pa, la = hb.get_points_at(b)                     # the tracker's feature list and history lengths (the window is still too short
+        pb, lb = hs[pick[b]].get_points()                # for an update after these few frames, so the states alone would not see the tracker)
+        assert len(pa) > 100 and np.array_equal(pa, pb) and np.array_equal(la, lb), (case, b)
     hb.close()
     for h in hs:
         h.close()
