@@ -415,7 +415,7 @@ def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni,
     h.close()
     return {"value": (n - n_warm) / el, "unit": "frames/s",
             "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + (0 if cand_arr is None else cand_arr[0].nbytes)),
-            "note": "pageable host memory, hipMemcpyAsync on the tracker stream"}
+            "note": "caller's pageable buffers, packed into the library's pinned ring on the host, asynchronous H2D on the tracker stream"}
 
 
 def filter_flops(cfg, n, lens, types, m):

@@ -191,10 +191,10 @@ int rvio_hip_update_tracked(rvio_hip* h);
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
                        const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
 /* The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253-258
- * (pImageData->Image, the IMU list of the frame) plus the detector's corners.  The copies are
- * enqueued on the tracker stream (staging double-buffered by frame parity) and overlap the
- * previous frame's filter work.  Pageable buffers are consumed before the call returns;
- * pinned buffers must stay valid until two further frames or rvio_hip_sync. */
+ * (pImageData->Image, the IMU list of the frame) plus the detector's corners.  The caller's
+ * buffers are packed into a pinned ring on the host and consumed before the call returns; the
+ * H2D copies then run asynchronously on the tracker stream (device staging double-buffered by
+ * frame parity) and overlap the previous frame's filter work. */
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride,
                    const rvio_imu* imu, int m, const float* cand_xy, int n_cand);
 /* The pipelined frame split open for callers that run the update themselves (the feature-sharded

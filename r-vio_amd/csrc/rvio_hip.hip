@@ -64,6 +64,12 @@ struct rvio_hip {
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
     rvio_imu* hb_imu[2] = {nullptr, nullptr};
     float* hb_cand[2] = {nullptr, nullptr};
+    // pinned host ring of rvio_hip_frame: the caller's (pageable) buffers are packed into it on the host, the H2D copies then run
+    // asynchronously from pinned memory.  Slot s may be refilled once evPin[s] (recorded behind its copies) has completed.
+    static const int kPin = 3;
+    uint8_t* pin[kPin] = {nullptr, nullptr, nullptr};
+    hipEvent_t evPin[kPin] = {nullptr, nullptr, nullptr};
+    size_t pin_img = 0, pin_imu = 0, pin_bytes = 0;
     uint8_t *d_eq = nullptr, *d_lut = nullptr;   // CLAHE output image and tile LUTs (enable_equalizer)
     int cl_tx = 0, cl_ty = 0, cl_tw = 0, cl_th = 0, cl_clip = 0;
     float cl_scale = 0.f;
@@ -384,6 +390,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) hipFree(p);
+    for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); }
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
@@ -1041,13 +1048,31 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
             DALLOC(h, h->hb_cand[k], (size_t)2 * h->dc.F);
             HIPCHK(h, hipStreamSynchronize(h->stream));   // DALLOC clears on the filter stream
         }
+    const size_t npx = (size_t)h->dc.W * h->dc.H;
+    if (!h->pin[0]) {
+        h->pin_img = 0; h->pin_imu = (npx + 255) & ~(size_t)255;
+        const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
+        h->pin_bytes = pin_cand + sizeof(float) * 2 * h->dc.F;
+        for (int k = 0; k < rvio_hip::kPin; ++k) {
+            HIPCHK(h, hipHostMalloc((void**)&h->pin[k], h->pin_bytes, hipHostMallocDefault));
+            HIPCHK(h, hipEventCreateWithFlags(&h->evPin[k], kEvFlags));
+        }
+    }
     const int b = (int)(h->frame_no & 1);
+    const int ps = (int)(h->frame_no % rvio_hip::kPin);
+    uint8_t* pp = h->pin[ps];
+    const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
+    HIPCHK(h, hipEventSynchronize(h->evPin[ps]));   // the copies issued from this slot three frames ago are done (no-op before its first use)
+    for (int y = 0; y < h->dc.H; ++y) std::memcpy(pp + (size_t)y * h->dc.W, img + (size_t)y * stride, (size_t)h->dc.W);
+    if (m > 0) std::memcpy(pp + h->pin_imu, imu, sizeof(rvio_imu) * m);
+    if (nc > 0) std::memcpy(pp + pin_cand, cand_xy, sizeof(float) * 2 * nc);
     if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
     else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
+    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
     HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
-    HIPCHK(h, hipMemcpy2DAsync(h->hb_img[b], h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream_t));
-    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], cand_xy, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
+    HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, h->stream_t));
+    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], pp + pin_cand, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
+    HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_t));
     return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
