@@ -249,7 +249,10 @@ def main():
         if args.batch:
             out["batched_filter"] = batched_filter_leg(cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
+            _CFG_NAME[0] = args.config
             out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
+            if _MULTI[0] is not None:
+                out["cpu_baseline_multicore"] = _MULTI[0]
             if xs_cpu is not None and "x_at_cpu_frames" in out:
                 xg = _qfix(out.pop("x_at_cpu_frames"))
                 out["max_state_delta_vs_cpu"] = float(np.max(np.abs(xg - _qfix(xs_cpu[0]))))
@@ -586,6 +589,10 @@ def batched_streams_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=12, n_timed
             "algorithmic_MB_per_frame_klt_chain": by_klt / 1e6, "sizes": res}
 
 
+_CFG_NAME = ["B"]
+_MULTI = [None]
+
+
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):
     """The CPU oracle (oracle/liborc.so, -O3, 1 core) on the first n frames of the same sequence."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -606,6 +613,28 @@ def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, n
     for i in range(n):
         s2.frame(imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]], img=imgs[i])
     xs = (xs_lit, s2.get_state()[0])
+    multi = None
+    if cand_arr is None:   # secondary figure: the same sources with their OpenMP loops active, all host cores, in a child process
+        import subprocess
+        import tempfile
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(8, cores))     # SURVEY.md 8d brackets OpenCV's threading with 8 host cores; more threads only add fork/join cost here
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "in.npz")
+                np.savez(f, config=_CFG_NAME[0], equalizer=int(cfg.enable_equalizer), imgs=imgs[:n], imu=imu_arr[:n].view(np.uint8), imu_cnt=imu_cnt[:n],
+                         wi=np.asarray(wi, float), ai=np.asarray(ai, float), ni=int(ni))
+                env = dict(os.environ, ORC_LIB="liborc_omp.so", OMP_NUM_THREADS=str(cores), OMP_WAIT_POLICY="passive")
+                r = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_omp.py"), f], env=env, timeout=120).decode().strip().splitlines()[-1])
+            multi = {"value": r["value"], "unit": "frames/s", "cores": cores, "kind": "port",
+                     "sample": "the same %d frames, oracle/liborc_omp.so (image rows, CLAHE tiles, KLT features and cornerSubPix corners in parallel)" % n,
+                     "same_state_as_single_thread": bool(np.array_equal(np.array(r["x"]), xs_lit))}
+        except Exception as e:   # the baseline is a reported extra: never fail the bench line over it
+            multi = {"error": repr(e)[:200]}
+    _MULTI[0] = multi
     return ({"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
              "sample": "first %d frames of the same synthetic sequence, oracle/liborc.so (g++ -O3, single thread); "
                        "p50 ms: track %.3f propagate %.3f update %.3f augment+compose %.3f"

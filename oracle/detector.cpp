@@ -36,11 +36,13 @@ void min_eig_map(const uint8_t* src, int w, int h, int stride, float* eig) {
     // source with a 1-px reflected frame, as float
     const int pw = w + 2;
     std::vector<float> s((size_t)pw * (h + 2));
+#pragma omp parallel for schedule(static)
     for (int y = -1; y <= h; ++y)
         for (int x = -1; x <= w; ++x) s[(size_t)(y + 1) * pw + (x + 1)] = (float)src[(size_t)refl(y, h) * stride + refl(x, w)];
     // the three product planes, with a 1-px reflected frame (boxFilter's border), as double
     std::vector<double> pr[3];
     for (auto& p : pr) p.assign((size_t)pw * (h + 2), 0.0);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y) {
         const float* r0 = &s[(size_t)y * pw + 1];
         const float* r1 = r0 + pw;
@@ -59,6 +61,7 @@ void min_eig_map(const uint8_t* src, int w, int h, int stride, float* eig) {
         for (int y = 0; y < h; ++y) { p[(size_t)(y + 1) * pw] = p[(size_t)(y + 1) * pw + 1 + refl(-1, w)]; p[(size_t)(y + 1) * pw + w + 1] = p[(size_t)(y + 1) * pw + 1 + refl(w, w)]; }
         for (int x = 0; x < pw; ++x) { p[x] = p[(size_t)(1 + refl(-1, h)) * pw + x]; p[(size_t)(h + 1) * pw + x] = p[(size_t)(1 + refl(h, h)) * pw + x]; }
     }
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             float cov[3];
@@ -153,7 +156,7 @@ void rect_subpix(const uint8_t* src, int w, int h, int stride, float cx, float c
 // same way.  Written for window half-sizes <= 7 (<= 15 rows / columns).
 void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps) {
     const int ww = 2 * win + 1, pw = ww + 2;
-    std::vector<float> mask((size_t)ww * ww), patch((size_t)pw * pw);
+    std::vector<float> mask((size_t)ww * ww);
     for (int i = 0; i < ww; ++i) {
         const float y = (float)(i - win) / (float)win;
         const float vy = std::exp(-y * y);
@@ -164,7 +167,10 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
     }
     eps *= eps;
     max_iter = std::min(std::max(max_iter, 1), 100);
+    // (the points are independent: the multi-core build of the oracle, liborc_omp.so, runs them in parallel; results are identical)
+#pragma omp parallel for schedule(dynamic, 4)
     for (int p = 0; p < n; ++p) {
+        std::vector<float> patch((size_t)pw * pw);
         const float tx = pts[2 * p], ty = pts[2 * p + 1];
         float cx = tx, cy = ty;
         int iter = 0;

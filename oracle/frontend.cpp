@@ -71,8 +71,9 @@ struct Pyramid { std::vector<Level> lv; };
 
 void pyr_down(const uint8_t* src, int w, int h, int stride, uint8_t* dst) {
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    std::vector<int> rows((size_t)5 * dw);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; ++y) {
+        std::vector<int> rows((size_t)5 * dw);
         for (int k = 0; k < 5; ++k) {
             const uint8_t* s = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
             int* r = &rows[(size_t)k * dw];
@@ -89,8 +90,9 @@ void pyr_down(const uint8_t* src, int w, int h, int stride, uint8_t* dst) {
 }
 
 void scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy) {
-    std::vector<int> t0(w + 2), t1(w + 2);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y) {
+        std::vector<int> t0(w + 2), t1(w + 2);
         const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : (h > 1 ? 1 : 0)) * stride;
         const uint8_t* r1 = src + (size_t)y * stride;
         const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0)) * stride;
@@ -121,6 +123,7 @@ void clahe_apply(const uint8_t* src, int w, int h, int stride, double clip, int 
     int clip_limit = 0;
     if (clip > 0.0) { clip_limit = (int)(clip * area / 256); clip_limit = std::max(clip_limit, 1); }
     std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+#pragma omp parallel for schedule(dynamic, 1)
     for (int t = 0; t < tiles_x * tiles_y; ++t) {
         const int ty = t / tiles_x, tx = t % tiles_x;
         int hist[256] = {0};
@@ -148,6 +151,7 @@ void clahe_apply(const uint8_t* src, int w, int h, int stride, double clip, int 
         }
     }
     const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y) {
         const float tyf = (float)y * inv_th - 0.5f;
         int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
@@ -440,6 +444,7 @@ void orc_scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy) { sc
 void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
              const float* pts, int n, float* out, unsigned char* status) {
     Pyramid P = build_pyramid(prev, w, h, stride, true), N = build_pyramid(next, w, h, stride, false);
+#pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < n; ++i) lk_point(P, N, pts[2 * i], pts[2 * i + 1], &out[2 * i], &out[2 * i + 1], &status[i]);
 }
 
@@ -505,8 +510,10 @@ static void track_impl(orc_tracker* T, const uint8_t* img, int stride, const flo
         fi.n_tracked_in = N;
         std::vector<float> tracked(2 * N), un(2 * N);
         std::vector<unsigned char> flag(N);
-        if (img) for (int i = 0; i < N; ++i) lk_point(T->last, cur, T->feats[i].x, T->feats[i].y, &tracked[2 * i], &tracked[2 * i + 1], &flag[i]);
-        else for (int i = 0; i < N; ++i) { tracked[2 * i] = given_xy[2 * i]; tracked[2 * i + 1] = given_xy[2 * i + 1]; flag[i] = given_flag[i]; }
+        if (img) {
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int i = 0; i < N; ++i) lk_point(T->last, cur, T->feats[i].x, T->feats[i].y, &tracked[2 * i], &tracked[2 * i + 1], &flag[i]);
+        } else for (int i = 0; i < N; ++i) { tracked[2 * i] = given_xy[2 * i]; tracked[2 * i + 1] = given_xy[2 * i + 1]; flag[i] = given_flag[i]; }
         for (int i = 0; i < N; ++i) fi.n_klt_ok += flag[i] ? 1 : 0;
         undistort(&c, tracked.data(), N, un.data());  // all points incl. status 0 (:252-253)
         std::vector<double> pts2(3 * N);

@@ -30,7 +30,8 @@ def _p(a, t):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ROOT, "oracle", "liborc.so")
+        # ORC_LIB=liborc_omp.so selects the multi-core build of the same sources (bench.py's secondary CPU baseline)
+        path = os.path.join(ROOT, "oracle", os.environ.get("ORC_LIB", "liborc.so"))
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         L = C.CDLL(path)
