@@ -102,7 +102,7 @@ struct rvio_hip {
 // The handle's events only order kernels of ONE device across its streams and are never inspected by the host (the host waits with
 // hipStreamSynchronize): no timing, and no system-scope fence when they are recorded — that fence writes the dirty L2 lines of the
 // recording queue back before the NEXT kernel of that queue may start (measured: a 35 us hole in the tracker stream per frame)
-static const unsigned kEvFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+static const unsigned kEvFlags = getenv("RVIO_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 #define HIPCHK(h, call)                                                                          \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
@@ -282,11 +282,17 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
     if (h->one_stream) h->stream_t = h->stream;
     else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
+    // the side stream is created here, right behind the other two: HIP deals its streams onto the hardware queues in creation order,
+    // so three streams created back to back land on three different queues
+    if (h->one_stream) h->stream_d = h->stream;
+    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
+    HIPCHK(h, hipEventCreateWithFlags(&h->evD1, kEvFlags));
     h->ts = h->stream;
     for (int b = 0; b < 2; ++b) {
-        HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], kEvFlags));
     }
     const size_t ldh = d.ldh;
     // launch geometry (decides two optional slab members)
@@ -705,10 +711,6 @@ static int detector_init(rvio_hip* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
     HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
-    if (h->one_stream) h->stream_d = h->stream;
-    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->evD0, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->evD1, hipEventDisableTiming));
     h->det_ready = true;
     return RVIO_OK;
 }
