@@ -201,20 +201,6 @@ def main():
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
     }
 
-    if rank == 0 and world == 1 and not args.no_streams:
-        # (first of the extra legs: a process normally owns ONE handle.  HIP multiplexes its streams onto 4 hardware queues in creation
-        # order; a handle created after dozens of other streams — the later legs — can find two of its three streams on one queue and
-        # loses their overlap: 2.3 k instead of 4.1 k frames/s were measured for this leg when it ran last)
-        out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
-    if rank == 0 and not args.no_latency:
-        # (also at N>1: the per-kernel roofline is a property of one GPU; the other ranks wait in the barrier below)
-        out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
-                                img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni, device=local_rank))
-        x_single = out.pop("x_final")
-        if sharded:   # the sharded updater against the same frames through the one-GPU updater (block sums in rank order: rounding only)
-            out["max_state_delta_sharded_vs_single_gpu"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(x_single))))
-        if world > 1:
-            out.pop("x_at_cpu_frames", None)
     if sharded and not args.no_streams:
         # beside the sharded figure: every rank ALSO runs the same K frames as an independent camera stream on its own handle (N cameras
         # on N GPUs, no collective) — the weak-scaling counterpart of `value`, reported in its own object
@@ -242,6 +228,20 @@ def main():
         h2.close()
         out["independent_streams"] = {"value": world * K / el2, "unit": "frames/s", "scaling": "weak",
                                       "note": "one camera stream per GPU, no collective; `value` above is ONE stream with its updater sharded over the GPUs"}
+    if rank == 0 and world == 1 and not args.no_streams:
+        # (first of the extra legs: a process normally owns ONE handle.  HIP multiplexes its streams onto 4 hardware queues in creation
+        # order; a handle created after dozens of other streams — the later legs — can find two of its three streams on one queue and
+        # loses their overlap: 2.3 k instead of 4.1 k frames/s were measured for this leg when it ran last)
+        out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
+    if rank == 0 and not args.no_latency:
+        # (also at N>1: the per-kernel roofline is a property of one GPU; the other ranks wait in the barrier below)
+        out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
+                                img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni, device=local_rank))
+        x_single = out.pop("x_final")
+        if sharded:   # the sharded updater against the same frames through the one-GPU updater (block sums in rank order: rounding only)
+            out["max_state_delta_sharded_vs_single_gpu"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(x_single))))
+        if world > 1:
+            out.pop("x_at_cpu_frames", None)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:
