@@ -39,11 +39,11 @@ __host__ __device__ inline size_t feat_lds_doubles(int max_len, int ldh, bool tm
     return n;
 }
 
-__global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
-                                  const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
-                                  int shard_rank, int shard_world,
-                                  double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
+__device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double* x, const double* P,
+                                                const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
+                                                int shard_rank, int shard_world,
+                                                double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Hstack = zoffi(Hstack, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
@@ -459,6 +459,15 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
         for (int e = tid; e < rr * ldh; e += T) out[e] = Hn[e];
     }
     DBG_T(40);
+}
+
+__global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
+                                  const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
+                                  int shard_rank, int shard_world,
+                                  double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
+    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Hstack, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
+                    tm_global, bs, bin);
 }
 
 // =============================================================== U7 compression, information form (reduction stage)

@@ -23,8 +23,8 @@ __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
 #define PROP3_CH 16
 struct Prop3Sample { double dR[9], up[3], uv[3], w[3], dt, Rk[9], vk[3], gk[3]; };
 
-__global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
-                                                         double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+__device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                               double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
     meta = zoff(meta, bs); x = zoff(x, bs); P = zoff(P, bs); imu = zoff(imu, imu_bs);
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
@@ -188,6 +188,24 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
             P[(24 + c) + (size_t)(9 + r) * ld] = acc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                                         double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+    propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+}
+
+// PreIntegrator::propagate and the per-feature stage of Updater::update in ONE launch (single instance, pipelined whole-frame path):
+// U1-U5 read only the clone states and P[24:,24:], which propagation does not touch (it rewrites the IMU state, P[0:24,0:24] and the
+// cross terms P[0:24,24:] / P[24:,0:24]), so the two are independent; the last workgroup IS propagate_kernel3, the others ARE
+// feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
+__global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
+                                                        const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
+                                                        double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                                        double* pfinv_out, double* tm_global, BatchIn bin,
+                                                        FilterMeta* meta, const rvio_imu* imu, int m) {
+    if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
+    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Hstack, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition

@@ -87,6 +87,9 @@ struct rvio_hip {
     size_t slab_off = 0, slab_bytes = 0;
     bool slab_mode = false;
     int batch = 1;
+    const rvio_imu* fuse_imu = nullptr;   // whole-frame path: propagate of this frame rides in the per-feature launch (feat_prop_kernel)
+    int fuse_m = -1;                      // >= 0 while such a propagate is pending
+    bool fuse_ok = false;
     bool one_stream = false;
     bool wide_px = false;            // throughput forms of the image kernels (several pixels per thread): batch handles of >= 8 instances
     bool front_end = true;           // a batch handle may carry the filter only
@@ -348,6 +351,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
+    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)((size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double))));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
@@ -539,6 +544,12 @@ static int update_local_dev(rvio_hip* h, int rank, int world) {
     const int n = h->n_clones_host;
     const size_t bs = h->slab_bytes;
     const int B = h->batch;
+    if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
+        hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + 1), dim3(256), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                           h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                           h->meta, h->fuse_imu, h->fuse_m);
+        h->fuse_m = -1;
+    } else
     hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global, bs, h->bin);
@@ -974,7 +985,12 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg_host ? now() : 0;
     if (staged) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));   // the IMU batch was copied on the tracker stream
-    int rc = propagate_dev(h, d_imu, m, h->imu_bs);                          // filter stream, right behind augment/compose(k-1)
+    // propagate: with an update in this frame (and nobody sequencing the update from outside) it rides in the per-feature launch,
+    // otherwise it goes to the filter stream right behind augment/compose(k-1)
+    const bool fuse = h->fuse_ok && !begin_only && h->n_clones_host > h->cfg.min_track_len - 1;
+    int rc = RVIO_OK;
+    if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }
+    else rc = propagate_dev(h, d_imu, m, h->imu_bs);
     if (rc != RVIO_OK) return rc;
     const double t1 = dbg_host ? now() : 0;
     h->ts = h->stream_t;
