@@ -3,7 +3,7 @@
 //
 //   propagate_kernel     PreIntegrator::propagate          PreIntegrator.cc:51-194
 //   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455
-//   gram_kernel / gram_reduce_kernel / block_sum_kernel
+//   (epilogue of feat_build_kernel) / gram_reduce_kernel / block_sum_kernel
 //                        measurement compression (Updater.cc:469-536) in information
 //                        form [A|b] = Hw^T [Hw | r]   
 //   gemm_f64_kernel      FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
@@ -42,11 +42,11 @@ __host__ __device__ inline size_t feat_lds_doubles(int max_len, int ldh, bool tm
 __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double* x, const double* P,
                                                 const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                 int shard_rank, int shard_world,
-                                                double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                                double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                 double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
-    x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Hstack = zoffi(Hstack, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
+    x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
     ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
     if (tm_global) tm_global = zoffi(tm_global, bs, bi.z);
     n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, bi.z); types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z); meas = zoffi(meas, bin.meas, bi.z);
@@ -455,8 +455,31 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     const bool accept = gam < kChi2Dev[rr - 1];
     if (tid == 0) { acc_out[f] = accept ? 1 : 0; ndof_out[f] = rr; gamma_out[f] = gam; nrows_out[f] = accept ? rr : 0; }
     if (accept) {
-        double* out = Hstack + (size_t)f * rhomax * ldh;
-        for (int e = tid; e < rr * ldh; e += T) out[e] = Hn[e];
+        // this feature's share of the information block, G_f = Hn^T [Hn | r] (rows 0..c6-1, columns 0..c6), on the FP64 matrix cores
+        // straight from the LDS copy of Hn:  A[i = p][k = row] = Hn[row][p0 + i],  B[k = row][j = q] = Hn[row][q0 + j]; rows >= rr are zero.
+        // gram_reduce_kernel adds the accepted features' shares in feature order (Updater.cc:469-536 in information form).
+        double* out = Gshare + (size_t)f * ldh * ldh;
+        const int gw = tid >> 6, gl = tid & 63, gi = gl & 15, gk = gl >> 4, nw = T >> 6;
+        const int nqt = (c6 + 1 + 15) / 16, ntile = ((c6 + 15) / 16) * nqt;
+        for (int tile = gw; tile < ntile; tile += nw) {
+            const int p0 = (tile / nqt) * 16, q0 = (tile % nqt) * 16;
+            const bool pok = p0 + gi < c6, qok = q0 + gi <= c6;
+            d4 acc = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < rr; k0 += 4) {
+                const int row = k0 + gk;
+                const double* hr = Hn + (size_t)(row < rr ? row : 0) * ldh;
+                const double a = (row < rr && pok) ? hr[p0 + gi] : 0.0;
+                const double b = (row < rr && qok) ? hr[q0 + gi] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            if (qok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pp = p0 + gk + 4 * r;
+                    if (pp < c6) out[(size_t)pp * ldh + q0 + gi] = acc[r];
+                }
+            }
+        }
     }
     DBG_T(40);
 }
@@ -464,46 +487,54 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
 __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
-                                  double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                  double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
-    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Hstack, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
+    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
                     tm_global, bs, bin);
 }
 
 // =============================================================== U7 compression, information form (reduction stage)
-// partial[g][p][q] = sum over the rows of feature group g of H[row][p] * H[row][q], q = 0..c6 (column c6 is the residual -> b),
-// is produced by gram_mfma_kernel (filter_kernels2.hip); the kernels below reduce it.
-// feature groups of the Gram stage (gram_mfma_kernel in filter_kernels2.hip): GRAM2_FG consecutive feature slots
-#define GRAM2_FG 8
-#define GRAM_MAX_GROUPS 256
-__device__ __forceinline__ int gram_group_rows(const int* nrows, int g, int Fu) {
-    int o = 0;
-#pragma unroll
-    for (int ff = 0; ff < GRAM2_FG; ++ff) { const int f = g * GRAM2_FG + ff; o += (f < Fu) ? nrows[f] : 0; }
-    return o;
-}
-// block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the all-gather payload of the sharded updater
-__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, int n_groups,
-                                                          const int* nrows, double* block, size_t bs) {
+// partial[f][p][q] = sum over the rows of accepted feature f of H[row][p] * H[row][q], q = 0..c6 (column c6 is the residual -> b),
+// is produced by the epilogue of feat_build_kernel; the kernels below reduce it.
+#define GRAM_MAX_FEATS 2048
+// block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the sum of the accepted features' shares G_f (written by feat_build_kernel to
+// partial[f]) in ascending feature order — deterministic; also the all-gather payload of the sharded updater
+__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, const int* nrows, double* block, size_t bs) {
     const BatchIdx bi = batch_plain();
     partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z);
-    const int c6 = 6 * n, ldh = cfg.ldh;
+    const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
-    // groups without a stacked row were not written by gram_mfma_kernel (they would add +0.0): skip them
-    __shared__ unsigned char s_ne[GRAM_MAX_GROUPS];
-    for (int g = threadIdx.x; g < n_groups; g += 256) s_ne[g] = gram_group_rows(nrows, g, cfg.Fu) > 0;
+    // ascending list of the accepted features (wave ballots: order-preserving compaction)
+    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int e = bi.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    for (int f0 = 0; f0 < Fu; f0 += 256) {
+        const int f = f0 + tid;
+        const bool flag = f < Fu && nrows[f] > 0;
+        const unsigned long long mask = __ballot(flag);
+        if (lane == 0) s_wtot[wave] = __popcll(mask);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w];
+        if (flag) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = f;
+        __syncthreads();
+        if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        __syncthreads();
+    }
+    const int ng = s_base;
+    const size_t gs = (size_t)ldh * ldh;
+    for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
         double acc = 0;
-        if (q <= c6) for (int g = 0; g < n_groups; ++g) if (s_ne[g]) acc += partial[(size_t)g * ldh * ldh + e];
+        if (q <= c6) for (int t = 0; t < ng; ++t) acc += partial[(size_t)s_list[t] * gs + e];
         block[e] = acc;
     }
-    if (bi.x == 0 && threadIdx.x < 64) {
+    if (bi.x == 0 && tid < 64) {
         int good = 0, rows = 0;
-        for (int f = threadIdx.x; f < cfg.Fu; f += 64) { const int r = nrows[f]; if (r > 0) { good++; rows += r; } }
+        for (int f = tid; f < Fu; f += 64) { const int r = nrows[f]; if (r > 0) { good++; rows += r; } }
         good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows);
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             block[(size_t)cfg.ldh * (cfg.ldh - 1)] = (double)good;
             block[(size_t)cfg.ldh * (cfg.ldh - 1) + 1] = (double)rows;
         }

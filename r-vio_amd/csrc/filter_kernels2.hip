@@ -201,11 +201,11 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
 __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
-                                                        double* Hstack, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
+                                                        double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
                                                         FilterMeta* meta, const rvio_imu* imu, int m) {
     if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
-    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Hstack, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin);
+    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition
@@ -309,76 +309,6 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
                 }
             }
             P_out[(size_t)a + (size_t)b * ld] = v;
-        }
-    }
-}
-
-// =============================================================== U7 compression, information form (v2, FP64 MFMA)
-// partial[g] = sum over the stacked rows of feature group g of H^T [H | r]  (rows 0..c6-1, cols 0..c6).
-// grid = (groups of GRAM2_FG features, 16-row tiles of p); 4 waves, wave w owns the 16-column q-tiles w, w+4, w+8.
-// Rows are staged through LDS 32 at a time (coalesced), then v_mfma_f64_16x16x4_f64 with
-//   A[i = p][k = row] = H[row][p0+i],  B[k = row][j = q] = H[row][q].
-#define GRAM2_RB 64
-__global__ __launch_bounds__(256) void gram_mfma_kernel(DevCfg cfg, int n, const double* __restrict__ Hstack, const int* __restrict__ nrows,
-                                                        double* __restrict__ partial, size_t bs) {
-    extern __shared__ __align__(16) double hs[];   // [GRAM2_RB][ldh + 1]
-    const BatchIdx bi = batch_plain();
-    Hstack = zoffi(Hstack, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); partial = zoffi(partial, bs, bi.z);
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    const int c6 = 6 * n, ldh = cfg.ldh, rhomax = cfg.rho_max, lds = ldh + 1;
-    const int g = bi.x, p0 = bi.y * 16;
-    if (p0 >= c6) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int ntile = (c6 + 1 + 15) / 16;
-    d4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    // compact row list of the group: rows [off[ff], off[ff+1]) belong to feature g*FG+ff
-    __shared__ int s_off[GRAM2_FG + 1];
-    if (tid == 0) {
-        int o = 0;
-        for (int ff = 0; ff < GRAM2_FG; ++ff) { s_off[ff] = o; const int f = g * GRAM2_FG + ff; o += (f < cfg.Fu) ? nrows[f] : 0; }
-        s_off[GRAM2_FG] = o;
-    }
-    __syncthreads();
-    const int R = s_off[GRAM2_FG];
-    if (R == 0) return;   // nothing stacked in this group: gram_reduce_kernel skips it as well (same test)
-    for (int r0 = 0; r0 < R; r0 += GRAM2_RB) {
-        if (r0 > 0) __syncthreads();
-        // stage GRAM2_RB rows: wave w takes rows w, w+4, ...; lanes walk the columns (coalesced, no div/mod)
-        for (int r = wave; r < GRAM2_RB; r += 4) {
-            const int gr = r0 + r;
-            int ff = 0;
-#pragma unroll
-            for (int t = 1; t < GRAM2_FG; ++t) ff += (gr >= s_off[t]) ? 1 : 0;
-            const bool ok = gr < R;
-            const double* Hrow = Hstack + ((size_t)(g * GRAM2_FG + ff) * rhomax + (gr - s_off[ff])) * ldh;
-            for (int c = lane; c < ldh; c += 64) hs[r * lds + c] = ok ? Hrow[c] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int ks = 0; ks < GRAM2_RB / 4; ++ks) {
-            const double a = hs[(4 * ks + lk) * lds + p0 + li];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int jt = wave + 4 * t;
-                if (jt < ntile) {
-                    const int q = jt * 16 + li;
-                    const double b = (q < ldh) ? hs[(4 * ks + lk) * lds + q] : 0.0;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    }
-    double* out = partial + (size_t)g * ldh * ldh;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int jt = wave + 4 * t;
-        if (jt < ntile) {
-            const int q = jt * 16 + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = p0 + lk + 4 * r;
-                if (p < c6 && q <= c6) out[(size_t)p * ldh + q] = acc[t][r];
-            }
         }
     }
 }

@@ -44,10 +44,10 @@ struct rvio_hip {
     int img_count = 0;      // host mirror of nImageCountAfterInit (data-independent)
     int n_clones_host = 0;  // host mirror of nCloneStates (data-independent)
     // update scratch
-    double *Hstack = nullptr, *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
+    double *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
            *Pt1 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
     int *nrows = nullptr, *acc = nullptr, *ndof = nullptr;
-    int n_groups = 0, feat_threads = 64;
+    int feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
@@ -210,8 +210,7 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     TrackerDev& t = h->t;
     DALLOC(h, h->meta, 1);
     for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
-    DALLOC(h, h->Hstack, (size_t)d.Fu * d.rho_max * ldh);
-    DALLOC(h, h->partial, (size_t)h->n_groups * ldh * ldh);
+    DALLOC(h, h->partial, (size_t)d.Fu * ldh * ldh);   // per-feature shares G_f = Hn^T [Hn | r] of the information block
     DALLOC(h, h->block, ldh * ldh);
     DALLOC(h, h->Ab, ldh * ldh);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
@@ -299,8 +298,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     }
     const size_t ldh = d.ldh;
     // launch geometry (decides two optional slab members)
-    h->n_groups = (d.Fu + GRAM2_FG - 1) / GRAM2_FG;
-    if (h->n_groups > GRAM_MAX_GROUPS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
+    if (d.Fu > GRAM_MAX_FEATS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
     if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
@@ -353,8 +351,6 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)gram_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double))));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
@@ -546,17 +542,15 @@ static int update_local_dev(rvio_hip* h, int rank, int world) {
     const int B = h->batch;
     if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
         hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + 1), dim3(256), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                           h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                           h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
                            h->meta, h->fuse_imu, h->fuse_m);
         h->fuse_m = -1;
     } else
     hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                       h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
+                       h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global, bs, h->bin);
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(h->n_groups, (6 * n + 15) / 16, B), dim3(256), (size_t)GRAM2_RB * (d.ldh + 1) * sizeof(double), h->stream,
-                       d, n, h->Hstack, h->nrows, h->partial, bs);
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), 0, h->stream, d, n,
-                       h->partial, h->n_groups, h->nrows, h->block, bs);
+                       h->partial, h->nrows, h->block, bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -1194,7 +1188,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
                                h->t.tracked, h->t.status, (size_t)0);
         } else {
             hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->Hstack, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin);
         }
     }
