@@ -23,7 +23,7 @@ struct DetDev {
     const int* first;        // Tracker's mbIsTheFirstImage (device)
     float* eig;              // W*H
     int* maxkey;             // ordered-int key of the image maximum
-    int* counters;           // [0] n candidates, [1] n accepted, [2] n output corners
+    int* counters;           // [0] n candidates, [1] n accepted
     int* cell_cnt;           // [cells at s=1]
     unsigned long long* cell_ent;   // bucketed candidate keys  [(W+cell)*(H+cell)]
     int* cell_ci;                   // ... and their index in `cand`
@@ -34,7 +34,8 @@ struct DetDev {
     unsigned long long* acc;        // accepted keys            [W*H]
     unsigned char* state;           // general path, per candidate: 1 undecided, 2 taken, 3 dropped
     float* raw_xy;           // goodFeaturesToTrack output [F][2]
-    float* xy;               // after cornerSubPix         [F][2]
+    float* xy;               // after cornerSubPix         [F][2]   (one of two buffers, by frame parity: see rvio_hip.hip)
+    int* n_out;              // number of output corners (same parity)
     const float* spmask;     // 15x15 Gaussian window of cornerSubPix (host-computed: expf is glibc's)
     int W, H, F;
     float min_dist;          // Tracker.nMinDist
@@ -46,7 +47,7 @@ struct DetDev {
 __device__ __forceinline__ void det_shift(DetDev& d, size_t off) {
     zmove(d.first, off); zmove(d.eig, off); zmove(d.maxkey, off); zmove(d.counters, off); zmove(d.cell_cnt, off); zmove(d.cell_ent, off);
     zmove(d.cell_ci, off); zmove(d.nb, off); zmove(d.nb_cnt, off); zmove(d.cand, off); zmove(d.acc, off); zmove(d.state, off);
-    zmove(d.raw_xy, off); zmove(d.xy, off);
+    zmove(d.raw_xy, off); zmove(d.xy, off); zmove(d.n_out, off);
 }
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : (b ^ 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
     }
     DBG_T(60);
     if (tid == 0) {
-        d.counters[2] = na < d.F ? na : d.F;
+        *d.n_out = na < d.F ? na : d.F;
         *d.maxkey = (int)0x80000000;                       // consumed by nms_kernel; ready for the next image
     }
 }
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
     __shared__ unsigned char reg[SP_RS * SP_RS];
     __shared__ double s_part[2][4][5];        // by iteration parity: one barrier per iteration
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = d.counters[2];
+    const int n = *d.n_out;
     if (p >= n) return;
     const int W = d.W, H = d.H;
     const float tx = d.raw_xy[2 * p], ty = d.raw_xy[2 * p + 1];
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel1(const uint8_t* __restrict
     __shared__ unsigned char regs[4][SP_RS * SP_RS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = blockIdx.x * 4 + wv;
-    const int n = d.counters[2];
+    const int n = *d.n_out;
     const bool act = p < n;
     const int W = d.W, H = d.H;
     unsigned char* reg = regs[wv];

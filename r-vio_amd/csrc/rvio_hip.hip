@@ -71,6 +71,14 @@ struct rvio_hip {
     hipEvent_t evPin[kPin] = {nullptr, nullptr, nullptr};
     size_t pin_img = 0, pin_imu = 0, pin_bytes = 0;
     uint8_t *d_eq = nullptr, *d_lut = nullptr;   // CLAHE output image and tile LUTs (enable_equalizer)
+    // Buffers the front end of frame k+1 would otherwise overwrite while book-keeping of frame k still reads them (run-ahead of the
+    // image chain on the pipelined path, see track_dev_impl): equalised image, detector corner list and its count, by frame parity
+    uint8_t* d_eq2[2] = {nullptr, nullptr};
+    float* det_xy2[2] = {nullptr, nullptr};
+    int* det_nout = nullptr;
+    int par = 0;                                  // parity of the call in progress / of the last call (getters)
+    hipStream_t tail = nullptr;                   // stream that ran book-keeping in the call in progress (the hand-over event is recorded there)
+    bool runahead = false;                        // call in progress: pipelined whole-frame path with the device detector
     int cl_tx = 0, cl_ty = 0, cl_tw = 0, cl_th = 0, cl_clip = 0;
     float cl_scale = 0.f;
     float* d_in_xy = nullptr;
@@ -235,7 +243,8 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, h->d_cand, (size_t)2 * d.F);
     DALLOC(h, h->d_img, (size_t)d.W * d.H);
     if (h->cfg.enable_equalizer) {
-        DALLOC(h, h->d_eq, (size_t)d.W * d.H);
+        DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H);
+        h->d_eq = h->d_eq2[0];
         DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
     }
     DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
@@ -690,7 +699,9 @@ static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a sla
     q.n_cap = (int)std::min(npx, (size_t)16384);
     DALLOC(h, q.nb, (size_t)q.n_cap * DET_NBCAP); DALLOC(h, q.nb_cnt, (size_t)q.n_cap);
     DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
-    DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, q.xy, (size_t)2 * d.F);
+    DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F);
+    DALLOC(h, h->det_nout, 2);
+    q.xy = h->det_xy2[0]; q.n_out = h->det_nout;
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)SP_WW * SP_WW);
     q.spmask = mask;
@@ -719,27 +730,39 @@ static int detector_init(rvio_hip* h) {
     h->det_ready = true;
     return RVIO_OK;
 }
-// FeatureDetector::DetectWithSubPix on the tracker stream itself: it is the LONGEST chain of the front end (~130 us against ~90 us of
-// pyramid + KLT + RANSAC), so the shorter chain is the one that forks to the side stream and pays the cross-stream hops
-static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs) {
+// Front-end sequencing.  Two streams: the IMAGE stream h->ts (CLAHE and FeatureDetector::DetectWithSubPix: the longest chain, ~170 us)
+// and the side stream h->side (pyramid, KLT, RANSAC: ~90 us).  Two modes:
+//  * plain (per-stage calls, or a caller-side corner list): the side stream joins back and book-keeping runs on h->ts;
+//  * run-ahead (pipelined whole-frame path with the device detector): book-keeping runs on the SIDE stream, so the image stream is
+//    free for CLAHE + detector of frame k+1 as soon as the detector of frame k is done — the image chain never reads tracker state,
+//    except mbIsTheFirstImage (the detector's distance factor), hence one wait on book-keeping(k-1) in front of nms(k).  What
+//    book-keeping(k) still reads while frame k+1 is being detected is double-buffered by frame parity (equalised image, corner list).
+static DetDev det_view(const rvio_hip* h) {
+    DetDev q = h->det;
+    q.xy = h->det_xy2[h->par]; q.n_out = h->det_nout + h->par;
+    return q;
+}
+static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs, hipEvent_t first_flag_ready) {
     const DevCfg& d = h->dc;
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
+    const DetDev q = det_view(h);
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
     if (h->wide_px)
-        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->ts, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->ts, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->ts, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->ts, img, stride, q, src_bs, bs);
+    if (first_flag_ready) HIPCHK(h, hipStreamWaitEvent(h->ts, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
     if (h->wide_px && d.W % 4 == 0)
-        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->ts, h->det, bs);
+        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->ts, q, bs);
     else
-        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->ts, h->det, bs);
-    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->ts, h->det, bs);
-    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->ts, h->det, bs);
+        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->ts, q, bs);
+    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->ts, q, bs);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->ts, q, bs);
     if (h->wide_px)
-        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->ts, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->ts, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->ts, img, stride, h->det, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->ts, img, stride, q, src_bs, bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -752,15 +775,16 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     const unsigned B = (unsigned)h->batch;
     size_t src_bs = h->img_bs;       // the caller's images: instance stride of the call in progress
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
+        uint8_t* eq = h->d_eq2[h->par];
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, h->d_lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
             hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
         else
             hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, h->d_eq, src_bs, bs);
-        d_img = h->d_eq; stride = d.W; src_bs = bs;
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
+        d_img = eq; stride = d.W; src_bs = bs;
     }
     h->side = h->ts;
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
@@ -768,8 +792,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         HIPCHK(h, hipEventRecord(h->evD0, h->ts));
         HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
         h->side = h->stream_d;
-        const int rc = detect_dev(h, d_img, stride, src_bs);
+        // run-ahead: book-keeping(k-1) ran on the side stream; its hand-over event also says that mbIsTheFirstImage is final
+        const hipEvent_t flag = (h->runahead && h->frame_no >= 1) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
+        const int rc = detect_dev(h, d_img, stride, src_bs, flag);
         if (rc != RVIO_OK) return rc;
+        if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, h->ts));   // corners of frame k ready (book-keeping on the side stream waits for it)
     }
     // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
     for (int l = 0; l < d.levels; ++l) {
@@ -798,10 +825,18 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     const unsigned B = (unsigned)h->batch;
     hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
-    if (h->use_det) {   // join the side stream (long finished when the detector is); the detector's corner list replaces the caller's
-        HIPCHK(h, hipEventRecord(h->evD1, h->side));
-        HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->ts, h->dc, h->t, (const float*)h->det.xy, 0, (const int*)(h->det.counters + 2), bs);
+    h->tail = h->ts;
+    if (h->use_det) {   // the detector's corner list replaces the caller's
+        const float* xy = h->det_xy2[h->par];
+        const int* nout = h->det_nout + h->par;
+        if (h->runahead) {   // book-keeping on the side stream, behind RANSAC, once the corners are there
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
+            h->tail = h->side;
+        } else {             // join the side stream (long finished when the detector is)
+            HIPCHK(h, hipEventRecord(h->evD1, h->side));
+            HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
+        }
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs);
     } else
         hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0);
     HIPCHK(h, hipGetLastError());
@@ -810,10 +845,14 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
 
 static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped && h->ts == h->stream) HIPCHK(h, hipStreamSynchronize(h->stream_t));
+    if (h->piped && h->ts == h->stream) { HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }
     int rc;
     h->use_det = (d_cand == nullptr);   // no corner list from the caller: run FeatureDetector::DetectWithSubPix on the device
     if (h->use_det && (rc = detector_init(h)) != RVIO_OK) return rc;
+    const bool piped_call = h->ts == h->stream_t && !h->one_stream;
+    h->par = piped_call ? (int)(h->frame_no & 1) : 0;
+    static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;   // A/B timing only
+    h->runahead = piped_call && h->use_det && !no_runahead;
     const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
@@ -970,8 +1009,10 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     if (h->in_frame) { h->err = "rvio_hip_frame_begin_dev without rvio_hip_frame_end"; return RVIO_ERR_INVALID; }
     const int b = (int)(h->frame_no & 1);
     h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
-    if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
-    else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
+    if (h->frame_no >= 2) {   // the filter of frame k-2 has consumed this hand-over buffer (book-keeping may run on either front-end stream)
+        HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evF[b], 0));
+    } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
     if (m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
     static const bool dbg_host = getenv("RVIO_DBG_HOST") != nullptr;
@@ -992,7 +1033,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
     const double t2 = dbg_host ? now() : 0;
-    HIPCHK(h, hipEventRecord(h->evT[b], h->stream_t));
+    HIPCHK(h, hipEventRecord(h->evT[b], h->tail));      // behind book-keeping, on the stream that ran it
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
@@ -1132,11 +1173,11 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     HIPCHK(h, hipStreamSynchronize(h->stream_d));
     HIPCHK(h, hipStreamSynchronize(h->stream_t));   // the detector runs on the tracker stream of the call that used it
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    int cnt[4] = {0, 0, 0, 0};
-    HIPCHK(h, hipMemcpy(cnt, h->det.counters, sizeof cnt, hipMemcpyDeviceToHost));
-    if (n) *n = cnt[2];
-    if (xy && cnt[2] > 0) HIPCHK(h, hipMemcpy(xy, h->det.xy, sizeof(float) * 2 * cnt[2], hipMemcpyDeviceToHost));
-    if (raw_xy && cnt[2] > 0) HIPCHK(h, hipMemcpy(raw_xy, h->det.raw_xy, sizeof(float) * 2 * cnt[2], hipMemcpyDeviceToHost));
+    int cnt = 0;
+    HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->par, sizeof cnt, hipMemcpyDeviceToHost));
+    if (n) *n = cnt;
+    if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->par], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
+    if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, h->det.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
     if (eig) HIPCHK(h, hipMemcpy(eig, h->det.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
     return RVIO_OK;
 }
