@@ -527,7 +527,18 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
         double acc = 0;
-        if (q <= c6) for (int t = 0; t < ng; ++t) acc += partial[(size_t)s_list[t] * gs + e];
+        if (q <= c6) {
+            // eight loads in flight, then the additions in list order (the order fixes the result)
+            int t = 0;
+            for (; t + 8 <= ng; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)s_list[t + u] * gs + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; t < ng; ++t) acc += partial[(size_t)s_list[t] * gs + e];
+        }
         block[e] = acc;
     }
     if (bi.x == 0 && tid < 64) {
