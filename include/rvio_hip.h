@@ -189,8 +189,9 @@ int rvio_hip_update_tracked(rvio_hip* h);
  * [update if nCloneStates > nMinTrackingLength-1] -> augment -> compose, all
  * enqueued on the handle's streams with no host synchronisation; the front end of frame k+1
  * overlaps the filter of frame k.  The call returns before the device has read the inputs:
- * d_img / d_imu / d_cand_xy must stay valid (and unchanged) until two further frames have been
- * issued or rvio_hip_sync has returned. */
+ * d_img / d_imu / d_cand_xy must stay valid (and unchanged) until the frame has completed on the
+ * device, i.e. until rvio_hip_sync or any getter (rvio_hip_get_pose, rvio_hip_get_state, ...)
+ * issued after this call has returned.  (rvio_hip_frame, below, has no such condition.) */
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride,
                        const rvio_imu* d_imu, int m, const float* d_cand_xy, int n_cand);
 /* The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253-258
