@@ -59,6 +59,8 @@ struct rvio_hip {
     DetDev det = {};                              // device detector (T7), allocated on first use
     bool det_ready = false, use_det = false;
     hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
+    hipStream_t stream_c = nullptr;               // CLAHE stream of the run-ahead mode (frame k+1 is equalised while frame k is still being detected)
+    hipEvent_t evC[2] = {nullptr, nullptr};       // equalised image of the frame ready, by frame parity
     hipStream_t side = nullptr;                   // stream of pyramid / KLT / RANSAC of the call in progress (stream_d beside the detector, else ts)
     hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
@@ -143,6 +145,12 @@ static int dalloc(rvio_hip* h, T** p, size_t n) {
 #define FRONT_END_ONLY(h)                                                                                              \
     do {                                                                                                               \
         if ((h)->batch > 1) { (h)->err = "single-instance entry point called on a batch handle"; return RVIO_ERR_UNSUPPORTED; } \
+    } while (0)
+#define SYNC_FRONT(h)                                                                     \
+    do {                                                                                  \
+        if ((h)->stream_c) HIPCHK(h, hipStreamSynchronize((h)->stream_c));                \
+        if ((h)->stream_d) HIPCHK(h, hipStreamSynchronize((h)->stream_d));                \
+        HIPCHK(h, hipStreamSynchronize((h)->stream_t));                                   \
     } while (0)
 #define DALLOC(h, p, n)                               \
     do {                                              \
@@ -297,8 +305,11 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     // so three streams created back to back land on three different queues
     if (h->one_stream) h->stream_d = h->stream;
     else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
+    if (h->one_stream) h->stream_c = h->stream;
+    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));   // the fourth of HIP's four hardware queues
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, kEvFlags));
+    for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->evC[b], kEvFlags));
     h->ts = h->stream;
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], kEvFlags));
@@ -402,6 +413,7 @@ int rvio_hip_batch_size(const rvio_hip* h) { return h ? h->batch : 0; }
 void rvio_hip_destroy(rvio_hip* h) {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->stream_c) hipStreamSynchronize(h->stream_c);
     if (h->stream_d) hipStreamSynchronize(h->stream_d);
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -410,6 +422,8 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
+    if (h->stream_c && !h->one_stream) hipStreamDestroy(h->stream_c);
+    for (int b = 0; b < 2; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
     for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
     if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -419,6 +433,7 @@ const char* rvio_hip_last_error(const rvio_hip* h) { return h ? h->err.c_str() :
 void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
 int rvio_hip_sync(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
+    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
     if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d));
     HIPCHK(h, hipStreamSynchronize(h->stream_t));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -646,7 +661,7 @@ int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
 int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -774,23 +789,36 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
     size_t src_bs = h->img_bs;       // the caller's images: instance stride of the call in progress
+    bool forked = false;
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
         uint8_t* eq = h->d_eq2[h->par];
-        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
+        // run-ahead: CLAHE has its own stream, so frame k+1 is equalised while frame k is still being detected.  d_eq2[par] is free
+        // once book-keeping(k-2) is done: the pyramid (same stream, earlier) and cornerSubPix (it waited for it) of frame k-2 were its last readers
+        hipStream_t cs = h->runahead ? h->stream_c : h->ts;
+        if (h->runahead && h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
+        hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, h->d_lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
-            hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+            hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                                1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
         else
-            hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, h->ts, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
+            hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                                1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
         d_img = eq; stride = d.W; src_bs = bs;
+        if (h->runahead) {   // both consumers of the equalised image wait for it
+            HIPCHK(h, hipEventRecord(h->evC[h->par], cs));
+            HIPCHK(h, hipStreamWaitEvent(h->ts, h->evC[h->par], 0));
+            HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->par], 0));
+            forked = true;
+        }
     }
     h->side = h->ts;
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
         // fork: pyramid / KLT / RANSAC go to the side stream (the image is complete on ts here), the detector stays on ts
-        HIPCHK(h, hipEventRecord(h->evD0, h->ts));
-        HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
+        if (!forked) {
+            HIPCHK(h, hipEventRecord(h->evD0, h->ts));
+            HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
+        }
         h->side = h->stream_d;
         // run-ahead: book-keeping(k-1) ran on the side stream; its hand-over event also says that mbIsTheFirstImage is final
         const hipEvent_t flag = (h->runahead && h->frame_no >= 1) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
@@ -845,7 +873,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
 
 static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->piped && h->ts == h->stream) { HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }
+    if (h->piped && h->ts == h->stream) SYNC_FRONT(h);
     int rc;
     h->use_det = (d_cand == nullptr);   // no corner list from the caller: run FeatureDetector::DetectWithSubPix on the device
     if (h->use_det && (rc = detector_init(h)) != RVIO_OK) return rc;
@@ -902,7 +930,7 @@ int rvio_hip_get_tracks(rvio_hip* h, int32_t* n_feat, unsigned char* types, int3
     if (!h) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     const DevCfg& d = h->dc;
     int nf = 0;
     HIPCHK(h, hipMemcpyAsync(&nf, h->t.n_feat, sizeof nf, hipMemcpyDeviceToHost, h->stream));
@@ -922,7 +950,7 @@ int rvio_hip_get_tracker_points_at(rvio_hip* h, int instance, int32_t* n, float*
     if (!h || instance < 0 || instance >= h->batch) return RVIO_ERR_INVALID;
     if (!h->front_end) { h->err = "this batch handle was created without its front end"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     const DevCfg& d = h->dc;
     const size_t o = (size_t)instance * h->slab_bytes;
     int np = 0;
@@ -1019,7 +1047,10 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     static double acc[5] = {0, 0, 0, 0, 0}; static long nacc = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg_host ? now() : 0;
-    if (staged) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));   // the IMU batch was copied on the tracker stream
+    if (staged) {   // the IMU batch was copied on the tracker stream: propagate (filter stream) and RANSAC (side stream) need it
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evIn[b], 0));
+    }
     // propagate: with an update in this frame (and nobody sequencing the update from outside) it rides in the per-feature launch,
     // otherwise it goes to the filter stream right behind augment/compose(k-1)
     const bool fuse = h->fuse_ok && !begin_only && h->n_clones_host > h->cfg.min_track_len - 1;
@@ -1123,9 +1154,13 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
     HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
-    HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, h->stream_t));
+    // the image goes where its first consumer runs: the CLAHE stream in run-ahead mode (device detector + equaliser), else the tracker stream
+    static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;
+    hipStream_t is = (!cand_xy && h->cfg.enable_equalizer && !h->one_stream && !no_runahead) ? h->stream_c : h->stream_t;
+    if (is != h->stream_t) HIPCHK(h, hipStreamWaitEvent(is, h->evIn[b], 0));   // (so that evPin below also covers the IMU copy)
+    HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
     if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], pp + pin_cand, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
-    HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_t));
+    HIPCHK(h, hipEventRecord(h->evPin[ps], is));
     return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
@@ -1139,7 +1174,7 @@ int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned c
 int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     if (!h || !info) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     FilterMeta m;
     HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
@@ -1170,8 +1205,7 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     FRONT_END_ONLY(h);
     if (!h->det_ready) { h->err = "the device detector has not run (pass a NULL corner list to track/frame)"; return RVIO_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream_d));
-    HIPCHK(h, hipStreamSynchronize(h->stream_t));   // the detector runs on the tracker stream of the call that used it
+    SYNC_FRONT(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int cnt = 0;
     HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->par, sizeof cnt, hipMemcpyDeviceToHost));
@@ -1186,7 +1220,7 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
     if (!h || level < 0 || level >= h->dc.levels) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     const PyrDev& p = h->pyr[h->pyr_cur];
     if (w) *w = p.w[level];
     if (hgt) *hgt = p.h[level];
@@ -1201,7 +1235,7 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
     if (!h || n < 0 || n > h->dc.F) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    { if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d)); HIPCHK(h, hipStreamSynchronize(h->stream_t)); }   // side / tracker streams first
+    SYNC_FRONT(h);   // image / side / tracker streams first
     if (n > 0 && xy) HIPCHK(h, hipMemcpyAsync(xy, h->t.tracked, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     if (n > 0 && un_xy) HIPCHK(h, hipMemcpyAsync(un_xy, h->t.un2, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
