@@ -1055,8 +1055,8 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     // otherwise it goes to the filter stream right behind augment/compose(k-1)
     const bool fuse = h->fuse_ok && !begin_only && h->n_clones_host > h->cfg.min_track_len - 1;
     int rc = RVIO_OK;
-    if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }
-    else rc = propagate_dev(h, d_imu, m, h->imu_bs);
+    h->fuse_m = -1;
+    if (!fuse) rc = propagate_dev(h, d_imu, m, h->imu_bs);
     if (rc != RVIO_OK) return rc;
     const double t1 = dbg_host ? now() : 0;
     h->ts = h->stream_t;
@@ -1068,7 +1068,9 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
+    if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
     rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
+    h->fuse_m = -1;
     const double t4 = dbg_host ? now() : 0;
     HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
     if (dbg_host) {
