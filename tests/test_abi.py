@@ -66,12 +66,23 @@ def test_product_path_fails_loudly_without_gpu(lib):
 
 def test_product_never_touches_the_oracle():
     """the product package must not import, link or call anything under oracle/"""
-    pkg = os.path.join(ROOT, "r-vio_amd")
-    for dp, _, fs in os.walk(pkg):
-        for f in fs:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                txt = open(os.path.join(dp, f)).read()
-                code = "\n".join(ln for ln in txt.splitlines() if not ln.lstrip().startswith(("//", "#", "*", "/*", '"""')))
-                assert "liborc" not in txt and not re.search(r"\borc_[a-z_]+\s*\(", txt), os.path.join(dp, f)
-                assert not re.search(r"^\s*(import|from)\s+oracle\b", code, re.M), os.path.join(dp, f)
-                assert not re.search(r"#include\s*[\"<][^\">]*oracle", txt), os.path.join(dp, f)
+    for pkg in (os.path.join(ROOT, "r-vio_amd"), os.path.join(ROOT, "host"), os.path.join(ROOT, "include")):
+      for dp, _, fs in os.walk(pkg):
+          for f in fs:
+              if f.endswith((".py", ".hip", ".h", ".cpp")):
+                  txt = open(os.path.join(dp, f)).read()
+                  code = "\n".join(ln for ln in txt.splitlines() if not ln.lstrip().startswith(("//", "#", "*", "/*", '"""')))
+                  assert "liborc" not in txt and not re.search(r"\borc_[a-z_]+\s*\(", txt), os.path.join(dp, f)
+                  assert not re.search(r"^\s*(import|from)\s+oracle\b", code, re.M), os.path.join(dp, f)
+                  assert not re.search(r"#include\s*[\"<][^\">]*oracle", txt), os.path.join(dp, f)
+
+
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py may use oracle/ for the reported CPU baseline, never for the thing measured"""
+    txt = open(os.path.join(ROOT, "bench.py")).read()
+    a = txt.index("def cpu_baseline(")
+    b = txt.index("\nif __name__", a)
+    outside = txt[:a] + txt[b:]
+    assert not re.search(r"^\s*(import|from)\s+oracle\b", outside, re.M)
+    assert "liborc" not in outside.replace("oracle/liborc.so (g++ -O3, single thread)", "")
+    assert re.search(r"^\s*import oracle as O", txt[a:b], re.M)
