@@ -44,6 +44,12 @@ def record_sequence(cfg, n_frames=40, seed=0, k0=38, duration=8.0, want=None):
     return seq, recs
 
 
+def small_image_config():
+    """a half-size camera (376 x 240, 100 features): keeps the image fixture of tests/golden/ small; every front-end stage still runs"""
+    return abi.config_named("B", width=376, height=240, fx=229.327, fy=228.648, cx=183.6075, cy=124.1875, n_features=100,
+                            block_x=75, block_y=60)
+
+
 def qfix(x):
     """sign-normalise the quaternions of a state vector (q and -q are the same rotation)"""
     x = np.array(x, float)

@@ -272,3 +272,18 @@ def test_golden_snapshot_regression():
     assert np.max(np.abs(r["P3"] - g["P3"])) < 1e-9 * np.max(np.abs(g["P3"]))
     assert np.array_equal(r["diag"]["accepted"], g["accepted"])
     assert np.array_equal(r["pts"], g["pts"])
+
+
+def test_golden_image_fixture_regression():
+    """tests/golden/small_images_tracker.npz (4 frames of a half-size camera: CLAHE + DetectWithSubPix + KLT + RANSAC + book-keeping):
+    the oracle reproduces the committed feature lists — the same file the GPU suite checks the HIP path against"""
+    import zlib
+    g = np.load(os.path.join(GOLD, "small_images_tracker.npz"))
+    cfg = S.small_image_config()
+    t = O.Tracker(cfg)
+    for i in range(4):
+        t.track(g["imgs"][i], g["imu%d" % i].view(abi.IMU_DTYPE), None)
+        pts, hl = t.get_points()
+        assert np.array_equal(pts, g["pts%d" % i]) and np.array_equal(hl, g["hist%d" % i]), i
+    assert np.array_equal(O.detect(cfg, O.clahe(g["imgs"][0]), 1), g["corners0"])
+    assert zlib.crc32(O.clahe(g["imgs"][0]).tobytes()) == int(g["clahe0_crc"])
