@@ -28,6 +28,7 @@ rv = load_pkg()
 abi, synth = rv.abi, rv.synth
 
 K0 = 38  # last stationary frame of the synthetic sequence (t = 1.9 s)
+PARITY_FRAMES = 141   # frames of the free-running device-vs-CPU comparison (and of the CPU baseline sample)
 
 
 def build_inputs(cfg, n_frames, seed=0):
@@ -143,7 +144,7 @@ def main():
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
-        nblk = (6 * (cfg.max_track_len - 1) + 1) ** 2
+        nblk = 2 * (6 * (cfg.max_track_len - 1) + 1) ** 2    # [S2 | S1] per rank (rvio_hip_update_local)
         gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda")
 
     def frame(i):
@@ -254,17 +255,19 @@ def main():
             out["batched_filter"] = batched_filter_leg(cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
             _CFG_NAME[0] = args.config
-            out["cpu_baseline"], xs_cpu = cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, min(args.cpu_frames, n_frames))
+            # parity + CPU baseline on a sequence of >= PARITY_FRAMES frames, whatever --steps says (the reference's rank truncation
+            # first bites at frame 90 of the stock sequence: a 26-frame comparison would not see it)
+            if n_frames >= PARITY_FRAMES:
+                pin = (imgs, imu_arr, imu_cnt, cand_arr, cand_cnt)
+            else:
+                _, pi, pa, pc, pca, pcc = build_inputs(cfg, PARITY_FRAMES)
+                pin = (pi, pa, pc, None, np.zeros_like(pcc)) if not args.host_corners else (pi, pa, pc, pca, pcc)
+            npar = min(len(pin[0]), 240)
+            out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, npar)
             if _MULTI[0] is not None:
                 out["cpu_baseline_multicore"] = _MULTI[0]
-            if xs_cpu is not None and "x_at_cpu_frames" in out:
-                xg = _qfix(out.pop("x_at_cpu_frames"))
-                out["max_state_delta_vs_cpu"] = float(np.max(np.abs(xg - _qfix(xs_cpu[0]))))
-                out["max_state_delta_vs_cpu_information_form"] = float(np.max(np.abs(xg - _qfix(xs_cpu[1]))))
-                out["parity_note"] = ("vs_cpu = the literal restatement of the reference (Givens QR + rank truncation, Updater.cc:469-529) after "
-                                      "the same free-running frames; information_form = the same oracle with the update in the device's "
-                                      "formulation.  They differ only in updates where the reference's order-dependent rank truncation discards "
-                                      "informative rows (tests/test_truncation.py, DESIGN.md section 3)")
+            out["parity"] = parity_leg(cfg, torch, pin, wi, ai, ni, npar, cpu_states)
+            out["max_state_delta_vs_cpu"] = out["parity"]["max_state_delta"]
         out.pop("x_at_cpu_frames", None)
     h.close()
     if sharded:
@@ -597,26 +600,51 @@ _CFG_NAME = ["B"]
 _MULTI = [None]
 
 
+def parity_leg(cfg, torch, pin, wi, ai, ni, n, cpu_states):
+    """The device, free-running over the same n frames as the CPU oracle in its LITERAL form (sequential Givens QR + leading-row rank
+    scan, Updater.cc:469-529): per-state and covariance deltas at EVERY frame, the update counters, and the frames in which the
+    reference's scan cut informative rows off (the device must report the same nRank there)."""
+    from rvio_amd import hip
+    imgs, imu_arr, imu_cnt, cand_arr, cand_cnt = pin
+    h = hip.RvioHip(cfg)
+    h.initialize(wi, ai, ni)
+    worst_x, worst_p, cuts, cuts_equal, counters_equal = 0.0, 0.0, [], True, True
+    for i in range(n):
+        h.frame(imgs[i], imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]])
+        x, P = h.get_state()
+        gi = h.frame_info()
+        xc, Pc, ci, crank = cpu_states[i]
+        worst_x = max(worst_x, float(np.max(np.abs(_qfix(x) - _qfix(xc)))))
+        worst_p = max(worst_p, float(np.max(np.abs(P - Pc)) / max(1e-300, float(np.max(np.abs(Pc))))))
+        counters_equal &= all(gi[k] == ci[k] for k in ("n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated"))
+        if gi["rank_truncated_at"] >= 0:
+            cuts.append(i)
+            cuts_equal &= gi["rank_truncated_at"] == crank
+    h.close()
+    return {"frames": n, "max_state_delta": worst_x, "max_cov_rel_delta": worst_p, "tolerance": 1e-6, "counters_equal_every_frame": bool(counters_equal),
+            "rank_truncation_frames": cuts, "rank_truncation_nrank_equal": bool(cuts_equal),
+            "against": "the CPU baseline run in its literal form (Givens QR + leading-row rank scan, Updater.cc:469-529); max over all frames of the free-running sequence"}
+
+
 def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n):
-    """The CPU oracle (oracle/liborc.so, -O3, 1 core) on the first n frames of the same sequence."""
+    """The CPU oracle (oracle/liborc.so, -O3, 1 core) on the first n frames of the same sequence; also returns (x, P, info, nRank) after every frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
     s = O.System(cfg)
     x0, P0 = O.initialize(cfg, wi, ai, ni)
     s.set_state(x0, P0)
-    tms = []
-    t0 = time.perf_counter()
+    tms, states = [], []
+    el = 0.0
     for i in range(n):
+        t0 = time.perf_counter()
         info, t, pp, pq = s.frame(imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]], img=imgs[i])
+        el += time.perf_counter() - t0
         tms.append(t)
-    el = time.perf_counter() - t0
+        xs, Ps = s.get_state()
+        states.append((xs, Ps, info, s.last_rank()))
     tms = np.array(tms)[20:]
-    xs_lit, _ = s.get_state()
-    s2 = O.System(cfg, information_form=True)          # untimed: the same frames with the update in the device's formulation
-    s2.set_state(x0, P0)
-    for i in range(n):
-        s2.frame(imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]], img=imgs[i])
-    xs = (xs_lit, s2.get_state()[0])
+    xs_lit = states[-1][0]
+    xs = states
     multi = None
     if cand_arr is None:   # secondary figure (SURVEY.md 8d): the same sources with their OpenMP loops active, all host cores, in a child process
         import subprocess

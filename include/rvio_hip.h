@@ -112,7 +112,9 @@ typedef struct rvio_frame_info {
     int32_t updated;           /* 1 if the EKF update was applied               */
     int32_t n_tracked_out;     /* mnFeatsToTrack leaving track() (after refill) */
     int32_t ransac_winner;     /* nWinnerHypothesisIdx                          */
-    int32_t reserved[6];
+    int32_t reserved[5];       /* [0]: sticky device-side error flag */
+    int32_t rank_truncated_at; /* Updater.cc:516-529: nRank when the leading-row scan cut informative rows off (the type-'1'
+                                * features' rows, dropped from this update), -1 otherwise */
 } rvio_frame_info;
 
 typedef struct rvio_hip rvio_hip;  /* opaque; replaces the System-owned stage objects (System.h:89-92) */
@@ -262,10 +264,12 @@ int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]);
 
 /* --- feature-sharded updater (no reference counterpart) ------ */
 /* Stage A: per-feature build + gate on the features f with f % world == rank,
- * then local compression to the information block [A|b] = Hw^T [Hw | r]
- * (6n x (6n+1) doubles, row-major, plus 2 trailing doubles: accepted-feature
- * count and stacked-row count).  *d_block is a device pointer owned by the
- * handle, *n_doubles its length: this is the payload of the all-gather. */
+ * then local compression to this shard's share of the information block
+ * [A|b] = Hw^T [Hw | r], kept in two parts (the sum over the type-'2' features and the sum over
+ * the type-'1' features, each 6n x (6n+1) doubles row-major inside a (6n_max+1)^2 square) plus
+ * five counters, so that stage B can apply the reference's rank truncation (Updater.cc:516-529)
+ * to the gathered whole.  *d_block is a device pointer owned by the handle, *n_doubles its
+ * length (2 (6n_max+1)^2): this is the payload of the all-gather. */
 int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int world,
                           double** d_block, int* n_doubles);
 /* Stage B: sum `world` gathered blocks (device pointer, rank-major) in rank

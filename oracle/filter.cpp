@@ -433,19 +433,18 @@ void orc_propagate(const rvio_config* cfg, const double* x, int xdim, double* Pi
     std::memcpy(Pio, P.a.data(), sizeof(double) * d * d);
 }
 
-// Updater::update, Updater.cc:72-628
-void orc_update(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
-                const rvio_tracks* tr, double* x_out, double* P_out,
-                int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int32_t info[4]) {
+// U1..U6 (Updater.cc:89-463): the stacked pair (Hw = Hx[:,24:], r) of the accepted features, in feature order.
+// Hw_out: nRows x 6n column-major with leading dimension ld_rows (>= sum of 2*len); returns nRowCount.
+static int stack_rows(const rvio_config* cfg, const double* x, int xdim, const Mat& P, const rvio_tracks* tr,
+                      Mat& Hw, std::vector<double>& r, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int* n_good) {
     const int n = (xdim - 26) / 7, nc6 = 6 * n;
     const Extr ex = extrinsics(cfg);
     const double sig = sigma_im(cfg);
-    Mat P = mat_from(Pin, d);
     Mat Pcc = P.block(24, 24, nc6, nc6);
     int nRows = 0;
     for (int f = 0; f < tr->n_feat; ++f) nRows += 2 * tr->len[f];
-    std::vector<double> r(nRows, 0.0);
-    Mat Hw(nRows, nc6);  // Hx[:,24:]; columns 0..23 of Hx are identically zero (:102-104,425)
+    r.assign(nRows, 0.0);
+    Hw = Mat(nRows, nc6);  // Hx[:,24:]; columns 0..23 of Hx are identically zero (:102-104,425)
     int nRowCount = 0, nGood = 0;
     for (int f = 0; f < tr->n_feat; ++f) {
         FeatOut fo = feature_rows(cfg, ex, sig, x, n, Pcc, tr->types[f], tr->meas + (size_t)f * tr->max_len * 2, tr->len[f]);
@@ -457,6 +456,17 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
         for (int i = 0; i < fo.ndof; ++i) { r[nRowCount + i] = fo.r_[i]; for (int j = 0; j < nc6; ++j) Hw(nRowCount + i, j) = fo.Hx_(i, j); }
         nRowCount += fo.ndof; nGood++;
     }
+    *n_good = nGood;
+    return nRowCount;
+}
+
+// U7..U10 (Updater.cc:460-627) on a given stacked pair: Ho = first nRowCount rows of Hw.
+// row_norms (may be NULL): norms of the rows of Ho after the Givens sweep, min(M, 2*nc6) entries (diagnostic).
+static void compress_and_apply(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d, const Mat& P,
+                               const Mat& Hw, const std::vector<double>& r, int nRowCount, int nGood,
+                               double* x_out, double* P_out, int32_t info[4], double* row_norms) {
+    const int n = (xdim - 26) / 7, nc6 = 6 * n;
+    const double sig = sigma_im(cfg);
     if (info) { info[0] = nGood; info[1] = nRowCount; info[2] = -1; info[3] = 0; }
     if (nGood > 2) {  // :460
         Mat Ho = Hw.block(0, 0, nRowCount, nc6);
@@ -480,6 +490,11 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
                 double s = 0; for (int j = 0; j < nc6; ++j) s += Ho(i, j) * Ho(i, j);
                 if (std::sqrt(s) < 1e-4) break; else nRank++;
             }
+            if (row_norms)
+                for (int i = 0; i < std::min(M, 2 * nc6); ++i) {
+                    double s = 0; for (int j = 0; j < nc6; ++j) s += Ho(i, j) * Ho(i, j);
+                    row_norms[i] = std::sqrt(s);
+                }
             Hn = Ho.block(0, 0, nRank, nc6);
             rn.resize(nRank); for (int i = 0; i < nRank; ++i) rn[i] = roM(i, 0);
             if (info) info[2] = nRank;
@@ -494,45 +509,129 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
     }
 }
 
-// Information-form compression (CPU mirror of the device design): per shard
-// [A|b] = sum_f Hx_f^T [Hx_f | r_f] over accepted features f with f%world==rank.
+// Updater::update, Updater.cc:72-628
+void orc_update(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
+                const rvio_tracks* tr, double* x_out, double* P_out,
+                int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int32_t info[4]) {
+    Mat P = mat_from(Pin, d);
+    Mat Hw; std::vector<double> r; int nGood = 0;
+    int nRowCount = stack_rows(cfg, x, xdim, P, tr, Hw, r, accepted, gamma, ndof, pfinv, &nGood);
+    compress_and_apply(cfg, x, xdim, Pin, d, P, Hw, r, nRowCount, nGood, x_out, P_out, info, nullptr);
+}
+
+// The two halves of orc_update, separately (analysis of the rank truncation, tests/test_truncation.py):
+// orc_update_stack returns the stacked pair (row-major M x 6n, M = return value; buffers sized sum(2*len) rows).
+int orc_update_stack(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
+                     const rvio_tracks* tr, double* Hw_rowmajor, double* r_out, int32_t* n_good) {
+    const int nc6 = 6 * ((xdim - 26) / 7);
+    Mat P = mat_from(Pin, d);
+    Mat Hw; std::vector<double> r; int nGood = 0;
+    int M = stack_rows(cfg, x, xdim, P, tr, Hw, r, nullptr, nullptr, nullptr, nullptr, &nGood);
+    for (int i = 0; i < M; ++i) { r_out[i] = r[i]; for (int j = 0; j < nc6; ++j) Hw_rowmajor[(size_t)i * nc6 + j] = Hw(i, j); }
+    *n_good = nGood;
+    return M;
+}
+void orc_update_from_stack(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
+                           const double* Hw_rowmajor, const double* r_in, int M, int n_good,
+                           double* x_out, double* P_out, int32_t info[4], double* row_norms) {
+    const int nc6 = 6 * ((xdim - 26) / 7);
+    Mat P = mat_from(Pin, d);
+    Mat Hw(M, nc6); std::vector<double> r(r_in, r_in + M);
+    for (int i = 0; i < M; ++i) for (int j = 0; j < nc6; ++j) Hw(i, j) = Hw_rowmajor[(size_t)i * nc6 + j];
+    compress_and_apply(cfg, x, xdim, Pin, d, P, Hw, r, M, n_good, x_out, P_out, info, row_norms);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Information-form compression (CPU mirror of the device design).
+//
+// [A|b] = sum_f Hx_f^T [Hx_f | r_f] replaces the Givens QR of Updater.cc:469-512, and the reference's leading-row rank scan
+// (Updater.cc:516-529) is reproduced by its structural equivalent.  What the scan does to the result (derived from the
+// sweep's handling of exact zeros — makeGivens(0,q) swaps, makeGivens(p,0) is the identity — and checked against the
+// literal path above in tests/test_truncation.py): rows of type-'2' features span columns [0, e2], e2 = 6(ceil(L/2)-1)-1;
+// rows of type-'1' features span [6(n-L+1), 6n-1].  If every accepted type-'1' feature starts behind e2, the sweep of
+// columns 0..e2 never mixes the two families.  The type-'2' block has the scale gauge of a monocular window as null
+// direction, so its column e2 is dependent: when that block has more than e2 rows, a left-over row of rounding residue
+// (norm ~1e-15) is carried to position e2, the scan stops there (nRank = e2) and every type-'1' row is discarded.  In all
+// other constellations the scan only drops rows that are zero to rounding.  Hence: keep the type-'2' sum apart from the
+// type-'1' sum, and drop the latter iff  (a) min start column of the accepted type-'1' features > e2,  (b) the accepted
+// type-'2' rows number >= e2+1,  (c) column e2 of the type-'2' block is dependent on columns 0..e2-1: the Schur
+// complement of A2[e2][e2] is < (1e-4)^2 (the scan's threshold on the row norm),  (d) the stack is tall (rows > 6n).
+//
+// block (per shard; doubles): part0 = type-'2' sum [6n x (6n+1)], part1 = type-'1' sum, then 8 doubles
+//   {n_good, n_rows, rows of type '2', e2 (-1: none), min start column of type '1' (1e9: none), 0, 0, 0}.
+static int e2_of(int L) { return 6 * ((int)std::ceil(.5 * L) - 1) - 1; }
+
 void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
                       const rvio_tracks* tr, int rank, int world, double* block) {
-    const int n = (xdim - 26) / 7, nc6 = 6 * n, ld = nc6 + 1;
+    const int n = (xdim - 26) / 7, nc6 = 6 * n, ld = nc6 + 1, part = nc6 * ld;
     const Extr ex = extrinsics(cfg);
     const double sig = sigma_im(cfg);
     Mat P = mat_from(Pin, d);
     Mat Pcc = P.block(24, 24, nc6, nc6);
-    for (int i = 0; i < nc6 * ld + 2; ++i) block[i] = 0;
-    int good = 0, rows = 0;
+    for (int i = 0; i < 2 * part + 8; ++i) block[i] = 0;
+    int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = 1000000000;
     for (int f = rank; f < tr->n_feat; f += world) {
         FeatOut fo = feature_rows(cfg, ex, sig, x, n, Pcc, tr->types[f], tr->meas + (size_t)f * tr->max_len * 2, tr->len[f]);
         if (!fo.accepted) continue;
         good++; rows += fo.ndof;
+        double* B = block;
+        if (tr->types[f] == '2') { rows2 += fo.ndof; e2 = std::max(e2, e2_of(tr->len[f])); }
+        else { B = block + part; smin = std::min(smin, 6 * (n - (tr->len[f] - 1))); }
         for (int k = 0; k < fo.ndof; ++k)
             for (int i = 0; i < nc6; ++i) {
                 double hi = fo.Hx_(k, i);
                 if (hi == 0) continue;
-                for (int j = 0; j < nc6; ++j) block[i * ld + j] += hi * fo.Hx_(k, j);
-                block[i * ld + nc6] += hi * fo.r_[k];
+                for (int j = 0; j < nc6; ++j) B[i * ld + j] += hi * fo.Hx_(k, j);
+                B[i * ld + nc6] += hi * fo.r_[k];
             }
     }
-    block[nc6 * ld] = good; block[nc6 * ld + 1] = rows;
+    double* m = block + 2 * part;
+    m[0] = good; m[1] = rows; m[2] = rows2; m[3] = e2; m[4] = smin;
+}
+
+// (c) above: eliminate columns 0..e-1 of the leading (e+1)x(e+1) block of A2 (square-root-free, unpivoted; a column whose
+// pivot has cancelled to rounding level is skipped, as the sweep's mixture row leaves the later columns' span alone)
+// and return what is left of A2[e][e].
+static double schur_last(const Mat& A2, int e) {
+    const int m = e + 1;
+    Mat M = A2.block(0, 0, m, m);
+    std::vector<double> d0(m);
+    for (int i = 0; i < m; ++i) d0[i] = M(i, i);
+    for (int k = 0; k < e; ++k) {
+        const double dk = M(k, k);
+        if (!(dk > 1e-12 * d0[k])) continue;
+        const double rd = 1.0 / dk;
+        for (int i = k + 1; i < m; ++i) {
+            const double f = M(i, k) * rd;
+            for (int j = k + 1; j <= i; ++j) M(i, j) -= f * M(j, k);
+        }
+    }
+    return M(e, e);
 }
 
 // dx = Pc (s2 I + A Pcc)^-1 b ;  Joseph form written through A ("information-form update")
 void orc_update_global(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
                        const double* blocks, int world, double* x_out, double* P_out, int32_t info[4]) {
-    const int n = (xdim - 26) / 7, nc6 = 6 * n, ld = nc6 + 1, blen = nc6 * ld + 2;
+    const int n = (xdim - 26) / 7, nc6 = 6 * n, ld = nc6 + 1, part = nc6 * ld, blen = 2 * part + 8;
     const double sig = sigma_im(cfg), s2 = std::pow(sig, 2);
-    Mat A(nc6, nc6); std::vector<double> b(nc6, 0.0);
-    int good = 0, rows = 0;
+    Mat A2(nc6, nc6), A1(nc6, nc6); std::vector<double> b2(nc6, 0.0), b1(nc6, 0.0);
+    int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = 1000000000;
     for (int w = 0; w < world; ++w) {
         const double* B = blocks + (size_t)w * blen;
-        for (int i = 0; i < nc6; ++i) { for (int j = 0; j < nc6; ++j) A(i, j) += B[i * ld + j]; b[i] += B[i * ld + nc6]; }
-        good += (int)B[nc6 * ld]; rows += (int)B[nc6 * ld + 1];
+        for (int i = 0; i < nc6; ++i) {
+            for (int j = 0; j < nc6; ++j) { A2(i, j) += B[i * ld + j]; A1(i, j) += B[part + i * ld + j]; }
+            b2[i] += B[i * ld + nc6]; b1[i] += B[part + i * ld + nc6];
+        }
+        const double* m = B + 2 * part;
+        good += (int)m[0]; rows += (int)m[1]; rows2 += (int)m[2]; e2 = std::max(e2, (int)m[3]); smin = std::min(smin, (int)m[4]);
     }
-    if (info) { info[0] = good; info[1] = rows; info[2] = -1; info[3] = 0; }
+    // the reference's rank truncation (Updater.cc:516-529), structural form (see above)
+    bool truncate = false;
+    if (good > 2 && rows > nc6 && e2 >= 0 && e2 < nc6 && smin < 1000000000 && smin > e2 && rows2 >= e2 + 1)
+        truncate = !(schur_last(A2, e2) >= 1e-8);
+    Mat A = A2; std::vector<double> b = b2;
+    if (!truncate) { A = add(A2, A1); for (int i = 0; i < nc6; ++i) b[i] = b2[i] + b1[i]; }
+    if (info) { info[0] = good; info[1] = rows; info[2] = truncate ? e2 : -1; info[3] = 0; }
     if (good <= 2) { std::memcpy(x_out, x, sizeof(double) * xdim); std::memcpy(P_out, Pin, sizeof(double) * d * d); return; }
     // Reuse ekf_apply with the Cholesky-free equivalent pair: eigen-free route —
     // form Hn := A^(1/2) is not needed; solve directly.

@@ -660,9 +660,9 @@ void orc_system_frame(orc_system* S, const uint8_t* img, int stride, const float
         rvio_tracks tr = {nf, ML, types.data(), len.data(), meas.data()};
         std::vector<double> xo(S->x.size()), Po(S->P.size());
         int32_t inf[4];
-        if (S->info_form) {   // analysis mode: the information-form restatement of the same update (no rank truncation)
+        if (S->info_form) {   // analysis mode: the information-form restatement of the same update (the device's formulation)
             const int nc6 = 6 * S->nClones;
-            std::vector<double> blk((size_t)nc6 * (nc6 + 1) + 2);
+            std::vector<double> blk((size_t)2 * nc6 * (nc6 + 1) + 8);
             orc_update_local(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, &tr, 0, 1, blk.data());
             orc_update_global(&S->cfg, xn.data(), S->xdim, S->P.data(), S->d, blk.data(), 1, xo.data(), Po.data(), inf);
             S->last_rank = -1;

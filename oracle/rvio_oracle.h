@@ -44,10 +44,21 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
                 const rvio_tracks* tracks, double* x_out, double* P_out,
                 int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int32_t info[4]);
 
+/* The two halves of orc_update (analysis of the rank truncation Updater.cc:516-529, tests/test_truncation.py):
+ * orc_update_stack = U1..U6, returns M and the stacked pair (Hw row-major M x 6n, r) of the accepted features;
+ * orc_update_from_stack = U7..U10 on a given pair; row_norms (may be NULL) = norms of the first min(M,12n) rows after the sweep */
+int orc_update_stack(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
+                     const rvio_tracks* tracks, double* Hw_rowmajor, double* r_out, int32_t* n_good);
+void orc_update_from_stack(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
+                           const double* Hw_rowmajor, const double* r_in, int M, int n_good,
+                           double* x_out, double* P_out, int32_t info[4], double* row_norms);
+
 /* Same update, but with the information-form compression [A|b]=Hw^T[Hw|r]
  * sharded over `world` ranks (features f%world==rank) and summed in rank
- * order — the CPU mirror of rvio_hip_update_local/_global, used by the gloo
- * tests.  block: (6n*(6n+1)+2) doubles. */
+ * order, and the reference's rank truncation (Updater.cc:516-529) applied in its structural form
+ * (filter.cpp, comment above orc_update_local) — the CPU mirror of rvio_hip_update_local/_global, used by the gloo
+ * tests.  block: 2*6n*(6n+1)+8 doubles (type-'2' sum, type-'1' sum, counters); info[2] = the column the scan stopped at
+ * when it discarded the type-'1' rows, else -1. */
 void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,
                       const rvio_tracks* tracks, int rank, int world, double* block);
 void orc_update_global(const rvio_config* cfg, const double* x, int xdim, const double* P, int d,

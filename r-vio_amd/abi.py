@@ -48,7 +48,7 @@ class rvio_frame_info(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("n_clones", "n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update",
                  "n_feat_accepted", "n_rows", "updated", "n_tracked_out", "ransac_winner")] + \
-               [("reserved", C.c_int32 * 6)]
+               [("reserved", C.c_int32 * 5), ("rank_truncated_at", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -1,17 +1,14 @@
 // filter_kernels.hip — hand-written gfx950 kernels for the filter half of the
 // R-VIO hot path.
 //
-//   propagate_kernel     PreIntegrator::propagate          PreIntegrator.cc:51-194
-//   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455
-//   (epilogue of feat_build_kernel) / gram_reduce_kernel / block_sum_kernel
-//                        measurement compression (Updater.cc:469-536) in information
-//                        form [A|b] = Hw^T [Hw | r]   
-//   gemm_f64_kernel      FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
-//   solve_kernel         W = T^-1, y = W b by Gauss-Jordan (partial pivoting, one barrier
-//                        per column), then dx = Pc y and state injection  (Updater.cc:540-613)
+//   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455 (U1..U5) + the feature's share of the information block
+//   gram_reduce_kernel / block_sum_kernel
+//                        measurement compression (Updater.cc:469-536) in information form [A|b] = Hw^T [Hw | r], with the
+//                        reference's rank truncation (Updater.cc:516-529) in its structural form   
+//   gemm_T_kernel        FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
 //   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG)
 //   final_kernel         P+ = sym( P1 - P1c G^T + s2 G U^T )   (Joseph form, Updater.cc:615-619)
-//   augcomp_kernel       augmentation/slide + composition, fused  (System.cc:279-365)
+// (propagate / augmentation + composition: filter_kernels2.hip; W = T^-1, dx, state injection: solve6.hip / solve4.hip)
 //
 // Design rules learnt from the first profile (profiles/r01_a): every kernel front-loads its
 // global reads in one batch (a dependent global load after a kernel boundary costs 1-2 us),
@@ -496,16 +493,91 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
 // =============================================================== U7 compression, information form (reduction stage)
 // partial[f][p][q] = sum over the rows of accepted feature f of H[row][p] * H[row][q], q = 0..c6 (column c6 is the residual -> b),
 // is produced by the epilogue of feat_build_kernel; the kernels below reduce it.
+//
+// The reference's leading-row rank scan (Updater.cc:516-529) in its structural form.  The Givens sweep treats exact zeros
+// specially (makeGivens(0,q) swaps, makeGivens(p,0) is the identity), so as long as every accepted type-'1' feature starts behind
+// the last column e2 = 6(ceil(L/2)-1)-1 of the type-'2' features the two families are never mixed while columns 0..e2 are swept.
+// The type-'2' block has the scale gauge of a monocular window as null direction: its column e2 is dependent, a left-over row of
+// rounding residue reaches position e2, the scan stops there (nRank = e2) and the type-'1' rows are discarded.  In every other
+// constellation the scan only drops rows that are zero to rounding (derivation and the CPU proof against the literal sweep:
+// oracle/filter.cpp above orc_update_local, tests/test_truncation.py).  So the type-'2' sum S2 and the type-'1' sum S1 are kept
+// apart, and [A|b] = S2 if   min start column of type '1' > e2,   rows of type '2' >= e2+1,   the stack is tall (rows > 6n) and
+// the Schur complement of S2[e2][e2] w.r.t. columns 0..e2-1 is < (1e-4)^2 (the scan's row-norm threshold);   else S2 + S1.
+//
+// block = the payload of one shard: part 0 = S2, part 1 = S1 (each c6 x ldh row-major inside an ldh x ldh square); the spare
+// last row of part 0 carries {n_good, n_rows, rows of type '2', e2 (-1: none), min start column of type '1' (TR_NONE: none)}.
 #define GRAM_MAX_FEATS 2048
-// block = [A|b] (c6 x ldh row-major) + {n_good, n_rows}: the sum of the accepted features' shares G_f (written by feat_build_kernel to
-// partial[f]) in ascending feature order — deterministic; also the all-gather payload of the sharded updater
-__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, const int* nrows, double* block, size_t bs) {
+#define TR_NONE 1000000000
+__host__ __device__ inline int trunc_mmax(int max_len) { return 6 * ((max_len + 1) / 2 - 1); }   // largest e2 + 1
+__host__ __device__ inline size_t trunc_lds_doubles(int max_len) { const size_t m = trunc_mmax(max_len); return m * (m | 1) + m + 8; }
+
+// data written by other workgroups of the same launch: read it from L2 (agent scope), not through this CU's vector cache
+__device__ __forceinline__ double ld_l2(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// true for exactly one workgroup of the launch (per instance): the one that finishes last.  cnt is re-armed for the next launch.
+__device__ __forceinline__ bool last_block_done(int* cnt, int nblocks) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(cnt, 1);
+        s_last = (t == nblocks - 1);
+        if (s_last) *cnt = 0;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+// The decision above and the final sum, by one workgroup of 256 threads: A holds S2 on entry and [A|b] on exit.  Msh: trunc_lds_doubles().
+__device__ void trunc_finish(const DevCfg& cfg, int n, double* A, const double* S1, int good, int rows, int rows2, int e2, int smin, double* Msh) {
+    const int c6 = 6 * n, ldh = cfg.ldh, tid = threadIdx.x;
+    bool truncate = false;
+    if (good > 2 && rows > c6 && e2 >= 0 && e2 < c6 && smin < TR_NONE && smin > e2 && rows2 >= e2 + 1) {
+        // square-root-free unpivoted elimination of columns 0..e2-1 on the lower triangle of S2[0..e2][0..e2]; a column whose pivot has
+        // cancelled to rounding level is skipped (the sweep's mixture row leaves the span of the later columns alone)
+        const int m = e2 + 1, ldm = m | 1;
+        double* M = Msh; double* d0 = Msh + (size_t)trunc_mmax(cfg.max_len) * (trunc_mmax(cfg.max_len) | 1);
+        for (int e = tid; e < m * m; e += 256) { const int i = e / m, j = e - i * m; if (j <= i) M[i * ldm + j] = ld_l2(A + (size_t)i * ldh + j); }
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) d0[i] = M[i * ldm + i];
+        __syncthreads();
+        for (int k = 0; k < e2; ++k) {
+            const double dk = M[k * ldm + k];
+            if (dk > 1e-12 * d0[k]) {
+                const double rd = 1.0 / dk;
+                for (int e = tid; e < m * m; e += 256) {
+                    const int i = e / m, j = e - i * m;
+                    if (i > k && j > k && j <= i) { const double f = M[i * ldm + k] * rd; M[i * ldm + j] -= f * M[j * ldm + k]; }
+                }
+            }
+            __syncthreads();
+        }
+        truncate = !(M[e2 * ldm + e2] >= 1e-8);
+    }
+    if (!truncate)
+        for (int e = tid; e < c6 * ldh; e += 256) { if (e % ldh <= c6) A[e] = ld_l2(A + e) + ld_l2(S1 + e); }
+    if (tid == 0) {
+        double* mr = A + (size_t)ldh * (ldh - 1);
+        mr[0] = (double)good; mr[1] = (double)rows; mr[2] = truncate ? (double)e2 : -1.0;
+    }
+}
+
+// block = this shard's [S2 | S1] + counters: the sums of the accepted features' shares G_f (written by feat_build_kernel to partial[f]) in
+// ascending feature order — deterministic; also the all-gather payload of the sharded updater.  combine = 1 (unsharded update): the
+// workgroup that finishes last turns part 0 into [A|b] in place (trunc_finish), so no further launch is needed.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, const int* nrows,
+                                                          const unsigned char* types, const int* lens, double* block, int* cnt, int combine,
+                                                          size_t bs, BatchIn bin) {
+    extern __shared__ __align__(16) double g_dyn[];
     const BatchIdx bi = batch_plain();
-    partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z);
+    partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z); cnt = zoffi(cnt, bs, bi.z);
+    types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z);
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
-    // ascending list of the accepted features (wave ballots: order-preserving compaction)
-    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base;
+    // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2'
+    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -517,56 +589,83 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
-        if (flag) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = f;
+        if (flag) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = f | ((types[f] == '2') ? (1 << 30) : 0);
         __syncthreads();
         if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
         __syncthreads();
     }
     const int ng = s_base;
     const size_t gs = (size_t)ldh * ldh;
+    double* S2 = block; double* S1 = block + gs;
     for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
-        double acc = 0;
+        double a2 = 0, a1 = 0;
         if (q <= c6) {
             // eight loads in flight, then the additions in list order (the order fixes the result)
             int t = 0;
             for (; t + 8 <= ng; t += 8) {
-                double v[8];
+                double v[8]; bool is2[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)s_list[t + u] * gs + e];
+                for (int u = 0; u < 8; ++u) { const int fl = s_list[t + u]; is2[u] = (fl >> 30) & 1; v[u] = partial[(size_t)(fl & 0xffff) * gs + e]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < 8; ++u) { if (is2[u]) a2 += v[u]; else a1 += v[u]; }
             }
-            for (; t < ng; ++t) acc += partial[(size_t)s_list[t] * gs + e];
+            for (; t < ng; ++t) { const int fl = s_list[t]; const double v = partial[(size_t)(fl & 0xffff) * gs + e]; if ((fl >> 30) & 1) a2 += v; else a1 += v; }
         }
-        block[e] = acc;
+        S2[e] = a2; S1[e] = a1;
     }
-    if (bi.x == 0 && tid < 64) {
-        int good = 0, rows = 0;
-        for (int f = tid; f < Fu; f += 64) { const int r = nrows[f]; if (r > 0) { good++; rows += r; } }
-        good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows);
-        if (tid == 0) {
-            block[(size_t)cfg.ldh * (cfg.ldh - 1)] = (double)good;
-            block[(size_t)cfg.ldh * (cfg.ldh - 1) + 1] = (double)rows;
+    const bool fin = combine && last_block_done(cnt, gridDim.x);
+    if ((combine ? fin : bi.x == 0)) {
+        // counters of this shard (wave 0): accepted features, their rows, the rows / last column of type '2', the first column of type '1'
+        if (tid < 64) {
+            int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
+            for (int f = tid; f < Fu; f += 64) {
+                const int r = nrows[f];
+                if (r > 0) {
+                    good++; rows += r;
+                    const int L = lens[f];
+                    if (types[f] == '2') { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
+                    else smin = min(smin, 6 * (n - (L - 1)));
+                }
+            }
+            good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
+            for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
+            if (tid == 0) {
+                s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin;
+                if (!combine) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = good; mr[1] = rows; mr[2] = rows2; mr[3] = e2; mr[4] = smin; }
+            }
+        }
+        if (combine) {
+            __syncthreads();
+            trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
         }
     }
 }
 
-// world > 1: sum the gathered blocks in rank order -> Ab (same layout as a block, counts included)
-__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const double* blocks, int world, size_t block_stride, double* Ab) {
+// Gathered shards (rank-major, `block_stride` doubles apart) -> Ab = [A|b] + {n_good, n_rows, truncation column}: both parts are summed
+// in rank order (Ab <- S2, Ab + ldh^2 <- S1), then the workgroup that finishes last applies trunc_finish.
+__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const double* blocks, int world, size_t block_stride, double* Ab, int* cnt) {
+    extern __shared__ __align__(16) double g_dyn[];
     const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
+    const size_t gs = (size_t)ldh * ldh;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        double acc = 0;
-        for (int w = 0; w < world; ++w) acc += blocks[(size_t)w * block_stride + e];
-        Ab[e] = acc;
+        double a2 = 0, a1 = 0;
+        for (int w = 0; w < world; ++w) { a2 += blocks[(size_t)w * block_stride + e]; a1 += blocks[(size_t)w * block_stride + gs + e]; }
+        Ab[e] = a2; Ab[gs + e] = a1;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 2) {
-        const size_t t = (size_t)ldh * (ldh - 1) + threadIdx.x;
-        double acc = 0;
-        for (int w = 0; w < world; ++w) acc += blocks[(size_t)w * block_stride + t];
-        Ab[t] = acc;
+    if (!last_block_done(cnt, gridDim.x)) return;
+    __shared__ int s_cnt[5];
+    if (threadIdx.x == 0) {
+        int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
+        for (int w = 0; w < world; ++w) {
+            const double* mr = blocks + (size_t)w * block_stride + (size_t)ldh * (ldh - 1);
+            good += (int)mr[0]; rows += (int)mr[1]; rows2 += (int)mr[2]; e2 = max(e2, (int)mr[3]); smin = min(smin, (int)mr[4]);
+        }
+        s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin;
     }
+    __syncthreads();
+    trunc_finish(cfg, n, Ab, Ab + gs, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
 }
 
 // =============================================================== FP64 MFMA GEMM:  T = s2 I + A Pcc

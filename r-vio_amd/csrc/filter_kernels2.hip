@@ -34,7 +34,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     __shared__ double xs[26];
     const int tid = threadIdx.x;
     const int ld = cfg.dmax;
-    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; }
+    if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; meta->trunc_at = -1; }
     for (int e = tid; e < 576; e += 256) {
         int i = e % 24, j = e / 24;
         Pl[i][j] = P[i + (size_t)j * ld];

@@ -42,7 +42,8 @@ struct FilterMeta {
     int n_rows;        // nRowCount of the last update
     int updated;       // last update applied?
     int err;           // sticky device-side error flag (singular pivot etc.)
-    int pad[2];
+    int trunc_at;      // column at which the reference's rank scan stopped and dropped the type-'1' rows (Updater.cc:516-529), -1: no such truncation
+    int pad;
 };
 
 // phase stamps for performance debugging (tools/dbg_clocks.py): DBG_T(i) records clock64() in slot i

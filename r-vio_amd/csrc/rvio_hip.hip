@@ -46,7 +46,8 @@ struct rvio_hip {
     // update scratch
     double *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
            *Pt1 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
-    int *nrows = nullptr, *acc = nullptr, *ndof = nullptr;
+    int *nrows = nullptr, *acc = nullptr, *ndof = nullptr, *gram_cnt = nullptr;
+    size_t trunc_lds = 0;
     int feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
@@ -227,8 +228,9 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->meta, 1);
     for (int b = 0; b < 2; ++b) { DALLOC(h, h->x[b], (size_t)d.xdmax + 8); DALLOC(h, h->P[b], PP); }
     DALLOC(h, h->partial, (size_t)d.Fu * ldh * ldh);   // per-feature shares G_f = Hn^T [Hn | r] of the information block
-    DALLOC(h, h->block, ldh * ldh);
-    DALLOC(h, h->Ab, ldh * ldh);
+    DALLOC(h, h->block, 2 * ldh * ldh);   // [S2 | S1]: the type-'2' and type-'1' sums of the information block (gram_reduce_kernel)
+    DALLOC(h, h->Ab, 2 * ldh * ldh);
+    DALLOC(h, h->gram_cnt, 8);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
@@ -321,6 +323,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     if (d.Fu > GRAM_MAX_FEATS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
     if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
+    h->trunc_lds = trunc_lds_doubles(d.max_len) * sizeof(double);
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     bool need_tm_global = false;
     // (a batch handle keeps T in global memory as well: a third less LDS per feature workgroup = 8 instead of 5 resident per CU)
@@ -369,6 +372,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
@@ -559,7 +564,7 @@ static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
     return RVIO_OK;
 }
 
-static int update_local_dev(rvio_hip* h, int rank, int world) {
+static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host;
     const size_t bs = h->slab_bytes;
@@ -573,8 +578,9 @@ static int update_local_dev(rvio_hip* h, int rank, int world) {
     hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global, bs, h->bin);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), 0, h->stream, d, n,
-                       h->partial, h->nrows, h->block, bs);
+    // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
+                       h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, bs, h->bin);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -598,7 +604,8 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
 }
 
-static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
+// combined: d_blocks is the handle's own block, already turned into [A|b] by gram_reduce_kernel (unsharded update)
+static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, bool combined) {
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host, c6 = 6 * n, dd = 24 + c6;
     const long ldh = d.ldh;
@@ -607,13 +614,10 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
     const double* Ab = d_blocks;
     const size_t bs = h->slab_bytes;
     const int B = h->batch;
-    if (B > 1 && (world > 1 || d_blocks != h->block)) { h->err = "a batch handle runs the unsharded updater only"; return RVIO_ERR_UNSUPPORTED; }
-    if (world > 1) {   // sum the gathered [A|b] blocks in rank order
+    if (B > 1 && !combined) { h->err = "a batch handle runs the unsharded updater only"; return RVIO_ERR_UNSUPPORTED; }
+    if (!combined) {   // gathered shards [S2 | S1]: sum both parts in rank order, then the rank truncation -> Ab = [A|b]
         const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
-        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), 0, h->stream, d, n, d_blocks, world, (size_t)(ldh * ldh), h->Ab);
-        Ab = h->Ab;
-    } else if (d_blocks != h->block) {   // a caller-owned block: the truncation below works on our copy
-        HIPCHK(h, hipMemcpyAsync(h->Ab, d_blocks, sizeof(double) * ldh * ldh, hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), h->trunc_lds, h->stream, d, n, d_blocks, world, (size_t)(2 * ldh * ldh), h->Ab, h->gram_cnt);
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
@@ -631,9 +635,9 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world) {
 int rvio_hip_update_tracked(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = update_local_dev(h, 0, 1);
+    int rc = update_local_dev(h, 0, 1, true);
     if (rc != RVIO_OK) return rc;
-    return update_global_dev(h, h->block, 1);
+    return update_global_dev(h, h->block, 1, true);
 }
 int rvio_hip_update(rvio_hip* h, const rvio_tracks* tracks) {
     if (!h) return RVIO_ERR_INVALID;
@@ -647,15 +651,15 @@ int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int 
     if (!h || world < 1 || rank < 0 || rank >= world) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     if (tracks) { int rc = upload_tracks(h, tracks); if (rc != RVIO_OK) return rc; }
-    int rc = update_local_dev(h, rank, world);
+    int rc = update_local_dev(h, rank, world, false);
     if (d_block) *d_block = h->block;
-    if (n_doubles) *n_doubles = h->dc.ldh * h->dc.ldh;
+    if (n_doubles) *n_doubles = 2 * h->dc.ldh * h->dc.ldh;
     return rc;
 }
 int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
     if (!h || !d_blocks || world < 1) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    return update_global_dev(h, d_blocks, world);
+    return update_global_dev(h, d_blocks, world, false);
 }
 
 int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv) {
@@ -1183,6 +1187,7 @@ int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     info->n_clones = h->n_clones_host; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
     info->reserved[0] = m.err;
+    info->rank_truncated_at = m.updated ? m.trunc_at : -1;
     return RVIO_OK;
 }
 int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]) {

@@ -33,7 +33,7 @@ __device__ __forceinline__ void solve4_body(const DevCfg& cfg, FilterMeta* __res
     double* M = USE_LDS ? sh : Mg;
     const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
     const bool upd = n_good > 2;                       // Updater.cc:460
-    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; }
     if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
         for (int e = tid; e < c6 * c6; e += SOLVE4_T) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
         for (int i = tid; i < xd; i += SOLVE4_T) x_out[i] = x[i];

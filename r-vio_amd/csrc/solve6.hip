@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * NW) void solve6_kernel(DevCfg cfg, FilterMeta*
     const int lrow = lane < RPW ? lane : 0;             // lane <-> row passes: surplus lanes alias row 0 (reads only)
     const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
     const bool upd = n_good > 2;                       // Updater.cc:460
-    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; }
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; }
     if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
         for (int e = tid; e < c6 * c6; e += NT) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
         for (int i = tid; i < xd; i += NT) x_out[i] = x[i];

@@ -102,8 +102,41 @@ def update(cfg, x, P, types, lens, meas):
                                   n_rows=int(info[1]), rank=int(info[2]), updated=int(info[3]))
 
 
+def update_stack(cfg, x, P, types, lens, meas):
+    """U1..U6: the stacked (Hw [M, 6n], r [M]) of the accepted features and nGoodFeatCount"""
+    x = np.ascontiguousarray(x, float)
+    d = P.shape[0]
+    Pf = np.asfortranarray(P, dtype=float)
+    tr = abi.make_tracks(types, lens, meas)
+    nc6 = 6 * ((len(x) - 26) // 7)
+    rows = int(2 * np.sum(lens))
+    Hw, r = np.zeros((max(rows, 1), nc6)), np.zeros(max(rows, 1))
+    ng = C.c_int32(0)
+    L = lib()
+    L.orc_update_stack.restype = C.c_int
+    M = L.orc_update_stack(C.byref(cfg), _p(x, dp), len(x), Pf.ctypes.data_as(dp), d, C.byref(tr), _p(Hw, dp), _p(r, dp), C.byref(ng))
+    return Hw[:M].copy(), r[:M].copy(), ng.value
+
+
+def update_from_stack(cfg, x, P, Hw, r, n_good):
+    """U7..U10 (literal Givens QR + rank scan) on a given stacked pair; diag carries the row norms after the sweep"""
+    x = np.ascontiguousarray(x, float)
+    d = P.shape[0]
+    Pf = np.asfortranarray(P, dtype=float)
+    Hw = np.ascontiguousarray(Hw, float)
+    r = np.ascontiguousarray(r, float)
+    M, nc6 = Hw.shape
+    xo, Po = np.zeros_like(x), np.zeros((d, d), order="F")
+    info = np.zeros(4, np.int32)
+    norms = np.zeros(max(min(M, 2 * nc6), 1))
+    lib().orc_update_from_stack(C.byref(cfg), _p(x, dp), len(x), Pf.ctypes.data_as(dp), d, _p(Hw, dp), _p(r, dp), M, int(n_good),
+                                _p(xo, dp), Po.ctypes.data_as(dp), _p(info, ip), _p(norms, dp))
+    return xo, np.array(Po), dict(n_good=int(info[0]), n_rows=int(info[1]), rank=int(info[2]), updated=int(info[3]), row_norms=norms)
+
+
 def block_len(n_clones):
-    return 6 * n_clones * (6 * n_clones + 1) + 2
+    """per-shard payload of the oracle's mirror: type-'2' part, type-'1' part, 8 counters (oracle/filter.cpp:orc_update_local)"""
+    return 2 * 6 * n_clones * (6 * n_clones + 1) + 8
 
 
 def update_local(cfg, x, P, types, lens, meas, rank, world):
@@ -126,7 +159,7 @@ def update_global(cfg, x, P, blocks):
     info = np.zeros(4, np.int32)
     lib().orc_update_global(C.byref(cfg), _p(x, dp), len(x), Pf.ctypes.data_as(dp), d, _p(blocks, dp), world,
                             _p(xo, dp), Po.ctypes.data_as(dp), _p(info, ip))
-    return xo, np.array(Po), dict(n_good=int(info[0]), n_rows=int(info[1]), updated=int(info[3]))
+    return xo, np.array(Po), dict(n_good=int(info[0]), n_rows=int(info[1]), truncated_at=int(info[2]), updated=int(info[3]))
 
 
 def augment_compose(cfg, x, P, do_augment=True):
@@ -293,8 +326,9 @@ class System:
     """oracle mirror of the timed body of System::MonoVIO."""
 
     def __init__(self, cfg, information_form=False):
-        """information_form=True: analysis mode — the update runs in the device's formulation ([A|b] = Hw^T[Hw|r]),
-        which keeps the rows the reference's rank truncation (Updater.cc:516-529) drops."""
+        """information_form=True: diagnostic mode — the update runs in the device's formulation ([A|b] = Hw^T[Hw|r] with the
+        structural form of the reference's rank truncation, oracle/filter.cpp:orc_update_local/global) instead of the literal
+        Givens QR + leading-row scan (Updater.cc:469-529)."""
         self.cfg = cfg
         self.h = C.c_void_p(lib().orc_system_create(C.byref(cfg)))
         self.nmax = cfg.max_track_len - 1

@@ -150,14 +150,16 @@ def test_sharded_updater_fake_shards_on_one_gpu(hipB, recB, world):
         blocks.append(torch.as_tensor(DA(ptr, n), device="cuda").clone())
     allb = torch.cat(blocks).contiguous()
     torch.cuda.synchronize()
-    # block of rank k equals the oracle's block (information form is order-insensitive up to rounding)
+    # block of rank k equals the oracle's block: type-'2' part, type-'1' part, counters (information form is order-insensitive up to rounding)
     nb = blocks[0].numel()
     ob = O.update_local(cfg, r["x1"], r["P1"], types, lens, meas, 1, world)
     gb = blocks[1].cpu().numpy()
     ldh = 6 * (cfg.max_track_len - 1) + 1
-    assert nb == ldh * ldh
-    assert np.allclose(gb[: ldh * (ldh - 1)], ob[: ldh * (ldh - 1)], rtol=1e-9, atol=1e-9 * np.max(np.abs(ob)))
-    assert gb[ldh * (ldh - 1)] == ob[-2] and gb[ldh * (ldh - 1) + 1] == ob[-1]
+    part = ldh * (ldh - 1)
+    assert nb == 2 * ldh * ldh and len(ob) == 2 * part + 8
+    for pt in range(2):
+        assert np.allclose(gb[pt * ldh * ldh: pt * ldh * ldh + part], ob[pt * part: (pt + 1) * part], rtol=1e-9, atol=1e-9 * np.max(np.abs(ob[: 2 * part])))
+    assert np.array_equal(gb[part: part + 5], ob[2 * part: 2 * part + 5])
     hipB.update_global(allb.data_ptr(), world)
     x, P = hipB.get_state()
     assert S.state_delta(x, xo) <= X_TOL

@@ -65,4 +65,6 @@ def test_sharded_update_gloo(world, tmp_path):
     assert S.state_delta(res[0]["x"], xo) < 1e-9
     assert np.max(np.abs(res[0]["P"] - Po)) < 1e-9 * np.max(np.abs(Po))
     # every feature is owned by exactly one rank: per-rank accepted counts add up
-    assert sum(int(res[k]["own"][-2]) for k in range(world)) == d["n_good"]
+    # (payload: type-'2' part, type-'1' part, then 8 counters starting with n_good, n_rows — oracle/filter.cpp:orc_update_local)
+    assert sum(int(res[k]["own"][-8]) for k in range(world)) == d["n_good"]
+    assert sum(int(res[k]["own"][-7]) for k in range(world)) == d["n_rows"]
