@@ -98,7 +98,7 @@ bool parse_settings(const std::string& text, Settings* out, std::string* err) {
     c.max_track_len = (int)num("Tracker.nMaxTrackingLength", c.max_track_len);
     c.min_track_len = (int)num("Tracker.nMinTrackingLength", c.min_track_len);
     c.min_dist = (float)num("Tracker.nMinDist", c.min_dist); c.qual_lvl = (float)num("Tracker.nQualLvl", c.qual_lvl);
-    c.block_x = (int)num("Tracker.nBlockSizeX", c.block_x); c.block_y = (int)num("Tracker.nBlockSizeY", c.block_y);
+    c.block_x = (float)num("Tracker.nBlockSizeX", c.block_x); c.block_y = (float)num("Tracker.nBlockSizeY", c.block_y);
     c.enable_equalizer = (int)num("Tracker.EnableEqualizer", c.enable_equalizer);
     c.use_sampson = (int)num("Tracker.UseSampson", c.use_sampson);
     c.inlier_thr = num("Tracker.nInlierThrd", c.inlier_thr);

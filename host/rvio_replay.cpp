@@ -25,8 +25,8 @@ static int check_settings(const char* path) {
     std::printf("{\"imu_rate\": %.17g, \"sigma_g\": %.17g, \"sigma_wg\": %.17g, \"sigma_a\": %.17g, \"sigma_wa\": %.17g, \"gravity\": %.17g, "
                 "\"small_angle\": %.17g, \"width\": %d, \"height\": %d, \"fx\": %.9g, \"fy\": %.9g, \"cx\": %.9g, \"cy\": %.9g, "
                 "\"k1\": %.9g, \"k2\": %.9g, \"p1\": %.9g, \"p2\": %.9g, \"k3\": %.9g, \"sigma_px\": %.9g, \"sigma_py\": %.9g, \"fisheye\": %d, "
-                "\"n_features\": %d, \"max_track_len\": %d, \"min_track_len\": %d, \"min_dist\": %.9g, \"qual_lvl\": %.9g, \"block_x\": %d, "
-                "\"block_y\": %d, \"enable_equalizer\": %d, \"use_sampson\": %d, \"inlier_thr\": %.17g, \"ini_thr_angle\": %.17g, "
+                "\"n_features\": %d, \"max_track_len\": %d, \"min_track_len\": %d, \"min_dist\": %.9g, \"qual_lvl\": %.9g, \"block_x\": %.9g, "
+                "\"block_y\": %.9g, \"enable_equalizer\": %d, \"use_sampson\": %d, \"inlier_thr\": %.17g, \"ini_thr_angle\": %.17g, "
                 "\"ini_thr_displ\": %.17g, \"ini_enable_alignment\": %d, \"cam_time_offset\": %.17g, \"record_outputs\": %d, \"T_bc\": [",
                 c.imu_rate, c.sigma_g, c.sigma_wg, c.sigma_a, c.sigma_wa, c.gravity, c.small_angle, c.width, c.height, c.fx, c.fy, c.cx, c.cy,
                 c.k1, c.k2, c.p1, c.p2, c.k3, c.sigma_px, c.sigma_py, c.fisheye, c.n_features, c.max_track_len, c.min_track_len, c.min_dist,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RVIO_HIP_ABI_VERSION 1
+#define RVIO_HIP_ABI_VERSION 2
 
 typedef enum rvio_status {
     RVIO_OK = 0,
@@ -67,7 +67,7 @@ typedef struct rvio_config {
     int32_t min_track_len;            /* Tracker.nMinTrackingLength (Tracker.cc:79)  */
     float   min_dist;                 /* Tracker.nMinDist           (FeatureDetector.cc:31) */
     float   qual_lvl;                 /* Tracker.nQualLvl           */
-    int32_t block_x, block_y;         /* Tracker.nBlockSizeX/Y      (FeatureDetector.cc:34-35) */
+    float   block_x, block_y;         /* Tracker.nBlockSizeX/Y, stored as float like upstream (FeatureDetector.h:72-73) */
     int32_t enable_equalizer;         /* Tracker.EnableEqualizer    (Tracker.cc:70-71) */
     int32_t use_sampson;              /* Tracker.UseSampson         (Ransac.cc:34-35) */
     double  inlier_thr;               /* Tracker.nInlierThrd        (Ransac.cc:37)    */

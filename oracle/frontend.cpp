@@ -390,7 +390,7 @@ struct orc_tracker {
     std::vector<unsigned char> types;          // mvFeatTypesForUpdate
     std::vector<std::list<Pt>> meas;           // mvlFeatMeasForUpdate
     // FeatureDetector grid params, FeatureDetector.cc:29-52
-    int gridCols, gridRows, blocks; float offX, offY, maxPerBlock;
+    int gridCols, gridRows, blocks, offX, offY, maxPerBlock;   // all int members upstream (FeatureDetector.h:66-77)
 };
 
 namespace {
@@ -456,8 +456,9 @@ orc_tracker* orc_tracker_create(const rvio_config* cfg) {
     T->hist.resize(T->F);
     T->gridCols = (int)std::floor(cfg->width / cfg->block_x); T->gridRows = (int)std::floor(cfg->height / cfg->block_y);
     T->blocks = T->gridCols * T->gridRows;
-    T->offX = .5f * (cfg->width - T->gridCols * cfg->block_x); T->offY = .5f * (cfg->height - T->gridRows * cfg->block_y);
-    T->maxPerBlock = (float)T->F / T->blocks;
+    // int members upstream (FeatureDetector.h:69-77): the assignments truncate
+    T->offX = (int)(.5 * (cfg->width - T->gridCols * cfg->block_x)); T->offY = (int)(.5 * (cfg->height - T->gridRows * cfg->block_y));
+    T->maxPerBlock = (int)((float)T->F / T->blocks);
     return T;
 }
 void orc_tracker_destroy(orc_tracker* T) { delete T; }

@@ -7,7 +7,7 @@ import ctypes as C
 import math
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class rvio_config(C.Structure):
@@ -23,7 +23,7 @@ class rvio_config(C.Structure):
         ("fisheye", C.c_int32),
         ("n_features", C.c_int32), ("max_track_len", C.c_int32), ("min_track_len", C.c_int32),
         ("min_dist", C.c_float), ("qual_lvl", C.c_float),
-        ("block_x", C.c_int32), ("block_y", C.c_int32),
+        ("block_x", C.c_float), ("block_y", C.c_float),
         ("enable_equalizer", C.c_int32), ("use_sampson", C.c_int32),
         ("inlier_thr", C.c_double),
         ("ini_thr_angle", C.c_double), ("ini_thr_displ", C.c_double),

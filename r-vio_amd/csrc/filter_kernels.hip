@@ -40,7 +40,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                                                 const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                 int shard_rank, int shard_world,
                                                 double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
+                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
@@ -71,6 +71,11 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     }
     const unsigned char type = types[f];
     const int L = lens[f];
+    // a track the window cannot hold (caller-provided device tables, or a tracker that outlived a state reset): drop it and say so
+    if (L < 2 || L > cfg.max_len || L - 1 > n || (type != '1' && type != '2')) {
+        if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; atomicOr(&zoffi(meta, bs, bi.z)->err, 2); }
+        return;
+    }
     const float* mz = meas + (size_t)f * cfg.max_len * 2;
     float mxv = 0, myv = 0;
     const int lane = tid & 63;
@@ -485,9 +490,9 @@ __global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const doub
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
                                   double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin) {
+                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
     feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
-                    tm_global, bs, bin);
+                    tm_global, bs, bin, meta);
 }
 
 // =============================================================== U7 compression, information form (reduction stage)

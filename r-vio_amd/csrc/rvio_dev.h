@@ -24,13 +24,14 @@ struct DevCfg {
     double inlier_thr;
     double Ric[9], Rci[9], tic[3], tci[3];  // row-major 3x3 (Updater.cc:46-53)
     float fx, fy, cx, cy, k1, k2, p1, p2, k3;
-    float min_dist, off_x, off_y, max_per_block;  // FeatureDetector.cc:29-52
+    float min_dist, off_x, off_y, max_per_block;  // FeatureDetector.cc:29-52; the last three hold the reference's INT members (FeatureDetector.h:69-77)
+    float block_x, block_y;                       // float members upstream (FeatureDetector.h:72-73)
     int W, H;
     int F, Fu, max_len, min_len;
     int nmax, dmax, xdmax;
     int rho_max;   // max nullspace rows per feature = 2*max_len - 2
     int ldh;       // row stride (doubles) of stacked [Hx | r] rows = 6*nmax + 1
-    int grid_cols, grid_rows, block_x, block_y;
+    int grid_cols, grid_rows;
     int use_sampson;
     int levels;    // pyramid levels actually used (maxLevel+1)
 };

@@ -208,11 +208,12 @@ static void fill_devcfg(const rvio_config* c, DevCfg* d) {
     // FeatureDetector ctor, FeatureDetector.cc:29-52
     d->min_dist = c->min_dist;
     d->block_x = c->block_x; d->block_y = c->block_y;
-    d->grid_cols = (int)std::floor((double)(c->width / c->block_x));
-    d->grid_rows = (int)std::floor((double)(c->height / c->block_y));
-    d->off_x = (float)(.5 * (c->width - d->grid_cols * c->block_x));
-    d->off_y = (float)(.5 * (c->height - d->grid_rows * c->block_y));
-    d->max_per_block = (float)c->n_features / (float)(d->grid_cols * d->grid_rows);
+    // (mnGridCols/Rows, mnOffsetX/Y and mnMaxFeatsPerBlock are `int` members upstream: the assignments truncate, FeatureDetector.h:66-77)
+    d->grid_cols = (int)std::floor(c->width / c->block_x);
+    d->grid_rows = (int)std::floor(c->height / c->block_y);
+    d->off_x = (float)(int)(.5 * (c->width - d->grid_cols * c->block_x));
+    d->off_y = (float)(int)(.5 * (c->height - d->grid_rows * c->block_y));
+    d->max_per_block = (d->grid_cols * d->grid_rows > 0) ? (float)(int)((float)c->n_features / (d->grid_cols * d->grid_rows)) : 0.f;
     d->use_sampson = c->use_sampson;
     // buildOpticalFlowPyramid: stop when a level is not larger than the window
     int w = c->width, hgt = c->height, lv = 1;
@@ -526,6 +527,23 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
     for (int i = 18; i < 21; ++i) D(i, n_imu * dt * std::pow(c.sigma_wg, 2));
     for (int i = 21; i < 24; ++i) D(i, n_imu * dt * std::pow(c.sigma_wa, 2));
     h->img_count = 0;
+    // a (re-)initialised filter starts with an empty window: the tracker starts over too (mbIsTheFirstImage, Tracker.cc:88), or its
+    // histories would be longer than the window they refer to
+    if (h->front_end) {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc0 = rvio_hip_sync(h);
+        if (rc0 != RVIO_OK) return rc0;
+        std::vector<int> ones((size_t)h->batch, 1);
+        HIPCHK(h, hipMemcpy2DAsync(h->t.first, h->slab_bytes, ones.data(), sizeof(int), sizeof(int), (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+        for (int i = 0; i < h->batch; ++i) {
+            const size_t o = (size_t)i * h->slab_bytes;
+            HIPCHK(h, hipMemsetAsync((char*)h->t.n_pts + o, 0, sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync((char*)h->t.hist_len + o, 0, sizeof(int) * h->dc.F, h->stream));
+            for (int b = 0; b < 2; ++b) HIPCHK(h, hipMemsetAsync((char*)h->tout[b].n_feat + o, 0, sizeof(int), h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->frame_no = 0; h->piped = false; h->in_frame = false; h->fuse_m = -1;
+    }
     return rvio_hip_set_state(h, x, 26, P, 24);
 }
 
@@ -577,7 +595,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     } else
     hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global, bs, h->bin);
+                       h->tm_global, bs, h->bin, h->meta);
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
                        h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, bs, h->bin);
@@ -1271,7 +1289,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         } else {
             hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
-                               h->slab_bytes, h->bin);
+                               h->slab_bytes, h->bin, h->meta);
         }
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));

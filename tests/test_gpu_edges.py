@@ -115,3 +115,21 @@ def test_row_strided_image_and_empty_corner_list(gpu_required, seqB):
         _same_tracker(h2, t, i)
     h.close()
     h2.close()
+
+
+def test_find_newer_int_members_on_the_device(gpu_required):
+    """FeatureDetector's grid members are int upstream (FeatureDetector.h:66-77): odd left-over border, nFeatures not divisible by the
+    block count, non-integer block sizes — the device refill against the oracle (itself pinned by tests/test_oracle_pins.py)"""
+    from rvio_amd import hip
+    from test_oracle_pins import FIND_NEWER_CASES, find_newer_inputs
+    imu = np.zeros(0, abi.IMU_DTYPE)
+    for case in FIND_NEWER_CASES:
+        cfg = abi.config_named("B", width=376, height=240, fx=229.327, fy=228.648, cx=183.6075, cy=124.1875, min_dist=5, enable_equalizer=0, **case)
+        ref, cand = find_newer_inputs(cfg)
+        h, t = hip.RvioHip(cfg), O.Tracker(cfg)
+        for tr in (h, t):
+            tr.track_points(np.zeros((0, 2), np.float32), np.zeros(0, np.uint8), imu, ref)
+            tr.track_points(ref, np.ones(len(ref), np.uint8), imu, cand)
+        n_pts, _ = _same_tracker(h, t, case)
+        assert n_pts > 50
+        h.close()

@@ -287,3 +287,69 @@ def test_golden_image_fixture_regression():
         assert np.array_equal(pts, g["pts%d" % i]) and np.array_equal(hl, g["hist%d" % i]), i
     assert np.array_equal(O.detect(cfg, O.clahe(g["imgs"][0]), 1), g["corners0"])
     assert zlib.crc32(O.clahe(g["imgs"][0]).tobytes()) == int(g["clahe0_crc"])
+
+
+def _find_newer_py(cfg, corners, ref):
+    """FeatureDetector::FindNewer/ChessGrid (FeatureDetector.cc:78-150) written out independently, with the member types of
+    FeatureDetector.h:66-77: mnGridCols/Rows, mnOffsetX/Y and mnMaxFeatsPerBlock are int (their initialisers truncate),
+    mnBlockSizeX/Y and mnMinDistance are float"""
+    f32 = np.float32
+    bx, by, md = f32(cfg.block_x), f32(cfg.block_y), f32(cfg.min_dist)
+    gc, gr = int(np.floor(f32(cfg.width) / bx)), int(np.floor(f32(cfg.height) / by))
+    offx, offy = int(.5 * (cfg.width - gc * float(bx))), int(.5 * (cfg.height - gr * float(by)))
+    maxpb = int(f32(cfg.n_features) / f32(gc * gr))
+    grid = [[] for _ in range(gc * gr)]
+
+    def outside(p):
+        return p[0] <= f32(offx) or p[1] <= f32(offy) or p[0] >= f32(cfg.width - offx) or p[1] >= f32(cfg.height - offy)
+
+    def cell(p):
+        return int(np.floor((p[0] - f32(offx)) / bx)), int(np.floor((p[1] - f32(offy)) / by))
+    for p in ref:
+        if not outside(p):
+            c, r = cell(p)
+            grid[r * gc + c].append(p)
+    out = []
+    for p in corners:
+        if outside(p):
+            continue
+        c, r = cell(p)
+        xl = f32(f32(c) * bx + f32(offx)); xr = f32(xl + bx); yt = f32(f32(r) * by + f32(offy)); yb = f32(yt + by)
+        if abs(f32(p[0] - xl)) < md or abs(f32(p[0] - xr)) < md or abs(f32(p[1] - yt)) < md or abs(f32(p[1] - yb)) < md:
+            continue
+        g = grid[r * gc + c]
+        if float(f32(len(g))) < .75 * maxpb:
+            if all(np.sqrt(float(f32(p[0] - q[0])) ** 2 + float(f32(p[1] - q[1])) ** 2) > float(md) for q in g):
+                out.append(p)
+                g.append(p)
+    return out
+
+
+FIND_NEWER_CASES = [dict(block_x=75, block_y=75, n_features=250), dict(block_x=75.5, block_y=60.25, n_features=250),
+                    dict(block_x=94, block_y=80, n_features=100)]
+
+
+def find_newer_inputs(cfg, seed=3):
+    """ten tracked points (too few for RANSAC: every one stays) and a dense, randomly ordered candidate list"""
+    rng = np.random.default_rng(seed)
+    ref = (rng.uniform([20, 20], [cfg.width - 20, cfg.height - 20], (10, 2))).astype(np.float32)
+    cand = (rng.uniform([0, 0], [cfg.width, cfg.height], (cfg.n_features, 2))).astype(np.float32)
+    return ref, cand
+
+
+@pytest.mark.parametrize("case", FIND_NEWER_CASES)
+def test_find_newer_uses_the_int_members_of_the_reference(case):
+    """odd left-over border (376 - 5*75 = 1 -> mnOffsetX = 0, not 0.5), nFeatures not divisible by the block count
+    (250/15 -> 16, the refill cap .75*16 = 12, not 12.5) and non-integer block sizes (float members upstream)"""
+    cfg = abi.config_named("B", width=376, height=240, fx=229.327, fy=228.648, cx=183.6075, cy=124.1875, min_dist=5, enable_equalizer=0, **case)
+    ref, cand = find_newer_inputs(cfg)
+    t = O.Tracker(cfg)
+    imu = np.zeros(0, abi.IMU_DTYPE)
+    t.track_points(np.zeros((0, 2), np.float32), np.zeros(0, np.uint8), imu, ref)          # first image: the list is taken as it is
+    assert np.array_equal(t.get_points()[0], ref)
+    t.track_points(ref, np.ones(len(ref), np.uint8), imu, cand)                              # refill through FindNewer
+    pts = t.get_points()[0]
+    want = _find_newer_py(cfg, cand, ref)[: cfg.n_features - len(ref)]
+    assert len(want) > 40
+    assert np.array_equal(pts[: len(ref)], ref)
+    assert np.array_equal(pts[len(ref):], np.array(want, np.float32))
