@@ -108,8 +108,12 @@ struct FeatOut {
 };
 
 // Updater.cc:109-455 for one feature.  Pcc = Pk1k.block(24,24,6n,6n).
+// probe (tests only): evaluate the measurement model at a GIVEN inverse-depth triple instead of the LM result, and hand out the
+// residual / Jacobians as they are before the nullspace projection (finite-difference pin of U3, tests/test_oracle_pins.py)
+struct FeatProbe { const double* pf = nullptr; Mat* Hx_raw = nullptr; Mat* Hf_raw = nullptr; std::vector<double>* r_raw = nullptr; };
+
 FeatOut feature_rows(const rvio_config* cfg, const Extr& ex, double sig, const double* x, int n_clones,
-                     const Mat& Pcc, unsigned char type, const float* meas, int L) {
+                     const Mat& Pcc, unsigned char type, const float* meas, int L, const FeatProbe* probe = nullptr) {
     FeatOut out;
     const int nc6 = 6 * n_clones;
     int nTrackLength = L, nTrackPhases = L - 1;
@@ -150,7 +154,14 @@ FeatOut feature_rows(const rvio_config* cfg, const Extr& ex, double sig, const d
     const int maxIter = 10;
     double lambda = 0.01;
     double lastCost = std::numeric_limits<double>::infinity();
-    for (int it = 0; it < maxIter; ++it) {
+    if (probe && probe->pf) {
+        phi = probe->pf[0]; psi = probe->pf[1]; rho = probe->pf[2];
+        ep = v3(std::cos(phi) * std::sin(psi), std::sin(phi), std::cos(phi) * std::cos(psi));
+        Jang[0][0] = -std::sin(phi) * std::sin(psi); Jang[0][1] = std::cos(phi) * std::cos(psi);
+        Jang[1][0] = std::cos(phi);                  Jang[1][1] = 0;
+        Jang[2][0] = -std::sin(phi) * std::cos(psi); Jang[2][1] = -std::cos(phi) * std::sin(psi);
+    }
+    for (int it = 0; it < ((probe && probe->pf) ? 0 : maxIter); ++it) {
         double HTH[3][3] = {{0}}; double HTe[3] = {0}; double cost = 0;
         auto accumulate = [&](const double H[2][3], float exf, float eyf) {
             double e[2] = {(double)exf, (double)eyf};
@@ -250,6 +261,11 @@ FeatOut feature_rows(const rvio_config* cfg, const Extr& ex, double sig, const d
         }
     }
 
+    if (probe) {
+        if (probe->Hx_raw) *probe->Hx_raw = Hx;
+        if (probe->Hf_raw) *probe->Hf_raw = Hf;
+        if (probe->r_raw) *probe->r_raw = r;
+    }
     // Givens left-nullspace marginalisation :370-402
     int N = 3;
     { double s = 0; for (int i = 0; i < M; ++i) s += Hf(i, 2) * Hf(i, 2); if (std::sqrt(s) < 1e-4) N--; }
@@ -517,6 +533,27 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
     Mat Hw; std::vector<double> r; int nGood = 0;
     int nRowCount = stack_rows(cfg, x, xdim, P, tr, Hw, r, accepted, gamma, ndof, pfinv, &nGood);
     compress_and_apply(cfg, x, xdim, Pin, d, P, Hw, r, nRowCount, nGood, x_out, P_out, info, nullptr);
+}
+
+// U1..U3 of one feature at a given (phi, psi, rho) (pf == NULL: the LM estimate): residual (2 Lu), Hx (2 Lu x 6n, row-major) and
+// Hf (2 Lu x 3) before the nullspace projection; returns 2 Lu (Lu = L, or ceil(L/2) for type '2'), 0 if the feature is rejected early
+int orc_feature_model(const rvio_config* cfg, const double* x, int xdim, unsigned char type, const float* meas, int L,
+                      const double* pf, double* r_out, double* Hx_rowmajor, double* Hf_rowmajor, double* pf_out) {
+    const int n = (xdim - 26) / 7, nc6 = 6 * n;
+    const Extr ex = extrinsics(cfg);
+    Mat Pcc = Mat::identity(nc6);
+    Mat Hx, Hf; std::vector<double> r;
+    FeatProbe pr; pr.pf = pf; pr.Hx_raw = &Hx; pr.Hf_raw = &Hf; pr.r_raw = &r;
+    FeatOut fo = feature_rows(cfg, ex, sigma_im(cfg), x, n, Pcc, type, meas, L, &pr);
+    if (pf_out) { pf_out[0] = fo.phi; pf_out[1] = fo.psi; pf_out[2] = fo.rho; }
+    if (r.empty()) return 0;
+    const int M = (int)r.size();
+    for (int i = 0; i < M; ++i) {
+        r_out[i] = r[i];
+        for (int j = 0; j < nc6; ++j) Hx_rowmajor[(size_t)i * nc6 + j] = Hx(i, j);
+        for (int j = 0; j < 3; ++j) Hf_rowmajor[i * 3 + j] = Hf(i, j);
+    }
+    return M;
 }
 
 // The two halves of orc_update, separately (analysis of the rank truncation, tests/test_truncation.py):

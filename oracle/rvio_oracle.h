@@ -44,6 +44,11 @@ void orc_update(const rvio_config* cfg, const double* x, int xdim, const double*
                 const rvio_tracks* tracks, double* x_out, double* P_out,
                 int32_t* accepted, double* gamma, int32_t* ndof, double* pfinv, int32_t info[4]);
 
+/* U1..U3 of one feature evaluated at a given inverse-depth triple pf = (phi, psi, rho) (NULL: the LM estimate, returned in pf_out):
+ * residual, Hx (row-major 2Lu x 6n) and Hf (2Lu x 3) BEFORE the nullspace projection; returns 2Lu.  Finite-difference pin of U3. */
+int orc_feature_model(const rvio_config* cfg, const double* x, int xdim, unsigned char type, const float* meas, int L,
+                      const double* pf, double* r_out, double* Hx_rowmajor, double* Hf_rowmajor, double* pf_out);
+
 /* The two halves of orc_update (analysis of the rank truncation Updater.cc:516-529, tests/test_truncation.py):
  * orc_update_stack = U1..U6, returns M and the stacked pair (Hw row-major M x 6n, r) of the accepted features;
  * orc_update_from_stack = U7..U10 on a given pair; row_norms (may be NULL) = norms of the first min(M,12n) rows after the sweep */

@@ -102,6 +102,19 @@ def update(cfg, x, P, types, lens, meas):
                                   n_rows=int(info[1]), rank=int(info[2]), updated=int(info[3]))
 
 
+def feature_model(cfg, x, ftype, meas, L, pf=None):
+    """U1..U3 of one feature at pf = (phi, psi, rho) (None: the LM estimate): (r [2Lu], Hx [2Lu, 6n], Hf [2Lu, 3], pf)"""
+    x = np.ascontiguousarray(x, float)
+    meas = np.ascontiguousarray(meas, np.float32)
+    nc6 = 6 * ((len(x) - 26) // 7)
+    r, Hx, Hf, pfo = np.zeros(2 * L), np.zeros((2 * L, nc6)), np.zeros((2 * L, 3)), np.zeros(3)
+    pfa = None if pf is None else np.ascontiguousarray(pf, float)
+    L_ = lib()
+    L_.orc_feature_model.restype = C.c_int
+    M = L_.orc_feature_model(C.byref(cfg), _p(x, dp), len(x), C.c_ubyte(int(ftype)), _p(meas, fp), int(L), _p(pfa, dp), _p(r, dp), _p(Hx, dp), _p(Hf, dp), _p(pfo, dp))
+    return r[:M].copy(), Hx[:M].copy(), Hf[:M].copy(), pfo
+
+
 def update_stack(cfg, x, P, types, lens, meas):
     """U1..U6: the stacked (Hw [M, 6n], r [M]) of the accepted features and nGoodFeatCount"""
     x = np.ascontiguousarray(x, float)

@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "A": (dict(), 34, [20, 33]),                                   # stock EuRoC: 200 f / 14 clones (d = 108)
     "C": (dict(), 46, [30, 45]),                                   # 400 f / 20 clones (d = 144)
-    "E-shaped": (dict(n_features=400), 66, [50, 65]),              # 30 clones (d = 204), fewer features to keep the CPU oracle quick
+    "D": (dict(), 40, [25, 39]),                                   # 800 f / 15 clones (d = 114), filter side of the 1080p configuration
+    "E-shaped": (dict(n_features=400), 66, [50, 65]),              # 30 clones (d = 204), fewer features
+    "E": (dict(), 66, [50, 65]),                                   # the real thing: 1600 f / 30 clones (Fu = 800 feature slots)
 }
 
 
@@ -91,6 +93,45 @@ def test_free_running_sequence(case):
         assert np.array_equal(pts, r["pts"]) and np.array_equal(hl, r["hist_len"])
     h.close()
     assert worst <= 1e-6, worst
+
+
+@pytest.mark.parametrize("name", ["A", "C", "D"])
+def test_whole_frame_on_images(gpu_required, name):
+    """the stock path (CLAHE + device detector + KLT + RANSAC + filter) on the other configurations: 12 rendered frames through
+    rvio_hip_frame against the oracle's System::MonoVIO body — tracker tables bit-exact, counters equal, states within 1e-6"""
+    from rvio_amd import hip
+    cfg = abi.config_named(name, enable_equalizer=1)
+    seq = rv.synth.SynthSequence(cfg, duration=4.0)
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    t = s.tracker()
+    worst, updates = 0.0, 0
+    for k in range(39, 39 + 12):
+        img, imu = seq.render(k), seq.imu_between(k)
+        oi = s.frame(imu, None, img=img)[0]
+        h.frame(img, imu, None)
+        h.sync()
+        gi = h.frame_info()
+        for key in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "ransac_winner", "n_tracked_out", "n_feat_update", "n_feat_accepted", "n_rows", "updated"):
+            assert gi[key] == oi[key], (name, k, key, gi, oi)
+        pa, ha = h.get_points()
+        pb, hb = t.get_points()
+        assert np.array_equal(pa, pb) and np.array_equal(ha, hb), (name, k)
+        xa, Pa = h.get_state()
+        xb, Pb = s.get_state()
+        worst = max(worst, S.state_delta(xa, xb))
+        assert p_close_rel(Pa, Pb, 1e-6), (name, k)
+        updates += gi["updated"]
+    h.close()
+    assert updates >= 5 and worst <= 1e-6, (name, updates, worst)
+
+
+def p_close_rel(Pa, Pb, rel):
+    return float(np.max(np.abs(Pa - Pb))) <= rel * np.max(np.abs(Pb)) + 1e-15
 
 
 def test_images_1080p(gpu_required):

@@ -49,7 +49,51 @@ def test_klt_bit_exact(gpu_required, frames):
     want, st = O.klt(imgs[0], imgs[1], pts0)
     assert st.sum() > 150
     assert np.array_equal(got, want)
-    # border / textureless / far-off points exercise the early-outs
+    h.close()
+
+
+def test_klt_early_outs(gpu_required, frames):
+    """The early-outs of cv::calcOpticalFlowPyrLK (SURVEY.md appendix B.2), each with its own point and an explicit status:
+    a window that starts outside the image at the coarsest level / a start position outside the image (status 0), a textureless
+    patch (min eigenvalue below minEigThreshold: status 0), a window that leaves the image mid-iteration (status 0), and ordinary
+    blobs beside them (status 1) — positions and flags bit-exact against the oracle."""
+    from rvio_amd import hip
+    cfg, seq, ks, imgs = frames
+    H, W = cfg.height, cfg.width
+    a = np.full((H, W), 90, np.uint8)
+    b = np.full((H, W), 90, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+
+    def blob(img, cx, cy, amp=120.0, sig=2.5):
+        g = amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sig * sig))
+        np.copyto(img, np.clip(img.astype(np.float64) + g, 0, 255).astype(np.uint8))
+    centres = [(200.0, 150.0), (400.0, 300.0), (600.0, 100.0)]
+    for cx, cy in centres:
+        blob(a, cx, cy)
+        blob(b, cx + 2.3, cy - 1.6)                      # ordinary sub-pixel motion: tracked
+    blob(a, 6.0, 240.0)                                  # a blob at the left border that moves out of the image
+    blob(b, -9.0, 240.0)
+    blob(a, 300.0, 474.0)
+    blob(b, 300.0, 492.0)                                # ... and one that leaves through the bottom
+    pts = np.array(list(centres) + [(6.0, 240.0), (300.0, 474.0),
+                                    (500.0, 400.0),      # textureless patch (uniform 90)
+                                    (0.25, 0.25), (751.0, 479.0),    # corners of the image
+                                    (-30.0, 100.0), (900.0, 600.0)], np.float32)   # outside the image
+    want, st = O.klt(a, b, pts)
+    assert list(st[:3]) == [1, 1, 1]
+    assert np.all(np.abs(want[:3] - (pts[:3] + np.float32([2.3, -1.6]))) < 0.15)
+    assert st[5] == 0, "textureless patch must fail the min-eigenvalue test"
+    assert st[8] == 0 and st[9] == 0, "start positions outside the image"
+    assert st[3] == 0 or st[4] == 0, "a window that leaves the image"
+    h = hip.RvioHip(cfg)
+    imu = np.zeros(0, abi.IMU_DTYPE)
+    h.track(a, imu, pts)                                 # first image: the list is taken as it is
+    assert np.array_equal(h.get_points()[0], pts)
+    h.track(b, imu, np.zeros((0, 2), np.float32))
+    got, _ = h.debug_tracked(len(pts))
+    info = h.frame_info()
+    assert np.array_equal(got, want)
+    assert info["n_klt_ok"] == int(st.sum())
     h.close()
 
 

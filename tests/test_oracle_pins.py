@@ -353,3 +353,236 @@ def test_find_newer_uses_the_int_members_of_the_reference(case):
     assert len(want) > 40
     assert np.array_equal(pts[: len(ref)], ref)
     assert np.array_equal(pts[len(ref):], np.array(want, np.float32))
+
+
+# ---- (5) finite-difference pins of the two Jacobian builders
+def _small_quat(th):
+    q = np.zeros(4)
+    q[:3] = .5 * np.asarray(th, float)
+    q[3] = np.sqrt(1 - q[:3] @ q[:3])
+    return q
+
+
+def _boxplus(x, d):
+    """the state injection of Updater.cc:546-613 (q+ = dq (x) q, everything else additive), i.e. the error-state convention"""
+    x = np.array(x, float)
+    n = (len(x) - 26) // 7
+    x[0:4] = O.quat_mul(_small_quat(d[0:3]), x[0:4]); x[4:10] += d[3:9]
+    x[10:14] = O.quat_mul(_small_quat(d[9:12]), x[10:14]); x[14:26] += d[12:24]
+    for j in range(n):
+        x[26 + 7 * j:30 + 7 * j] = O.quat_mul(_small_quat(d[24 + 6 * j:27 + 6 * j]), x[26 + 7 * j:30 + 7 * j])
+        x[30 + 7 * j:33 + 7 * j] += d[27 + 6 * j:30 + 6 * j]
+    return x
+
+
+def _boxminus(xa, xb):
+    n = (len(xa) - 26) // 7
+    d = np.zeros(24 + 6 * n)
+
+    def dth(qa, qb):
+        qi = np.array(qb, float)
+        qi[:3] *= -1
+        return 2 * O.quat_mul(qa, qi)[:3]
+    d[0:3] = dth(xa[0:4], xb[0:4]); d[3:9] = xa[4:10] - xb[4:10]
+    d[9:12] = dth(xa[10:14], xb[10:14]); d[12:24] = xa[14:26] - xb[14:26]
+    for j in range(n):
+        d[24 + 6 * j:27 + 6 * j] = dth(xa[26 + 7 * j:30 + 7 * j], xb[26 + 7 * j:30 + 7 * j])
+        d[27 + 6 * j:30 + 6 * j] = xa[30 + 7 * j:33 + 7 * j] - xb[30 + 7 * j:33 + 7 * j]
+    return d
+
+
+def test_update_jacobians_against_central_differences():
+    """U3 (Updater.cc:271-368): Hx w.r.t. every clone's (theta, p) through the relative-pose chain and Hf w.r.t. (phi, psi, rho),
+    before the nullspace projection, against central differences of the residual itself at a fixed inverse-depth triple — for
+    type-'1' (newest clones, column offset 6(n-(L-1))) and type-'2' (oldest clones, first ceil(L/2) observations) features of several
+    lengths.  The residual passes through float32 (cv::Point2f, Updater.cc:307-308), which limits the agreement to ~3e-4."""
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=30)
+    r = recs[-1]
+    x = r["x1"]
+    n = (len(x) - 26) // 7
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq)
+    h = 1e-4
+    seen = set()
+    for f in range(len(types)):
+        key = (int(types[f]), int(lens[f]))
+        if key in seen or len(seen) >= 6:
+            continue
+        seen.add(key)
+        r0, Hx, Hf, pf = O.feature_model(cfg, x, types[f], meas[f], lens[f])
+        Lu = (lens[f] + 1) // 2 if types[f] == ord("2") else lens[f]
+        assert len(r0) == 2 * Lu
+        Hfd = np.zeros_like(Hx)
+        for k in range(6 * n):
+            d = np.zeros(24 + 6 * n)
+            d[24 + k] = h
+            rp = O.feature_model(cfg, _boxplus(x, d), types[f], meas[f], lens[f], pf)[0]
+            rm = O.feature_model(cfg, _boxplus(x, -d), types[f], meas[f], lens[f], pf)[0]
+            Hfd[:, k] = (rm - rp) / (2 * h)            # r = z - h(x): dr = -H dx
+        assert np.abs(Hx).max() > 0.5 and np.abs(Hx - Hfd).max() < 1e-3, key
+        lo = 6 * (n - (lens[f] - 1)) if types[f] == ord("1") else 0
+        assert not Hx[:, :lo].any() and not Hx[:, lo + 6 * (Lu - 1):].any()        # the column range of the feature (Updater.cc:288-293)
+        Hffd = np.zeros_like(Hf)
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = h
+            Hffd[:, k] = (O.feature_model(cfg, x, types[f], meas[f], lens[f], pf - d)[0] - O.feature_model(cfg, x, types[f], meas[f], lens[f], pf + d)[0]) / (2 * h)
+        assert np.abs(Hf - Hffd).max() < 1e-3, key
+    assert len(seen) >= 4
+
+
+def test_propagate_transition_against_central_differences():
+    """PreIntegrator::propagate (PreIntegrator.cc:97-193): with four clones and P[0:24,24:] = I the propagated cross block IS Psi =
+    prod(I + dt F); its columns against central differences of the propagated MEAN w.r.t. the initial error state.  Blocks that
+    grow linearly in time agree to 1e-3; blocks that grow quadratically (v<-bg, pk<-g, pk<-ba) carry the (m-1)/m factor of the
+    reference's first-order Phi = I + dt F and agree within 15 %.  Columns theta_k, p_k are left out: composition (System.cc:344-353)
+    resets that pose to identity with zero covariance, so the mean integration never sees a perturbed start there."""
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=8)
+    rec = [q for q in recs if (len(q["x0"]) - 26) // 7 == 4][0]
+    x0, imu = rec["x0"], rec["inp"]["imu"]
+    d = 48
+    P = np.eye(d)
+    P[:24, :24] *= 1e-6
+    P[:24, 24:] = np.eye(24)
+    P[24:, :24] = np.eye(24)
+    x1, P1 = O.propagate(cfg, x0, P, imu)
+    Psi = P1[:24, 24:]
+    h = 1e-5
+    Fd = np.zeros((24, 24))
+    for k in range(24):
+        dd = np.zeros(d)
+        dd[k] = h
+        xp, _ = O.propagate(cfg, _boxplus(x0, dd), P, imu)
+        xm, _ = O.propagate(cfg, _boxplus(x0, -dd), P, imu)
+        Fd[:, k] = (_boxminus(xp, x1) - _boxminus(xm, x1))[:24] / (2 * h)
+    blk = dict(thG=0, pG=3, g=6, thk=9, pk=12, v=15, bg=18, ba=21)
+
+    def B(M, a, b):
+        return M[blk[a]:blk[a] + 3, blk[b]:blk[b] + 3]
+    first_order = [("thG", "thG"), ("pG", "pG"), ("g", "g"), ("thk", "bg"), ("pk", "v"), ("v", "g"), ("v", "v"), ("v", "ba"), ("bg", "bg"), ("ba", "ba")]
+    for a, b in first_order:
+        m = np.abs(B(Psi, a, b)).max()
+        assert m > 1e-3 and np.abs(B(Psi, a, b) - B(Fd, a, b)).max() < 1e-3 * max(m, 1.0) + 3e-6, (a, b)
+    for a, b in [("v", "bg"), ("pk", "g"), ("pk", "ba")]:
+        m = np.abs(B(Fd, a, b)).max()
+        assert m > 1e-4 and np.abs(B(Psi, a, b) - B(Fd, a, b)).max() < 0.15 * m, (a, b)
+    # nothing else: every remaining block outside the theta_k / p_k columns is zero in both
+    for a in blk:
+        for b in blk:
+            if b in ("thk", "pk") or (a, b) in first_order or (a, b) in [("v", "bg"), ("pk", "g"), ("pk", "ba"), ("pk", "bg")]:
+                continue
+            assert np.abs(B(Psi, a, b)).max() < 1e-12 and np.abs(B(Fd, a, b)).max() < 1e-6, (a, b)
+
+
+def _lk_numpy(I_pyr, D_pyr, J_pyr, pt):
+    """cv::calcOpticalFlowPyrLK for one point, written from SURVEY.md appendix B.2 with NumPy window arithmetic (int64 sums
+    converted once to float32, as oracle/frontend.cpp states for its accumulators): returns (x, y, status)"""
+    f32 = np.float32
+    W = 15
+
+    def win(img, x0, y0, border):
+        """17x17 samples img[y0-? ..]: rows y0..y0+15, cols x0..x0+15 with the padded-image semantics"""
+        Hh, Ww = img.shape[:2]
+        ys, xs = np.arange(y0, y0 + W + 1), np.arange(x0, x0 + W + 1)
+        if border == "reflect":
+            def rf(v, nmax):
+                v = np.where(v < 0, -v, v)
+                return np.where(v >= nmax, 2 * nmax - 2 - v, v)
+            return img[np.ix_(rf(ys, Hh), rf(xs, Ww))].astype(np.int64)
+        out = np.zeros((W + 1, W + 1) + img.shape[2:], np.int64)
+        oky, okx = (ys >= 0) & (ys < Hh), (xs >= 0) & (xs < Ww)
+        sub = img[np.ix_(ys[oky], xs[okx])].astype(np.int64)
+        out[np.ix_(np.nonzero(oky)[0], np.nonzero(okx)[0])] = sub
+        return out
+
+    def weights(a, b):
+        w00 = int(np.rint(f32(f32(f32(1) - a) * f32(f32(1) - b)) * f32(1 << 14)))
+        w01 = int(np.rint(f32(a * f32(f32(1) - b)) * f32(1 << 14)))
+        w10 = int(np.rint(f32(f32(f32(1) - a) * b) * f32(1 << 14)))
+        return w00, w01, w10, (1 << 14) - w00 - w01 - w10
+
+    def interp(p, w, shift):
+        s = p[:-1, :-1] * w[0] + p[:-1, 1:] * w[1] + p[1:, :-1] * w[2] + p[1:, 1:] * w[3]
+        return (s + (1 << (shift - 1))) >> shift
+
+    st = 1
+    nx = ny = f32(0)
+    top = len(I_pyr) - 1
+    scale = f32(1.0 / (1 << 20))
+    for lv in range(top, -1, -1):
+        I, D, J = I_pyr[lv], D_pyr[lv], J_pyr[lv]
+        sc = f32(1.0 / (1 << lv))
+        ppx, ppy = f32(pt[0]) * sc, f32(pt[1]) * sc
+        if lv == top:
+            nx, ny = ppx, ppy
+        else:
+            nx, ny = f32(nx * f32(2)), f32(ny * f32(2))
+        ppx, ppy = f32(ppx - f32(7)), f32(ppy - f32(7))
+        ix, iy = int(np.floor(ppx)), int(np.floor(ppy))
+        if ix < -W or ix >= I.shape[1] or iy < -W or iy >= I.shape[0]:
+            if lv == 0:
+                st = 0
+            continue
+        w = weights(f32(ppx - f32(ix)), f32(ppy - f32(iy)))
+        Iw = interp(win(I, ix, iy, "reflect"), w, 14 - 5)
+        Dw = win(D, ix, iy, "zero")
+        Ix, Iy = interp(Dw[..., 0], w, 14), interp(Dw[..., 1], w, 14)
+        A11, A12, A22 = f32(f32(int((Ix * Ix).sum())) * scale), f32(f32(int((Ix * Iy).sum())) * scale), f32(f32(int((Iy * Iy).sum())) * scale)
+        Dd = f32(f32(A11 * A22) - f32(A12 * A12))
+        disc = f32(f32(f32(A11 - A22) * f32(A11 - A22)) + f32(f32(f32(4) * A12) * A12))
+        min_eig = f32(f32(f32(A22 + A11) - np.sqrt(disc)) / f32(2 * W * W))
+        if min_eig < f32(1e-3) or Dd < f32(1.1920929e-07):
+            if lv == 0:
+                st = 0
+            continue
+        Dd = f32(f32(1) / Dd)
+        npx, npy = f32(nx - f32(7)), f32(ny - f32(7))
+        pdx = pdy = f32(0)
+        for j in range(30):
+            jx, jy = int(np.floor(npx)), int(np.floor(npy))
+            if jx < -W or jx >= J.shape[1] or jy < -W or jy >= J.shape[0]:
+                if lv == 0:
+                    st = 0
+                break
+            w = weights(f32(npx - f32(jx)), f32(npy - f32(jy)))
+            diff = interp(win(J, jx, jy, "reflect"), w, 14 - 5) - Iw
+            b1, b2 = f32(f32(int((diff * Ix).sum())) * scale), f32(f32(int((diff * Iy).sum())) * scale)
+            dx = f32(f32(f32(A12 * b2) - f32(A22 * b1)) * Dd)
+            dy = f32(f32(f32(A12 * b1) - f32(A11 * b2)) * Dd)
+            npx, npy = f32(npx + dx), f32(npy + dy)
+            nx, ny = f32(npx + f32(7)), f32(npy + f32(7))
+            if float(dx) * float(dx) + float(dy) * float(dy) <= 1e-4:
+                break
+            if j > 0 and abs(float(f32(dx + pdx))) < 0.01 and abs(float(f32(dy + pdy))) < 0.01:
+                nx, ny = f32(nx - f32(dx * f32(0.5))), f32(ny - f32(dy * f32(0.5)))
+                break
+            pdx, pdy = dx, dy
+        if st and lv == 0:
+            rx, ry = int(np.rint(f32(nx - f32(7)))), int(np.rint(f32(ny - f32(7))))
+            if rx < -W or rx >= J.shape[1] or ry < -W or ry >= J.shape[0]:
+                st = 0
+    return float(nx), float(ny), st
+
+
+def test_klt_against_an_independent_numpy_lucas_kanade():
+    """pyramidal LK on single points, NumPy write-up of OpenCV's LKTrackerInvoker against orc_klt: to the last bit"""
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq = rv.synth.SynthSequence(cfg, duration=4.0)
+    a, b = seq.render(60), seq.render(61)
+    xy, vis = seq.project(60, noise=False)
+    pts = np.concatenate([xy[vis][:10], np.array([[3.5, 200.2], [748.9, 10.1], [300.0, 478.5]], np.float32)]).astype(np.float32)
+
+    def pyr(img):
+        lv = [img]
+        for _ in range(3):
+            lv.append(O.pyr_down(lv[-1]))
+        return lv
+    Ip, Jp = pyr(a), pyr(b)          # (pyrDown and Scharr themselves are pinned by test_pyr_down_and_scharr_against_numpy)
+    Dp = [O.scharr(l) for l in Ip]
+    want, st = O.klt(a, b, pts)
+    assert st.sum() >= 8
+    for i, p in enumerate(pts):
+        x, y, s = _lk_numpy(Ip, Dp, Jp, p)
+        assert s == st[i], i
+        assert np.float32(x) == want[i, 0] and np.float32(y) == want[i, 1], (i, x, y, want[i])
