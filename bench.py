@@ -249,6 +249,8 @@ def main():
         if not args.no_streams:
             out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
                                                wi, ai, ni, n_frames, 1 + W, streams=args.streams, threads=args.stream_threads)
+        if not args.no_latency:
+            out["update_at_load"] = update_at_load_leg(cfg, torch, name=args.config)
         if args.batch_streams:
             out["batched_streams"] = batched_streams_leg(cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
         if args.batch:
@@ -362,6 +364,63 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     ]
     h.close()
     return res
+
+
+def update_at_load_leg(cfg, torch, name="B", reps=60):
+    """The headline latency AT LOAD: Updater::update on ceil(F/2) features (SURVEY.md 8d).  The free-running synthetic scene hands the
+    update a dozen features per frame; here the window is filled by a direct-track sequence, then the update is driven with two
+    full loads generated for that very state (rvio_amd.synth.worst_case_tracks): "half" = every second feature type '2' at the
+    maximum length, the others type '1' with L ~ U[3, n+1]; "long" = every feature type '1' at L = n+1, the 2L-3 = 19-row worst
+    case W_filter = 51 MFLOP of SURVEY.md 8d is quoted on.  Timed with HIP events on the handle's stream around
+    rvio_hip_update_tracked (state re-seeded before every repetition); per-kernel times from rvio_hip_debug_time_kernel."""
+    from rvio_amd import hip
+    seq = rv.synth.SynthSequence(cfg, duration=(K0 + 40) / 20.0 + 1.0)
+    h = hip.RvioHip(cfg)
+    st = torch.cuda.ExternalStream(h.stream())
+    h.initialize(*seq.init_from_static(K0))
+    drv = rv.synth.DirectTrackDriver(seq)
+    nfill = cfg.max_track_len + 8
+    for f in range(nfill):
+        inp = drv.inputs(K0 + 1 + f)
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        drv.after(h.get_points()[0])
+    imu = seq.imu_between(K0 + 1 + nfill)
+    h.propagate(imu)
+    x1, P1 = h.get_state()
+    n = (len(x1) - 26) // 7
+    c6 = 6 * n
+    PEAK_F64 = 78.6
+    res = {}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for mix in ("half", "long"):
+        types, lens, meas = rv.synth.worst_case_tracks(cfg, x1, mix=mix)
+        h.set_state(x1, P1)
+        h.update(types, lens, meas)                     # uploads the hand-over tables (they stay on the device) + warm-up
+        info = h.frame_info()
+        ts = []
+        for _ in range(reps):
+            h.set_state(x1, P1)
+            with torch.cuda.stream(st):
+                ev0.record()
+            h.update_tracked()
+            with torch.cuda.stream(st):
+                ev1.record()
+            h.sync()
+            ts.append(ev0.elapsed_time(ev1))
+        h.set_state(x1, P1)
+        h.update_tracked()
+        h.sync()
+        kern = {k: h.time_kernel(w, 20) for k, w in (("feat_build", 2), ("gram_reduce", 3), ("solve", 0), ("ug", 4), ("final", 5))}
+        w_alg = filter_flops(cfg, n, lens, types, 0)    # W_filter of SURVEY.md 8d for exactly these tracks (update only: m = 0)
+        p50 = float(np.median(ts))
+        res[mix] = {"n_feat": int(len(types)), "n_feat_accepted": int(info["n_feat_accepted"]), "n_rows": int(info["n_rows"]),
+                    "p50_update_ms": p50, "p95_update_ms": float(np.percentile(ts, 95)), "kernel_us": kern,
+                    "w_filter_mflop": w_alg / 1e6,
+                    "roofline": {"bound": "mfma", "achieved": w_alg / (p50 * 1e-3) / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
+                                 "frac": w_alg / (p50 * 1e-3) / 1e12 / PEAK_F64,
+                                 "note": "the reference's FP64 work for these tracks (gate, Givens nullspace + compression, EKF) over the p50 update time of ONE stream"}}
+    h.close()
+    return {"workload": "cfg%s, window full (%d clones, 6n = %d), one stream: rvio_hip_update_tracked on full loads" % (name, n, c6), **res}
 
 
 def multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, wi, ai, ni, n_frames, n_warm, streams=8, threads=1):

@@ -1286,11 +1286,19 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status, (size_t)0);
-        } else {
+        } else if (which == 2) {
             hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta);
-        }
+        } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
+                               h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, h->slab_bytes, h->bin);
+        } else if (which == 4) {   // U, G, P1 strips on the operands of the last update (outputs to scratch)
+            hipLaunchKernelGGL(ug_kernel, dim3((24 + 6 * n + 15) / 16, 1, h->batch), dim3(256), h->ug_lds, h->stream, d, n, h->P[h->cur], h->W, h->block, h->U, h->G, h->Pt1, h->slab_bytes);
+        } else if (which == 5) {   // Joseph form, written to the spare covariance buffer (overwritten by the next stage anyway)
+            const int nt = (24 + 6 * n + 15) / 16, npair = nt * (nt + 1) / 2;
+            hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, h->batch), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, h->P[h->cur ^ 1], h->slab_bytes);
+        } else return RVIO_ERR_INVALID;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));

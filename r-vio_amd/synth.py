@@ -236,3 +236,68 @@ class DirectTrackDriver:
     def after(self, points_xy):
         """Call with the tracker's mvFeatsToTrack after the frame."""
         self.ids = np.array([self._lookup[key] for key in self._keys(np.asarray(points_xy, np.float32))], dtype=np.int64)
+
+
+# ---------------------------------------------------------------- full update loads (no images, no tracker)
+def _q2r_jpl(q):
+    """QuatToRot of util/Numerics.h:111-120 (JPL): I - 2 w [q]x + 2 [q]x^2"""
+    qx = _skew(q[:3])
+    return np.eye(3) - 2 * q[3] * qx + 2 * qx @ qx
+
+
+def _qmul_jpl(a, b):
+    """QuatMul of util/Numerics.h:30-63 (JPL, normalised, w >= 0)"""
+    q = np.array([a[3] * b[0] + a[2] * b[1] - a[1] * b[2] + a[0] * b[3],
+                  -a[2] * b[0] + a[3] * b[1] + a[0] * b[2] + a[1] * b[3],
+                  a[1] * b[0] - a[0] * b[1] + a[3] * b[2] + a[2] * b[3],
+                  -a[0] * b[0] - a[1] * b[1] - a[2] * b[2] + a[3] * b[3]])
+    q /= np.linalg.norm(q)
+    return q if q[3] >= 0 else -q
+
+
+def worst_case_tracks(cfg, x, n_feat=None, seed=0, mix="half"):
+    """A full update load for the state vector x (window of n clones): ceil(F/2) features that are geometrically consistent with
+    the clone poses of x — each a random 3-D point in front of its first camera, projected through the state's own relative-pose
+    chain (Updater.cc:125-141) plus sigma_im noise, so that the chi-square gate accepts most of them.
+    mix = "half": every second feature is type '2' at the maximum track length, the others type '1' with L ~ U[3, n+1] (the
+    direct-track load of SURVEY.md 8d);  mix = "long": every feature is type '1' with L = n+1, i.e. 2L-3 stacked rows each —
+    the worst case W_filter of SURVEY.md 8d is quoted on (cfg B: 100 x 19 = 1900 rows, 51 MFLOP)."""
+    rng = np.random.default_rng(1234 + seed)
+    n = (len(x) - 26) // 7
+    Fu = abi.fu(cfg) if n_feat is None else n_feat
+    ML = cfg.max_track_len
+    T = np.array(list(cfg.T_bc)).reshape(4, 4)
+    Ric, tic = T[:3, :3], T[:3, 3]
+    Rci, tci = Ric.T, -Ric.T @ tic
+    sig = float(max(cfg.sigma_px, cfg.sigma_py))
+    types = np.zeros(Fu, np.uint8)
+    lens = np.zeros(Fu, np.int32)
+    meas = np.zeros((Fu, ML, 2), np.float32)
+    for f in range(Fu):
+        if mix == "long":
+            ty, L = ord("1"), n + 1
+        elif f % 2 == 0 and n + 1 == ML:
+            ty, L = ord("2"), ML
+        else:
+            ty, L = ord("1"), int(rng.integers(3, n + 2))
+        nph = L - 1
+        rel = x[26 + 7 * n - 7 * nph:] if ty == ord("1") else x[26:26 + 7 * nph]
+        qI = [rel[0:4]]
+        tI = [-_q2r_jpl(rel[0:4]) @ rel[4:7]]
+        for i in range(1, nph):
+            qi = rel[7 * i:7 * i + 4]
+            tI.append(_q2r_jpl(qi) @ (tI[-1] - rel[7 * i + 4:7 * i + 7]))
+            qI.append(_qmul_jpl(qi, qI[-1]))
+        depth = rng.uniform(2.0, 8.0)
+        pc1 = np.array([rng.uniform(-0.5, 0.5) * depth, rng.uniform(-0.35, 0.35) * depth, depth])
+        obs = [pc1[:2] / pc1[2]]
+        for i in range(nph):
+            RI = _q2r_jpl(qI[i])
+            Rc = Rci @ RI @ Ric
+            tc = Rci @ RI @ tic + Rci @ tI[i] + tci
+            pc = Rc @ pc1 + tc
+            obs.append(pc[:2] / pc[2])
+        obs = np.array(obs) + sig * rng.standard_normal((L, 2))
+        types[f], lens[f] = ty, L
+        meas[f, :L] = obs.astype(np.float32)
+    return types, lens, meas

@@ -64,48 +64,7 @@ def state_delta(xa, xb):
     return float(np.max(np.abs(qfix(xa) - qfix(xb))))
 
 
-def worst_case_tracks(cfg, rec, seq, n_feat=None, seed=0):
-    """Synthesise a full update load (ceil(F/2) features: half type '2' at max length, half type '1'
-    with L ~ U[3, n+1]) that is geometrically consistent with the clone poses of `rec`'s state, by
-    triangulating nothing: each feature is a random 3-D point projected through the state's own
-    relative-pose chain plus sigma_im noise (so the chi-square gate accepts most of them)."""
-    rng = np.random.default_rng(1234 + seed)
-    x = rec["x1"]
-    n = (len(x) - 26) // 7
-    Fu = abi.fu(cfg) if n_feat is None else n_feat
-    ML = cfg.max_track_len
-    T = np.array(list(cfg.T_bc)).reshape(4, 4)
-    Ric, tic = T[:3, :3], T[:3, 3]
-    Rci, tci = Ric.T, -Ric.T @ tic
-    sig = float(max(cfg.sigma_px, cfg.sigma_py))
-    types = np.zeros(Fu, np.uint8)
-    lens = np.zeros(Fu, np.int32)
-    meas = np.zeros((Fu, ML, 2), np.float32)
-    for f in range(Fu):
-        if f % 2 == 0 and n + 1 == ML:
-            ty, L = ord("2"), ML
-        else:
-            ty, L = ord("1"), int(rng.integers(3, n + 2))
-        nph = L - 1
-        rel = x[26 + 7 * n - 7 * nph:] if ty == ord("1") else x[26:26 + 7 * nph]
-        # camera poses w.r.t. the first camera frame (Updater.cc:125-141)
-        qI = [rel[0:4]]
-        tI = [-O.quat_to_rot(rel[0:4]) @ rel[4:7]]
-        for i in range(1, nph):
-            qi = rel[7 * i:7 * i + 4]
-            tI.append(O.quat_to_rot(qi) @ (tI[-1] - rel[7 * i + 4:7 * i + 7]))
-            qI.append(O.quat_mul(qi, qI[-1]))
-        # a point in front of the first camera
-        depth = rng.uniform(2.0, 8.0)
-        pc1 = np.array([rng.uniform(-0.5, 0.5) * depth, rng.uniform(-0.35, 0.35) * depth, depth])
-        obs = [pc1[:2] / pc1[2]]
-        for i in range(nph):
-            RI = O.quat_to_rot(qI[i])
-            Rc = Rci @ RI @ Ric
-            tc = Rci @ RI @ tic + Rci @ tI[i] + tci
-            pc = Rc @ pc1 + tc
-            obs.append(pc[:2] / pc[2])
-        obs = np.array(obs) + sig * rng.standard_normal((L, 2))
-        types[f], lens[f] = ty, L
-        meas[f, :L] = obs.astype(np.float32)
-    return types, lens, meas
+def worst_case_tracks(cfg, rec, seq, n_feat=None, seed=0, mix="half"):
+    """a full update load (ceil(F/2) features) that is geometrically consistent with the clone poses of `rec`'s propagated state:
+    rv.synth.worst_case_tracks (the same generator bench.py's update-at-load leg uses)"""
+    return rv.synth.worst_case_tracks(cfg, rec["x1"], n_feat=n_feat, seed=seed, mix=mix)
