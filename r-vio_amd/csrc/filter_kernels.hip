@@ -14,6 +14,7 @@
 // global reads in one batch (a dependent global load after a kernel boundary costs 1-2 us),
 // n_clones is a kernel argument (data-independent, mirrored on the host), wave reductions use
 // DPP, serial chains are hoisted out of barrier-separated loops.
+#include <type_traits>
 #include "rvio_dev.h"
 #include "../../include/rvio_hip.h"
 
@@ -36,6 +37,8 @@ __host__ __device__ inline size_t feat_lds_doubles(int max_len, int ldh, bool tm
     return n;
 }
 
+// HOIST: k-values whose operand loads are in flight before the first MFMA of a gate tile (16: one stream, latency; 4: batch handles, 128 VGPRs)
+template <int HOIST>
 __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double* x, const double* P,
                                                 const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                 int shard_rank, int shard_world,
@@ -367,16 +370,17 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
             const double* ap = Hn + (size_t)ai * ldh + cLo;
             const double* bp = P + (size_t)(24 + cLo + bj) + (size_t)(24 + cLo) * ld;
             d4 acc = {0, 0, 0, 0};
-            for (int k0 = 0; k0 < wa; k0 += 16) {
-                double a[4], b[4];
+            // a dependent global load per k-step costs ~1.5 us here: all loads of 64 k-values go out before the first MFMA
+            for (int k0 = 0; k0 < wa; k0 += 4 * HOIST) {
+                double a[HOIST], b[HOIST];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < HOIST; ++u) {
                     const int k = k0 + 4 * u + lk;
                     a[u] = (aok && k < wa) ? ap[k] : 0.0;
                     b[u] = (bok && k < wa) ? bp[(size_t)k * ld] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+                for (int u = 0; u < HOIST; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -460,11 +464,17 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         // this feature's share of the information block, G_f = Hn^T [Hn | r] (rows 0..c6-1, columns 0..c6), on the FP64 matrix cores
         // straight from the LDS copy of Hn:  A[i = p][k = row] = Hn[row][p0 + i],  B[k = row][j = q] = Hn[row][q0 + j]; rows >= rr are zero.
         // gram_reduce_kernel adds the accepted features' shares in feature order (Updater.cc:469-536 in information form).
+        // Only tiles (pt, qt) with qt >= pt whose columns meet the feature's range [cLo, cHi) — plus, in the tile row of such a pt, the
+        // tile that holds the residual column c6 — are computed and stored (tile-granular: gram_reduce_kernel applies the same rule
+        // and mirrors the lower triangle once at the end).
         double* out = Gshare + (size_t)f * ldh * ldh;
         const int gw = tid >> 6, gl = tid & 63, gi = gl & 15, gk = gl >> 4, nw = T >> 6;
-        const int nqt = (c6 + 1 + 15) / 16, ntile = ((c6 + 15) / 16) * nqt;
-        for (int tile = gw; tile < ntile; tile += nw) {
-            const int p0 = (tile / nqt) * 16, q0 = (tile % nqt) * 16;
+        const int t0 = cLo >> 4, t1 = (cHi - 1) >> 4, tr = c6 >> 4;      // first / last tile of the range, tile of the residual column
+        const int nts = t1 - t0 + 1, nq = nts + ((tr > t1) ? 1 : 0);
+        for (int tile = gw; tile < nts * nq; tile += nw) {
+            const int pt = t0 + tile / nq, qi = tile % nq, qt = (qi < nts) ? t0 + qi : tr;
+            if (qt < pt) continue;
+            const int p0 = pt * 16, q0 = qt * 16;
             const bool pok = p0 + gi < c6, qok = q0 + gi <= c6;
             d4 acc = {0, 0, 0, 0};
             for (int k0 = 0; k0 < rr; k0 += 4) {
@@ -486,13 +496,14 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     DBG_T(40);
 }
 
-__global__ void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
+template <int HOIST>
+__global__ __launch_bounds__(HOIST > 4 ? 256 : 1024) void feat_build_kernel(DevCfg cfg, int n, const double* x, const double* P,
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
                                   double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
-    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
-                    tm_global, bs, bin, meta);
+    feat_build_body<HOIST>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
+                           tm_global, bs, bin, meta);
 }
 
 // =============================================================== U7 compression, information form (reduction stage)
@@ -544,7 +555,7 @@ __device__ void trunc_finish(const DevCfg& cfg, int n, double* A, const double* 
         // cancelled to rounding level is skipped (the sweep's mixture row leaves the span of the later columns alone)
         const int m = e2 + 1, ldm = m | 1;
         double* M = Msh; double* d0 = Msh + (size_t)trunc_mmax(cfg.max_len) * (trunc_mmax(cfg.max_len) | 1);
-        for (int e = tid; e < m * m; e += 256) { const int i = e / m, j = e - i * m; if (j <= i) M[i * ldm + j] = ld_l2(A + (size_t)i * ldh + j); }
+        for (int e = tid; e < m * m; e += 256) { const int i = e / m, j = e - i * m; if (j <= i) M[i * ldm + j] = ld_l2(A + (size_t)j * ldh + i); }
         __syncthreads();
         for (int i = tid; i < m; i += 256) d0[i] = M[i * ldm + i];
         __syncthreads();
@@ -561,8 +572,15 @@ __device__ void trunc_finish(const DevCfg& cfg, int n, double* A, const double* 
         }
         truncate = !(M[e2 * ldm + e2] >= 1e-8);
     }
+    // (only the tiles on and above the diagonal are filled in: the elimination above reads S2[i][j], j <= i, as S2[j][i])
     if (!truncate)
-        for (int e = tid; e < c6 * ldh; e += 256) { if (e % ldh <= c6) A[e] = ld_l2(A + e) + ld_l2(S1 + e); }
+        for (int e = tid; e < c6 * ldh; e += 256) { const int q = e % ldh; if (q <= c6 && (q >> 4) >= ((e / ldh) >> 4)) A[e] = ld_l2(A + e) + ld_l2(S1 + e); }
+    __threadfence();
+    __syncthreads();
+    for (int e = tid; e < c6 * ldh; e += 256) {          // A is symmetric: the lower tiles are the mirror image
+        const int q = e % ldh, pr = e / ldh;
+        if (q < c6 && (q >> 4) < (pr >> 4)) A[e] = ld_l2(A + (size_t)q * ldh + pr);
+    }
     if (tid == 0) {
         double* mr = A + (size_t)ldh * (ldh - 1);
         mr[0] = (double)good; mr[1] = (double)rows; mr[2] = truncate ? (double)e2 : -1.0;
@@ -581,8 +599,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z);
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
-    // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2'
+    DBG_T(41);
+    // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2', bits 16..19 / 20..23 the
+    // first / last 16-column tile of the feature's range (feat_build_kernel stores a share's tiles inside that range only)
     __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
+    __shared__ int s_off[GRAM_MAX_FEATS];             // f * ldh^2: where the share of list entry t starts (doubles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -594,7 +615,14 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
-        if (flag) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = f | ((types[f] == '2') ? (1 << 30) : 0);
+        if (flag) {
+            const int L = lens[f];
+            const bool t2 = types[f] == '2';
+            const int Lu = t2 ? (L + 1) / 2 : L, lo = t2 ? 0 : 6 * (n - (Lu - 1)), hi = lo + 6 * (Lu - 1);
+            const int slot = off + __popcll(mask & ((1ull << lane) - 1ull));
+            s_list[slot] = f | (t2 ? (1 << 30) : 0) | ((lo >> 4) << 16) | (((hi - 1) >> 4) << 20);
+            s_off[slot] = f * ldh * ldh;
+        }
         __syncthreads();
         if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
         __syncthreads();
@@ -602,49 +630,93 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     const int ng = s_base;
     const size_t gs = (size_t)ldh * ldh;
     double* S2 = block; double* S1 = block + gs;
-    for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
-        const int q = e % ldh;
-        double a2 = 0, a1 = 0;
-        if (q <= c6) {
-            // eight loads in flight, then the additions in list order (the order fixes the result)
-            int t = 0;
-            for (; t + 8 <= ng; t += 8) {
-                double v[8]; bool is2[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int fl = s_list[t + u]; is2[u] = (fl >> 30) & 1; v[u] = partial[(size_t)(fl & 0xffff) * gs + e]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { if (is2[u]) a2 += v[u]; else a1 += v[u]; }
+    DBG_T(42);
+    // counters of this shard (wave 0 of every workgroup: Fu small integers): accepted features, their rows, the rows / last column of
+    // type '2', the first column of type '1'
+    if (tid < 64) {
+        int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
+        for (int f = tid; f < Fu; f += 64) {
+            const int r = nrows[f];
+            if (r > 0) {
+                good++; rows += r;
+                const int L = lens[f];
+                if (types[f] == '2') { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
+                else smin = min(smin, 6 * (n - (L - 1)));
             }
-            for (; t < ng; ++t) { const int fl = s_list[t]; const double v = partial[(size_t)(fl & 0xffff) * gs + e]; if ((fl >> 30) & 1) a2 += v; else a1 += v; }
         }
-        S2[e] = a2; S1[e] = a1;
+        good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
+        for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
+        if (tid == 0) { s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin; }
     }
-    const bool fin = combine && last_block_done(cnt, gridDim.x);
-    if ((combine ? fin : bi.x == 0)) {
-        // counters of this shard (wave 0): accepted features, their rows, the rows / last column of type '2', the first column of type '1'
-        if (tid < 64) {
-            int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
-            for (int f = tid; f < Fu; f += 64) {
-                const int r = nrows[f];
-                if (r > 0) {
-                    good++; rows += r;
-                    const int L = lens[f];
-                    if (types[f] == '2') { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
-                    else smin = min(smin, 6 * (n - (L - 1)));
+    __syncthreads();
+    // can the reference's rank scan cut the type-'1' rows off at all (structural precondition of trunc_finish)?  Almost never: then
+    // [A|b] = S2 + S1 is written directly, mirror image included, and nobody has to wait for the last workgroup
+    const bool cand = s_cnt[0] > 2 && s_cnt[1] > c6 && s_cnt[3] >= 0 && s_cnt[3] < c6 && s_cnt[4] < TR_NONE && s_cnt[4] > s_cnt[3] && s_cnt[2] >= s_cnt[3] + 1;
+    const bool direct = combine && !cand;
+    const bool split = !direct;                          // S2 and S1 are needed apart (a shard of the sharded updater, or a candidate)
+    DBG_T(43);
+    const int trq = c6 >> 4;                             // tile of the residual column
+    // The shares were written by ~100 other CUs: every load here is a remote (fabric) round trip, and what one CU can keep in flight
+    // bounds its rate.  So the reduction is spread wide: a workgroup covers only 64 consecutive elements, its four waves split the
+    // feature list into four contiguous chunks, and the chunk sums are added in chunk order (deterministic).
+    __shared__ double s_part[4][64][2];
+    for (int e0 = bi.x * 64; e0 < total; e0 += gridDim.x * 64) {
+        const int e = e0 + lane;
+        const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
+        const bool live = e < total && q <= c6 && qt >= pt;       // padding / lower tiles: the mirror image of the upper ones
+        double a2 = 0, a1 = 0;
+        if (live) {
+            // a share contributes where feat_build_kernel stored it — elsewhere its buffer holds stale numbers, which are loaded (no
+            // branch) and discarded.  16 loads in flight per round.
+            const double* pe = partial + e;
+            const int tb = (ng * wave) / 4, te = (ng * (wave + 1)) / 4;
+            int t = tb;
+            for (; t + 16 <= te; t += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = pe[s_off[t + u]];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int fl = s_list[t + u];
+                    const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
+                    const bool in = (unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq);
+                    const double w = in ? v[u] : 0.0;
+                    if (!split) a2 += w;
+                    else { const bool is2 = (fl >> 30) & 1; a2 += is2 ? w : 0.0; a1 += is2 ? 0.0 : w; }
                 }
             }
-            good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
-            for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
-            if (tid == 0) {
-                s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin;
-                if (!combine) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = good; mr[1] = rows; mr[2] = rows2; mr[3] = e2; mr[4] = smin; }
+            for (; t < te; ++t) {
+                const int fl = s_list[t];
+                const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
+                if ((unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq)) {
+                    const double v = pe[s_off[t]];
+                    if (!split || ((fl >> 30) & 1)) a2 += v; else a1 += v;
+                }
             }
         }
-        if (combine) {
-            __syncthreads();
-            trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
+        s_part[wave][lane][0] = a2; s_part[wave][lane][1] = a1;
+        __syncthreads();
+        if (wave == 0 && live) {
+            a2 = ((s_part[0][lane][0] + s_part[1][lane][0]) + s_part[2][lane][0]) + s_part[3][lane][0];
+            a1 = ((s_part[0][lane][1] + s_part[1][lane][1]) + s_part[2][lane][1]) + s_part[3][lane][1];
+            if (direct) {
+                const double v = a2 + a1;
+                S2[e] = v;
+                if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
+            } else { S2[e] = a2; S1[e] = a1; }
         }
+        __syncthreads();
     }
+    DBG_T(44);
+    if (direct) {
+        if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; }
+        return;
+    }
+    if (!combine) {
+        if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = s_cnt[2]; mr[3] = s_cnt[3]; mr[4] = s_cnt[4]; }
+        return;
+    }
+    if (last_block_done(cnt, gridDim.x)) trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
 }
 
 // Gathered shards (rank-major, `block_stride` doubles apart) -> Ab = [A|b] + {n_good, n_rows, truncation column}: both parts are summed
@@ -655,6 +727,8 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
     const int total = c6 * ldh;
     const size_t gs = (size_t)ldh * ldh;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int q = e % ldh;
+        if (q > c6 || (q >> 4) < ((e / ldh) >> 4)) continue;     // the shards carry the tiles on and above the diagonal
         double a2 = 0, a1 = 0;
         for (int w = 0; w < world; ++w) { a2 += blocks[(size_t)w * block_stride + e]; a1 += blocks[(size_t)w * block_stride + gs + e]; }
         Ab[e] = a2; Ab[gs + e] = a1;

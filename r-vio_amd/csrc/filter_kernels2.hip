@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
                                                         FilterMeta* meta, const rvio_imu* imu, int m) {
     if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
-    feat_build_body(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta);
+    feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition

@@ -17,6 +17,7 @@
 #include "filter_kernels2.hip"
 #include "solve4.hip"
 #include "solve6.hip"
+#include "solve7.hip"
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #include "klt3.hip"
@@ -52,6 +53,7 @@ struct rvio_hip {
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
+    int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
@@ -372,7 +374,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipMemcpy2DAsync(t.first, h->slab_bytes, ones.data(), sizeof(int), sizeof(int), (size_t)batch, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
@@ -391,6 +394,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 12; }
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
             if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
+            h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
+            if (getenv("RVIO_SOLVE6") || getenv("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
+            if (h->solve7_variant == 1)
+            {
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+            }
             if (h->solve5_variant) {
                 h->solve5_lds = (size_t)(nw * rpw) * (64 * nch + 1) * sizeof(double);
                 const int lds = (int)std::max(h->solve5_lds, (size_t)1024);
@@ -403,7 +414,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
     }
-    if (batch > 1 && !h->solve5_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
+    if (batch > 1 && !h->solve5_variant && !h->solve7_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
@@ -593,11 +604,16 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
                            h->meta, h->fuse_imu, h->fuse_m);
         h->fuse_m = -1;
     } else
-    hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+    if (B == 1)   // one stream: the latency form (every operand load of a gate tile in flight at once)
+    hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                       h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
+                       h->tm_global, bs, h->bin, h->meta);
+    else
+    hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global, bs, h->bin, h->meta);
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + 63) / 64)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
                        h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, bs, h->bin);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -606,6 +622,21 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
 static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
+    const dim3 gb(1, 1, h->batch);
+    switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
+    case 1: {
+        static const int nw = getenv("RVIO_S7_NW") ? atoi(getenv("RVIO_S7_NW")) : 4;
+        const size_t lds = (size_t)(3 * 64 * 65 + 24 * 64) * sizeof(double);
+        if (nw == 8) hipLaunchKernelGGL((solve7_kernel<1, 8, 8>), gb, dim3(512), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        else if (nw == 16) hipLaunchKernelGGL((solve7_kernel<1, 4, 16>), gb, dim3(1024), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        else hipLaunchKernelGGL((solve7_kernel<1, 16, 4>), gb, dim3(256), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        return;
+    }
+    case 2: hipLaunchKernelGGL((solve7_kernel<2, 12, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+    case 3: hipLaunchKernelGGL((solve7_kernel<2, 16, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+    case 4: hipLaunchKernelGGL((solve7_kernel<3, 16, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+    default: break;
+    }
     if (h->solve5_variant == 1)
         hipLaunchKernelGGL((solve6_kernel<1, 8, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 2)
@@ -639,7 +670,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
-    hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
+    if (!h->solve7_variant) hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     launch_solve(h, n, Ab);
     // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
     hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
@@ -1287,11 +1318,16 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status, (size_t)0);
         } else if (which == 2) {
-            hipLaunchKernelGGL(feat_build_kernel, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+            if (h->batch == 1)
+            hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
+                               h->slab_bytes, h->bin, h->meta);
+            else
+            hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
-            hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(64, (6 * n * d.ldh + 255) / 256)), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + 63) / 64)), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
                                h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, h->slab_bytes, h->bin);
         } else if (which == 4) {   // U, G, P1 strips on the operands of the last update (outputs to scratch)
             hipLaunchKernelGGL(ug_kernel, dim3((24 + 6 * n + 15) / 16, 1, h->batch), dim3(256), h->ug_lds, h->stream, d, n, h->P[h->cur], h->W, h->block, h->U, h->G, h->Pt1, h->slab_bytes);

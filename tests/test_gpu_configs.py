@@ -97,7 +97,7 @@ def test_free_running_sequence(case):
 
 @pytest.mark.parametrize("name", ["A", "C", "D"])
 def test_whole_frame_on_images(gpu_required, name):
-    """the stock path (CLAHE + device detector + KLT + RANSAC + filter) on the other configurations: 12 rendered frames through
+    """the stock path (CLAHE + device detector + KLT + RANSAC + filter) on the other configurations: max_track_len + 6 rendered frames through
     rvio_hip_frame against the oracle's System::MonoVIO body — tracker tables bit-exact, counters equal, states within 1e-6"""
     from rvio_amd import hip
     cfg = abi.config_named(name, enable_equalizer=1)
@@ -110,7 +110,7 @@ def test_whole_frame_on_images(gpu_required, name):
     s.set_state(x0, P0)
     t = s.tracker()
     worst, updates = 0.0, 0
-    for k in range(39, 39 + 12):
+    for k in range(39, 39 + cfg.max_track_len + 6):
         img, imu = seq.render(k), seq.imu_between(k)
         oi = s.frame(imu, None, img=img)[0]
         h.frame(img, imu, None)
@@ -127,7 +127,7 @@ def test_whole_frame_on_images(gpu_required, name):
         assert p_close_rel(Pa, Pb, 1e-6), (name, k)
         updates += gi["updated"]
     h.close()
-    assert updates >= 5 and worst <= 1e-6, (name, updates, worst)
+    assert updates >= 3 and worst <= 1e-6, (name, updates, worst)
 
 
 def p_close_rel(Pa, Pb, rel):

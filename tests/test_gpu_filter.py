@@ -157,8 +157,12 @@ def test_sharded_updater_fake_shards_on_one_gpu(hipB, recB, world):
     ldh = 6 * (cfg.max_track_len - 1) + 1
     part = ldh * (ldh - 1)
     assert nb == 2 * ldh * ldh and len(ob) == 2 * part + 8
+    # (the device carries the 16-column tiles on and above the diagonal only: A is symmetric, the lower tiles are mirrored after the sum)
+    pp, qq = np.divmod(np.arange(part), ldh)
+    upper = (qq >> 4) >= (pp >> 4)
     for pt in range(2):
-        assert np.allclose(gb[pt * ldh * ldh: pt * ldh * ldh + part], ob[pt * part: (pt + 1) * part], rtol=1e-9, atol=1e-9 * np.max(np.abs(ob[: 2 * part])))
+        a, b = gb[pt * ldh * ldh: pt * ldh * ldh + part][upper], ob[pt * part: (pt + 1) * part][upper]
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.max(np.abs(ob[: 2 * part])))
     assert np.array_equal(gb[part: part + 5], ob[2 * part: 2 * part + 5])
     hipB.update_global(allb.data_ptr(), world)
     x, P = hipB.get_state()
