@@ -34,6 +34,8 @@ struct TrackerDev {
     int* len;               // [Fu]
     float* meas;            // [Fu][max_len][2]
     rvio_frame_info* info;
+    int* first_host;        // host-mapped mirror of `first`, one int per instance (NOT a slab member: indexed by blockIdx.z); the host only
+                            // reads it to drop a cross-stream wait once the first image is behind every instance
 };
 
 // Batched launches (gridDim.z = instances, rvio_dev.h): every member of these views lies in the instance's slab

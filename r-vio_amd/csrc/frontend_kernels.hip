@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
         }
         if (tid == 0) {
             *t.n_pts = n0; *t.n_feat = 0;
-            if (n0 > 0) *t.first = 0;
+            if (n0 > 0) { *t.first = 0; if (t.first_host) t.first_host[blockIdx.z] = 0; }
             t.info->n_tracked_in = 0; t.info->n_klt_ok = 0; t.info->n_ransac_inliers = 0; t.info->ransac_winner = 0;
             t.info->n_tracked_out = n0; t.info->n_feat_update = 0;
         }

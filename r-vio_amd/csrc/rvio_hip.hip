@@ -110,6 +110,8 @@ struct rvio_hip {
     size_t img_bs = 0, imu_bs = 0;   // instance strides (bytes) of the image / IMU batch of the call in progress
     BatchIn bin = {0, 0, 0, 0, 0};   // strides of the hand-over read by feat_build (slab_bytes for the handle's own buffers)
     int* rng = nullptr;
+    int* first_mirror = nullptr;     // pinned, device-mapped: mbIsTheFirstImage of every instance as book-keeping leaves it
+    bool first_cleared = false;      // (cached) every instance has seen its first image: nms(k+1) need not wait for book-keeping(k)
     int* cand_scratch = nullptr;
     rvio_frame_info* d_info = nullptr;
     double* d_pose = nullptr;
@@ -368,6 +370,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->bin = {0, h->slab_bytes, h->slab_bytes, h->slab_bytes, h->slab_bytes};
     TrackerDev& t = h->t;
     t.info = h->d_info;
+    t.first_host = nullptr;
+    if (front_end) {
+        HIPCHK(h, hipHostMalloc((void**)&h->first_mirror, sizeof(int) * (size_t)batch, hipHostMallocMapped));
+        for (int i = 0; i < batch; ++i) h->first_mirror[i] = 1;
+        void* dp_ = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp_, h->first_mirror, 0));
+        t.first_host = (int*)dp_;
+    }
     h->tout[0] = {t.n_feat, t.types, t.len, t.meas};   // Tracker -> Updater hand-over, double-buffered for the pipelined path
     if (front_end) {   // mbIsTheFirstImage = true in every instance
         std::vector<int> ones((size_t)batch, 1);
@@ -436,6 +446,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) hipFree(p);
     for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); }
+    if (h->first_mirror) hipHostFree(h->first_mirror);
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
@@ -554,6 +565,8 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->frame_no = 0; h->piped = false; h->in_frame = false; h->fuse_m = -1;
+        for (int i = 0; i < h->batch; ++i) h->first_mirror[i] = 1;
+        h->first_cleared = false;
     }
     return rvio_hip_set_state(h, x, 26, P, 24);
 }
@@ -874,7 +887,14 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         }
         h->side = h->stream_d;
         // run-ahead: book-keeping(k-1) ran on the side stream; its hand-over event also says that mbIsTheFirstImage is final
-        const hipEvent_t flag = (h->runahead && h->frame_no >= 1) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
+        // ... until the flag has gone to 0 in every instance (it never comes back: Tracker.cc:233): the host sees that in the mirror
+        // book-keeping writes (a stale 1 only keeps the wait one frame longer) and the detector chain then paces itself
+        if (!h->first_cleared) {
+            bool all0 = true;
+            for (int i = 0; i < h->batch && all0; ++i) all0 = ((volatile int*)h->first_mirror)[i] == 0;
+            h->first_cleared = all0;
+        }
+        const hipEvent_t flag = (h->runahead && h->frame_no >= 1 && !h->first_cleared) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
         const int rc = detect_dev(h, d_img, stride, src_bs, flag);
         if (rc != RVIO_OK) return rc;
         if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, h->ts));   // corners of frame k ready (book-keeping on the side stream waits for it)
