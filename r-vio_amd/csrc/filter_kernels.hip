@@ -592,7 +592,7 @@ __device__ void trunc_finish(const DevCfg& cfg, int n, double* A, const double* 
 // workgroup that finishes last turns part 0 into [A|b] in place (trunc_finish), so no further launch is needed.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, const int* nrows,
                                                           const unsigned char* types, const int* lens, double* block, int* cnt, int combine,
-                                                          size_t bs, BatchIn bin) {
+                                                          int wide, size_t bs, BatchIn bin) {
     extern __shared__ __align__(16) double g_dyn[];
     const BatchIdx bi = batch_plain();
     partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z); cnt = zoffi(cnt, bs, bi.z);
@@ -660,52 +660,69 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     // bounds its rate.  So the reduction is spread wide: a workgroup covers only 64 consecutive elements, its four waves split the
     // feature list into four contiguous chunks, and the chunk sums are added in chunk order (deterministic).
     __shared__ double s_part[4][64][2];
-    for (int e0 = bi.x * 64; e0 < total; e0 += gridDim.x * 64) {
-        const int e = e0 + lane;
-        const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
-        const bool live = e < total && q <= c6 && qt >= pt;       // padding / lower tiles: the mirror image of the upper ones
-        double a2 = 0, a1 = 0;
-        if (live) {
-            // a share contributes where feat_build_kernel stored it — elsewhere its buffer holds stale numbers, which are loaded (no
-            // branch) and discarded.  16 loads in flight per round.
-            const double* pe = partial + e;
-            const int tb = (ng * wave) / 4, te = (ng * (wave + 1)) / 4;
-            int t = tb;
-            for (; t + 16 <= te; t += 16) {
-                double v[16];
+    // sum of the shares t in [tb, te) at element e (p-tile pt, q-tile qt): a share contributes where feat_build_kernel stored it —
+    // elsewhere its buffer holds stale numbers, which are loaded (no branch) and discarded.  16 loads in flight per round.
+    auto accumulate = [&](int e, int pt, int qt, int tb, int te, double& a2, double& a1) {
+        const double* pe = partial + e;
+        int t = tb;
+        for (; t + 16 <= te; t += 16) {
+            double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = pe[s_off[t + u]];
+            for (int u = 0; u < 16; ++u) v[u] = pe[s_off[t + u]];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int fl = s_list[t + u];
-                    const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
-                    const bool in = (unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq);
-                    const double w = in ? v[u] : 0.0;
-                    if (!split) a2 += w;
-                    else { const bool is2 = (fl >> 30) & 1; a2 += is2 ? w : 0.0; a1 += is2 ? 0.0 : w; }
-                }
-            }
-            for (; t < te; ++t) {
-                const int fl = s_list[t];
+            for (int u = 0; u < 16; ++u) {
+                const int fl = s_list[t + u];
                 const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
-                if ((unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq)) {
-                    const double v = pe[s_off[t]];
-                    if (!split || ((fl >> 30) & 1)) a2 += v; else a1 += v;
-                }
+                const bool in = (unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq);
+                const double w = in ? v[u] : 0.0;
+                if (!split) a2 += w;
+                else { const bool is2 = (fl >> 30) & 1; a2 += is2 ? w : 0.0; a1 += is2 ? 0.0 : w; }
             }
         }
-        s_part[wave][lane][0] = a2; s_part[wave][lane][1] = a1;
-        __syncthreads();
-        if (wave == 0 && live) {
-            a2 = ((s_part[0][lane][0] + s_part[1][lane][0]) + s_part[2][lane][0]) + s_part[3][lane][0];
-            a1 = ((s_part[0][lane][1] + s_part[1][lane][1]) + s_part[2][lane][1]) + s_part[3][lane][1];
-            if (direct) {
-                const double v = a2 + a1;
-                S2[e] = v;
-                if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
-            } else { S2[e] = a2; S1[e] = a1; }
+        for (; t < te; ++t) {
+            const int fl = s_list[t];
+            const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
+            if ((unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq)) {
+                const double v = pe[s_off[t]];
+                if (!split || ((fl >> 30) & 1)) a2 += v; else a1 += v;
+            }
         }
-        __syncthreads();
+    };
+    auto store = [&](int e, int q, int pq, int pt, int qt, double a2, double a1) {
+        if (direct) {
+            const double v = a2 + a1;
+            S2[e] = v;
+            if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
+        } else { S2[e] = a2; S1[e] = a1; }
+    };
+    if (wide) {
+        // one stream: the shares were written by ~100 other CUs, every load is a remote (fabric) round trip and what one CU can keep in
+        // flight bounds its rate.  A workgroup covers only 64 consecutive elements (the launch spreads over ~60 CUs), its four waves
+        // split the feature list into four contiguous chunks, and the chunk sums are added in chunk order (deterministic).
+        for (int e0 = bi.x * 64; e0 < total; e0 += gridDim.x * 64) {
+            const int e = e0 + lane;
+            const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
+            const bool live = e < total && q <= c6 && qt >= pt;       // padding / lower tiles: the mirror image of the upper ones
+            double a2 = 0, a1 = 0;
+            if (live) accumulate(e, pt, qt, (ng * wave) / 4, (ng * (wave + 1)) / 4, a2, a1);
+            s_part[wave][lane][0] = a2; s_part[wave][lane][1] = a1;
+            __syncthreads();
+            if (wave == 0 && live) {
+                a2 = ((s_part[0][lane][0] + s_part[1][lane][0]) + s_part[2][lane][0]) + s_part[3][lane][0];
+                a1 = ((s_part[0][lane][1] + s_part[1][lane][1]) + s_part[2][lane][1]) + s_part[3][lane][1];
+                store(e, q, pq, pt, qt, a2, a1);
+            }
+            __syncthreads();
+        }
+    } else {
+        // batch handles: one thread per element, every share in list order (few accepted features per instance, many instances)
+        for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
+            const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
+            if (q > c6 || qt < pt) continue;
+            double a2 = 0, a1 = 0;
+            accumulate(e, pt, qt, 0, ng, a2, a1);
+            store(e, q, pq, pt, qt, a2, a1);
+        }
     }
     DBG_T(44);
     if (direct) {

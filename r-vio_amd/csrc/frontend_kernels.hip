@@ -2,8 +2,7 @@
 // R-VIO hot path.  Compiled with FP contraction off: the
 // KLT arithmetic (integer fixed-point + float32) is bit-identical to oracle/frontend.cpp.
 //
-//   pyr_level_kernel  one launch per pyramid level: Scharr derivative of level l (calcSharrDeriv),
-//                     cv::pyrDown l -> l+1, and (level 0) the copy of the frame into the pyramid
+//   pyramid_kernel    every level of the image pyramid in one launch (cv::pyrDown chain + the copy of the frame into level 0)
 //   (klt_kernel3      LKTrackerInvoker, all levels, one wave per feature — klt3.hip; CLAHE — clahe.hip; detector — detector.hip)
 //   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
 //   bookkeep_kernel   track book-keeping + FindNewer + refill        (Tracker.cc:271-393, FeatureDetector.cc:78-150)
@@ -22,97 +21,98 @@ __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >
 // [-23, n+22] and every pyramid level has n >= 16)
 __device__ __forceinline__ int reflect2(int i, int n) { return reflect1(reflect1(i, n), n); }
 
-// ------------------------------------------------------------------ pyramid level
-// thread (x,y) of level l:  dxy[y][x] = un-normalised 3x3 Scharr (reflect-101 neighbours, int16 (dx,dy));
-// copy_dst[y][x] = src[y][x] (level 0 only);  if (x,y) lies in level l+1: pyrDown pixel
-// ([1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (v+128)>>8).
-__global__ __launch_bounds__(256) void pyr_level_kernel(const uint8_t* __restrict__ src, int w, int h, int stride,
-                                                        uint8_t* __restrict__ copy_dst, short* __restrict__ dxy,
-                                                        uint8_t* __restrict__ down, int dw, int dh, size_t src_bs, size_t bs) {
-    src = zoff(src, src_bs); if (copy_dst) copy_dst = zoff(copy_dst, bs); dxy = zoff(dxy, bs); if (down) down = zoff(down, bs);
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-    const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
-    const uint8_t *r0 = src + (size_t)ym * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yp * stride;
-    const int a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b1 = r1[x], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
-    const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
-    const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
-    ((int*)dxy)[(size_t)y * w + x] = ((t0p - t0m) & 0xffff) | (((t1p + t1m) * 3 + t1c * 10) << 16);
-    if (copy_dst) copy_dst[(size_t)y * w + x] = (uint8_t)b1;
-    if (down && x < dw && y < dh) {
-        int xs[5];
+// ------------------------------------------------------------------ pyramid
+// buildOpticalFlowPyramid of cv::calcOpticalFlowPyrLK (Tracker.cc:244) in ONE launch: a workgroup owns an 8x8 tile of level 3 and
+// everything above it — it stages the 85x85 patch of level 0 that tile depends on, forms its 41x41 / 19x19 dependency patches of
+// levels 1 / 2 in LDS (cv::pyrDown: [1 4 6 4 1]/16 separable, BORDER_REFLECT_101 at every level's own size, (v+128)>>8) and
+// stores the tiles it owns: 64x64 of level 0 (the copy of the frame into the pyramid), 32x32 of level 1, 16x16 of level 2, 8x8 of
+// level 3.  The patches overlap between neighbours ((85/64)^2 = 1.8 x the level-0 reads, all L2 hits); nothing but the u8 levels is
+// written: the Scharr derivatives of the template are formed by the KLT kernel from its staged patch (they used to be
+// materialised as int16x2 images: 2.5 MB of stores per 752x480 frame against 0.12 MB for levels 1..3).
+#define PYR_T 256
+__device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int sw, int sx0, int sy0, int w, int h, int x, int y) {
+    // pyrDown pixel (x, y) of the next level from the LDS patch `src` (row stride sw) that holds level pixels [sx0.., sy0..]
+    int xs[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, w);
-        int rows[5];
+    for (int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, w) - sx0;
+    int rows[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint8_t* s = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
-            rows[k] = s[xs[2]] * 6 + (s[xs[1]] + s[xs[3]]) * 4 + s[xs[0]] + s[xs[4]];
+    for (int k = 0; k < 5; ++k) {
+        const uint8_t* s = src + (reflect101(2 * y - 2 + k, h) - sy0) * sw;
+        rows[k] = s[xs[2]] * 6 + (s[xs[1]] + s[xs[3]]) * 4 + s[xs[0]] + s[xs[4]];
+    }
+    return (rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6 + 128) >> 8;
+}
+__global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); pyr_shift(p, (size_t)blockIdx.z * bs);
+    __shared__ uint8_t L0[85 * 88], L1[41 * 44], L2[19 * 20];
+    const int tid = threadIdx.x;
+    const int X3 = blockIdx.x * 8, Y3 = blockIdx.y * 8;
+    const int w0 = p.w[0], h0 = p.h[0];
+    // level-0 patch [8 X3 - 14, 8 X3 + 70] clipped to the image
+    const int ax = max(8 * X3 - 14, 0), ay = max(8 * Y3 - 14, 0), bx = min(8 * X3 + 70, w0 - 1), by = min(8 * Y3 + 70, h0 - 1);
+    const int pw = bx - ax + 1, ph = by - ay + 1;
+    if (pw <= 0 || ph <= 0) return;
+    for (int e = tid; e < pw * ph; e += PYR_T) { const int yy = e / pw, xx = e - yy * pw; L0[yy * 88 + xx] = src[(size_t)(ay + yy) * stride + ax + xx]; }
+    __syncthreads();
+    if (copy0) {   // this workgroup's 64x64 tile of level 0
+        uint8_t* d0 = (uint8_t*)p.img[0];
+        for (int e = tid; e < 64 * 64; e += PYR_T) {
+            const int x = 8 * X3 + (e & 63), y = 8 * Y3 + (e >> 6);
+            if (x < w0 && y < h0) d0[(size_t)y * w0 + x] = L0[(y - ay) * 88 + (x - ax)];
         }
-        const int v = rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6;
-        down[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+    }
+    if (levels < 2) return;
+    const int w1 = p.w[1], h1 = p.h[1];
+    const int cx = max(4 * X3 - 6, 0), cy = max(4 * Y3 - 6, 0), dx = min(4 * X3 + 34, w1 - 1), dy = min(4 * Y3 + 34, h1 - 1);
+    const int qw = dx - cx + 1, qh = dy - cy + 1;
+    if (qw <= 0 || qh <= 0) return;
+    {
+        uint8_t* d1 = (uint8_t*)p.img[1];
+        for (int e = tid; e < qw * qh; e += PYR_T) {
+            const int yy = e / qw, xx = e - yy * qw, x = cx + xx, y = cy + yy;
+            const int v = pyr_down_at(L0, 88, ax, ay, w0, h0, x, y);
+            L1[yy * 44 + xx] = (uint8_t)v;
+            if (x >= 4 * X3 && x < 4 * X3 + 32 && y >= 4 * Y3 && y < 4 * Y3 + 32) d1[(size_t)y * w1 + x] = (uint8_t)v;
+        }
+    }
+    if (levels < 3) return;
+    __syncthreads();
+    const int w2 = p.w[2], h2 = p.h[2];
+    const int ex = max(2 * X3 - 2, 0), ey = max(2 * Y3 - 2, 0), fx = min(2 * X3 + 16, w2 - 1), fy = min(2 * Y3 + 16, h2 - 1);
+    const int rw = fx - ex + 1, rh = fy - ey + 1;
+    if (rw <= 0 || rh <= 0) return;
+    {
+        uint8_t* d2 = (uint8_t*)p.img[2];
+        for (int e = tid; e < rw * rh; e += PYR_T) {
+            const int yy = e / rw, xx = e - yy * rw, x = ex + xx, y = ey + yy;
+            const int v = pyr_down_at(L1, 44, cx, cy, w1, h1, x, y);
+            L2[yy * 20 + xx] = (uint8_t)v;
+            if (x >= 2 * X3 && x < 2 * X3 + 16 && y >= 2 * Y3 && y < 2 * Y3 + 16) d2[(size_t)y * w2 + x] = (uint8_t)v;
+        }
+    }
+    if (levels < 4) return;
+    __syncthreads();
+    const int w3 = p.w[3], h3 = p.h[3];
+    if (tid < 64) {
+        const int x = X3 + (tid & 7), y = Y3 + (tid >> 3);
+        if (x < w3 && y < h3) ((uint8_t*)p.img[3])[(size_t)y * w3 + x] = (uint8_t)pyr_down_at(L2, 20, ex, ey, w2, h2, x, y);
     }
 }
 
-// Throughput form of the same level (batched launches: many images per launch, the load/store instruction count is what
-// limits): one thread = 4 horizontally adjacent pixels, rows read as aligned 32-bit words.  Requires w % 4 == 0,
-// stride % 4 == 0 and 4-byte aligned rows (the host checks); identical integer arithmetic, identical output.
-__device__ __forceinline__ int pyr_dx(int a0, int b0, int c0, int a2, int b2, int c2) { return ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10); }
-__global__ __launch_bounds__(256) void pyr_level_kernel4(const uint8_t* __restrict__ src, int w, int h, int stride,
-                                                         uint8_t* __restrict__ copy_dst, short* __restrict__ dxy,
-                                                         uint8_t* __restrict__ down, int dw, int dh, size_t src_bs, size_t bs) {
-    src = zoff(src, src_bs); if (copy_dst) copy_dst = zoff(copy_dst, bs); dxy = zoff(dxy, bs); if (down) down = zoff(down, bs);
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+// calcSharrDeriv of one pyramid level, on demand (rvio_hip_debug_pyramid): un-normalised 3x3 Scharr with reflect-101 neighbours,
+// int16 (dx,dy) packed — the same arithmetic the KLT kernel applies to its staged template patch
+__device__ __forceinline__ int scharr_pack(int a0, int a1, int a2, int b0, int b2, int c0, int c1, int c2) {
+    const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
+    const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
+    return ((t0p - t0m) & 0xffff) | (((t1p + t1m) * 3 + t1c * 10) << 16);
+}
+__global__ __launch_bounds__(256) void scharr_debug_kernel(const uint8_t* __restrict__ src, int w, int h, int* __restrict__ dxy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-    const int xl = x > 0 ? x - 1 : 1, xr = x + 4 < w ? x + 4 : w - 2;      // reflect-101 neighbours of the 4-pixel run
-    const uint8_t *r0 = src + (size_t)ym * stride, *r1 = src + (size_t)y * stride, *r2 = src + (size_t)yp * stride;
-    const uint32_t wa = *(const uint32_t*)(r0 + x), wb = *(const uint32_t*)(r1 + x), wc = *(const uint32_t*)(r2 + x);
-    int a[6], b[6], c[6];
-    a[0] = r0[xl]; b[0] = r1[xl]; c[0] = r2[xl]; a[5] = r0[xr]; b[5] = r1[xr]; c[5] = r2[xr];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k + 1] = (wa >> (8 * k)) & 255; b[k + 1] = (wb >> (8 * k)) & 255; c[k + 1] = (wc >> (8 * k)) & 255; }
-    int o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int dxv = pyr_dx(a[k], b[k], c[k], a[k + 2], b[k + 2], c[k + 2]);
-        const int dyv = ((c[k + 2] - a[k + 2]) + (c[k] - a[k])) * 3 + (c[k + 1] - a[k + 1]) * 10;
-        o[k] = (dxv & 0xffff) | (dyv << 16);
-    }
-    *(int4*)((int*)dxy + (size_t)y * w + x) = make_int4(o[0], o[1], o[2], o[3]);
-    if (copy_dst) *(uint32_t*)(copy_dst + (size_t)y * w + x) = wb;
-    if (down && x < dw && y < dh) {
-        // pyrDown pixels (x..x+3, y): source columns 2x-2 .. 2x+8, rows 2y-2 .. 2y+2
-        const bool inner = x > 0 && 2 * x + 8 < w;       // no reflection in x: three aligned words + one byte per row
-        int v[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint8_t* sr = src + (size_t)reflect101(2 * y - 2 + k, h) * stride;
-            int e[11];
-            if (inner) {
-                const uint32_t u0 = *(const uint32_t*)(sr + 2 * x - 4), u1 = *(const uint32_t*)(sr + 2 * x), u2 = *(const uint32_t*)(sr + 2 * x + 4);
-                e[0] = (u0 >> 16) & 255; e[1] = u0 >> 24;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { e[2 + q] = (u1 >> (8 * q)) & 255; e[6 + q] = (u2 >> (8 * q)) & 255; }
-                e[10] = sr[2 * x + 8];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 11; ++q) e[q] = sr[reflect101(2 * x - 2 + q, w)];
-            }
-            const int wk = (k == 0 || k == 4) ? 1 : ((k == 2) ? 6 : 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += wk * (e[2 * q + 2] * 6 + (e[2 * q + 1] + e[2 * q + 3]) * 4 + e[2 * q] + e[2 * q + 4]);
-        }
-        uint8_t* dr = down + (size_t)y * dw + x;
-        if (x + 3 < dw && (dw & 3) == 0) {
-            *(uint32_t*)dr = (uint32_t)(((v[0] + 128) >> 8) & 255) | ((uint32_t)(((v[1] + 128) >> 8) & 255) << 8) |
-                             ((uint32_t)(((v[2] + 128) >> 8) & 255) << 16) | ((uint32_t)(((v[3] + 128) >> 8) & 255) << 24);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (x + q < dw) dr[q] = (uint8_t)((v[q] + 128) >> 8);
-        }
-    }
+    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    const uint8_t *r0 = src + (size_t)ym * w, *r1 = src + (size_t)y * w, *r2 = src + (size_t)yp * w;
+    dxy[(size_t)y * w + x] = scharr_pack(r0[xm], r0[x], r0[xp], r1[xm], r1[xp], r2[xm], r2[x], r2[xp]);
 }
 
 // ------------------------------------------------------------------ KLT

@@ -2,7 +2,8 @@
 // Included inside the FP-contraction-off region of rvio_hip.hip: bit-identical to oracle/frontend.cpp.
 //
 // One wave per feature, lane l owns window pixels p = l + 64 q (q < 4, p < 225).  Changes over klt_kernel:
-//   * ALL pyramid levels' template sources (16x16 u8 + 16x16 packed int16 gradients) and 32x32 search regions are
+//   * ALL pyramid levels' template sources (an 18x18 u8 patch: the 16x16 the bilinear template reads plus the one-pixel ring its
+//     Scharr derivatives need — calcSharrDeriv is applied to the staged patch, no derivative image exists) and 32x32 search regions are
 //     fetched in ONE batch at kernel start (the template positions depend only on the input point; the search
 //     regions are centred on the zero-motion guess and restaged only if the window leaves them) — one HBM/L2 round
 //     trip instead of one per level (profiles/r01_b: ~3 us per level);
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int 
                                                   const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status, size_t bs) {
     pyr_shift(prev, (size_t)blockIdx.z * bs); pyr_shift(next, (size_t)blockIdx.z * bs);
     n_pts_ptr = zoff(n_pts_ptr, bs); pts = zoff(pts, bs); out = zoff(out, bs); status = zoff(status, bs);
-    __shared__ uint8_t Ip[4][16 * 16];
+    __shared__ uint8_t Ip[4][18 * 18 + 4];   // (Y0 - 1 .. Y0 + 16) x (X0 - 1 .. X0 + 16), reflect-101 coordinates
     __shared__ int dIp[4][16 * 16];
     __shared__ uint8_t Jr[4][KLT3_JR * KLT3_JR];
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -64,23 +65,52 @@ __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int 
             const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
             jx0[level] = ipx - 8; jy0[level] = ipy - 8;
             if (!(ipx < -15 || ipx >= w || ipy < -15 || ipy >= h)) {
-                const uint8_t* I = prev.img[level]; const int* dI = (const int*)prev.dxy[level];
+                const uint8_t* I = prev.img[level];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = lane + 64 * q, X = ipx + (e & 15), Y = ipy + (e >> 4);
-                    Ip[level][e] = I[(size_t)reflect1(Y, h) * w + reflect1(X, w)];
-                    dIp[level][e] = (X < 0 || Y < 0 || X >= w || Y >= h) ? 0 : dI[(size_t)Y * w + X];
+                for (int q = 0; q < 6; ++q) {
+                    const int e = lane + 64 * q;
+                    if (e < 18 * 18) {
+                        const int X = ipx - 1 + (e % 18), Y = ipy - 1 + (e / 18);
+                        Ip[level][e] = I[(size_t)reflect2(Y, h) * w + reflect2(X, w)];
+                    }
                 }
                 klt3_stage_j(Jr[level], next.img[level], w, h, jx0[level], jy0[level], lane);
             }
         }
     }
     __syncthreads();
+    // calcSharrDeriv on the staged patches: derivative at template pixel (X, Y); outside the image the derivative image is 0
+    // (BORDER_CONSTANT), inside it the neighbours are the reflect-101 ones the patch already holds
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {
+        if (level < levels) {
+            const int w = prev.w[level], h = prev.h[level];
+            const float sc = (float)(1. / (1 << level));
+            const int ipx = (int)floorf(px * sc - 7.f), ipy = (int)floorf(py * sc - 7.f);
+            if (!(ipx < -15 || ipx >= w || ipy < -15 || ipy >= h)) {
+                const uint8_t* P = Ip[level];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = lane + 64 * q, xx = e & 15, yy = e >> 4, X = ipx + xx, Y = ipy + yy;
+                    const uint8_t* c = P + (yy + 1) * 18 + (xx + 1);
+                    int g = 0;
+                    if (!(X < 0 || Y < 0 || X >= w || Y >= h)) {
+                        const int a0 = c[-19], a1 = c[-18], a2 = c[-17], b0 = c[-1], b2 = c[1], c0 = c[17], c1 = c[18], c2 = c[19];
+                        const int t0m = (a0 + c0) * 3 + b0 * 10, t0p = (a2 + c2) * 3 + b2 * 10;
+                        const int t1m = c0 - a0, t1c = c1 - a1, t1p = c2 - a2;
+                        g = ((t0p - t0m) & 0xffff) | (((t1p + t1m) * 3 + t1c * 10) << 16);
+                    }
+                    dIp[level][e] = g;
+                }
+            }
+        }
+    }
+    __syncthreads();
     float nx = 0, ny = 0;
     int st = 1;
-    int wo16[4], woJ[4];      // this lane's window pixels as offsets into a 16-wide patch / the 32-wide region
+    int wo16[4], wo18[4], woJ[4];      // this lane's window pixels as offsets into the 16-wide gradient patch / the 18-wide template patch / the 32-wide region
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int p = lane + 64 * q; wo16[q] = (p / 15) * 16 + (p % 15); woJ[q] = (p / 15) * KLT3_JR + (p % 15); }
+    for (int q = 0; q < 4; ++q) { const int p = lane + 64 * q; wo16[q] = (p / 15) * 16 + (p % 15); wo18[q] = (p / 15 + 1) * 18 + (p % 15) + 1; woJ[q] = (p / 15) * KLT3_JR + (p % 15); }
 #pragma unroll
     for (int level = 3; level >= 0; --level) {
         if (level >= levels) continue;
@@ -104,8 +134,8 @@ __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int 
         for (int q = 0; q < 4; ++q) {
             Iw[q] = 0; Ixw[q] = 0; Iyw[q] = 0;
             if (lane + 64 * q < 225) {
-                const int o = wo16[q];
-                const int ival = descale(Il[o] * iw00 + Il[o + 1] * iw01 + Il[o + 16] * iw10 + Il[o + 17] * iw11, 14 - 5);
+                const int o = wo16[q], o8 = wo18[q];
+                const int ival = descale(Il[o8] * iw00 + Il[o8 + 1] * iw01 + Il[o8 + 18] * iw10 + Il[o8 + 19] * iw11, 14 - 5);
                 const int d00 = dIl[o], d01 = dIl[o + 1], d10 = dIl[o + 16], d11 = dIl[o + 17];
                 const int ixv = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 + (short)(d11 & 0xffff) * iw11, 14);
                 const int iyv = descale((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 + (d11 >> 16) * iw11, 14);

@@ -276,8 +276,8 @@ static int alloc_frontend_slab(rvio_hip* h) {
     for (int b = 0; b < 2; ++b) {
         int w = d.W, hg = d.H;
         for (int l = 0; l < 4; ++l) {
-            uint8_t* im = nullptr; short* dx = nullptr;
-            if (l < d.levels) { DALLOC(h, im, (size_t)w * hg); DALLOC(h, dx, (size_t)w * hg * 2); }
+            uint8_t* im = nullptr; short* dx = nullptr;   // (no derivative images: the KLT kernel forms them from its staged patch)
+            if (l < d.levels) DALLOC(h, im, (size_t)w * hg);
             h->pyr[b].img[l] = im; h->pyr[b].dxy[l] = dx; h->pyr[b].w[l] = w; h->pyr[b].h[l] = hg;
             w = (w + 1) / 2; hg = (hg + 1) / 2;
         }
@@ -406,6 +406,9 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
             h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
             if (getenv("RVIO_SOLVE6") || getenv("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
+            // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
+            // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
+            if (batch > 1 && h->solve5_variant && !getenv("RVIO_SOLVE7")) h->solve7_variant = 0;
             if (h->solve7_variant == 1)
             {
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
@@ -626,8 +629,10 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
                        h->tm_global, bs, h->bin, h->meta);
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + 63) / 64)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
-                       h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, bs, h->bin);
+    // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
+    const int gram_chunk = (B == 1) ? 64 : 256;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + gram_chunk - 1) / gram_chunk)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
+                       h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, (B == 1) ? 1 : 0, bs, h->bin);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -899,22 +904,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         if (rc != RVIO_OK) return rc;
         if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, h->ts));   // corners of frame k ready (book-keeping on the side stream waits for it)
     }
-    // one launch per level: Scharr(l) + pyrDown(l -> l+1) (+ the copy of the caller's frame into level 0)
-    for (int l = 0; l < d.levels; ++l) {
-        const bool last = (l + 1 == d.levels);
-        const uint8_t* src = (l == 0) ? d_img : p.img[l];
-        const int sst = (l == 0) ? stride : p.w[l];
-        const size_t sbs = (l == 0) ? src_bs : bs;
-        // many images per launch: the 4-pixels-per-thread form (word-aligned rows required); one image: the 1-pixel form (lower latency)
-        const bool wide = h->wide_px && p.w[l] % 4 == 0 && sst % 4 == 0 && ((uintptr_t)src & 3) == 0 && sbs % 4 == 0;
-        if (wide)
-            hipLaunchKernelGGL(pyr_level_kernel4, dim3((p.w[l] / 4 + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->side, src, p.w[l], p.h[l],
-                               sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
-                               last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
-        else
-            hipLaunchKernelGGL(pyr_level_kernel, dim3((p.w[l] + 63) / 64, (p.h[l] + 3) / 4, B), dim3(256), 0, h->side, src, p.w[l], p.h[l],
-                               sst, (l == 0) ? (uint8_t*)p.img[0] : (uint8_t*)nullptr, (short*)p.dxy[l],
-                               last ? (uint8_t*)nullptr : (uint8_t*)p.img[l + 1], last ? 0 : p.w[l + 1], last ? 0 : p.h[l + 1], sbs, bs);
+    // the whole pyramid in one launch (pyrDown chain + the copy of the frame into level 0); one workgroup per 8x8 tile of level 3
+    {
+        const int w3 = (((d.W + 1) / 2 + 1) / 2 + 1) / 2, h3 = (((d.H + 1) / 2 + 1) / 2 + 1) / 2;
+        hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, h->side, d_img, stride, p, d.levels, 1, src_bs, bs);
     }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -1302,7 +1295,14 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
     if (hgt) *hgt = p.h[level];
     const size_t n = (size_t)p.w[level] * p.h[level];
     if (img) HIPCHK(h, hipMemcpyAsync(img, p.img[level], n, hipMemcpyDeviceToHost, h->stream));
-    if (dxy) HIPCHK(h, hipMemcpyAsync(dxy, p.dxy[level], n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (dxy) {   // calcSharrDeriv of that level, computed on demand (the pipeline keeps no derivative image)
+        int* tmp = nullptr;
+        HIPCHK(h, hipMalloc((void**)&tmp, n * sizeof(int)));
+        hipLaunchKernelGGL(scharr_debug_kernel, dim3((p.w[level] + 63) / 64, (p.h[level] + 3) / 4), dim3(256), 0, h->stream, p.img[level], p.w[level], p.h[level], tmp);
+        HIPCHK(h, hipMemcpyAsync(dxy, tmp, n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        hipFree(tmp);
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
@@ -1347,8 +1347,8 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
-            hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + 63) / 64)), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
-                               h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, h->slab_bytes, h->bin);
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + (h->batch == 1 ? 63 : 255)) / (h->batch == 1 ? 64 : 256))), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
+                               h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);
         } else if (which == 4) {   // U, G, P1 strips on the operands of the last update (outputs to scratch)
             hipLaunchKernelGGL(ug_kernel, dim3((24 + 6 * n + 15) / 16, 1, h->batch), dim3(256), h->ug_lds, h->stream, d, n, h->P[h->cur], h->W, h->block, h->U, h->G, h->Pt1, h->slab_bytes);
         } else if (which == 5) {   // Joseph form, written to the spare covariance buffer (overwritten by the next stage anyway)

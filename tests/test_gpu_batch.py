@@ -1,6 +1,13 @@
 """Batched filter (rvio_hip_create_batch / rvio_hip_frame_tracks_dev): B instances advanced by one launch
-per stage must equal, BIT FOR BIT, B plain handles fed the same inputs through the per-stage calls — and therefore the oracle
-within the filter tolerance."""
+per stage against B plain handles fed the same inputs through the per-stage calls.  The front end (integer / float32 with order-free
+sums) is bit for bit the same; the filter agrees to rounding — a batch handle runs the throughput forms of three filter kernels
+(solve6 behind gemm_T instead of solve7, the compact share reduction, fewer loads in flight in the gate), the same algorithms with
+a different summation grouping — and therefore both agree with the oracle within the filter tolerance."""
+
+
+def same_filter_state(xa, Pa, xb, Pb):
+    """rounding-level agreement of two filter states (free-running sequences amplify the last bits a little)"""
+    return S.state_delta(xa, xb) <= 1e-11 and float(np.max(np.abs(Pa - Pb))) <= 1e-11 * max(1e-30, float(np.max(np.abs(Pb))))
 import numpy as np
 import pytest
 
@@ -67,7 +74,7 @@ def test_batch_equals_plain_handles_bit_for_bit(gpu_required, recs3, shared_imu)
         for i in range(B):
             xa, Pa = hb.get_state_at(i)
             xb, Pb = hs[i].get_state()
-            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), (f, i)
+            assert same_filter_state(xa, Pa, xb, Pb), (f, i)
             if not shared_imu:      # the recorded oracle states belong to the recorded IMU
                 assert S.state_delta(xa, rf[i]["x3"]) <= 1e-9, (f, i)
     assert n_upd > 20
@@ -151,7 +158,7 @@ def test_batch_with_front_end_equals_plain_handles_bit_for_bit(gpu_required, sce
         hs[i].sync()
         xa, Pa = hb.get_state_at(i)
         xb, Pb = hs[i].get_state()
-        assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), i
+        assert same_filter_state(xa, Pa, xb, Pb), i
         n_upd += hs[i].frame_info()["updated"]
         pa, la = hb.get_points_at(i)
         pb, lb = hs[i].get_points()
@@ -206,7 +213,7 @@ def test_batch_front_end_other_image_sizes(gpu_required, case):
     for b in range(B):
         xa, Pa = hb.get_state_at(b)
         xb, Pb = hs[pick[b]].get_state()
-        assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), (case, b)
+        assert same_filter_state(xa, Pa, xb, Pb), (case, b)
         pa, la = hb.get_points_at(b)                     # the tracker's feature list and history lengths (the window is still too short
         pb, lb = hs[pick[b]].get_points()                # for an update after these few frames, so the states alone would not see the tracker)
         assert len(pa) > 100 and np.array_equal(pa, pb) and np.array_equal(la, lb), (case, b)
