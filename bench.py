@@ -229,6 +229,20 @@ def main():
         h2.close()
         out["independent_streams"] = {"value": world * K / el2, "unit": "frames/s", "scaling": "weak",
                                       "note": "one camera stream per GPU, no collective; `value` above is ONE stream with its updater sharded over the GPUs"}
+        # the multi-GPU mode that pays at this window size: a FLEET of filter instances sharded by instance —
+        # rank r owns instances r, r + N, ... of a fixed fleet, one batch handle per GPU, no collective at all (strong scaling of the fleet)
+        fleet = 2048
+        per = max(1, fleet // world)
+        leg = batched_filter_leg(cfg, torch, [per], name=args.config, seed0=4 * rank, barrier=(dist.barrier if world > 1 else None))
+        el3 = torch.tensor([leg["sizes"][0]["ms_per_batched_frame"]], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+        ms = float(el3.item())
+        out["instance_sharded_fleet"] = {"instances_total": per * world, "instances_per_gpu": per, "ms_per_fleet_frame": ms,
+                                         "filter_frames_per_s": per * world / (ms * 1e-3), "scaling": "strong", "collectives_per_frame": 0,
+                                         "algorithmic_mflop_per_filter_frame": leg["algorithmic_mflop_per_filter_frame"],
+                                         "achieved_tflops_fp64_per_gpu": leg["algorithmic_mflop_per_filter_frame"] * 1e6 * per / (ms * 1e-3) / 1e12,
+                                         "note": "rvio_hip_create_batch per GPU, instances r, r+N, ... of a %d-instance fleet on rank r; max over ranks of the batched-frame time" % (per * world)}
     if rank == 0 and world == 1 and not args.no_streams:
         # (first of the extra legs: a process normally owns ONE handle.  HIP multiplexes its streams onto 4 hardware queues in creation
         # order; a handle created after dozens of other streams — the later legs — can find two of its three streams on one queue and
@@ -506,7 +520,7 @@ def filter_flops(cfg, n, lens, types, m):
     return w
 
 
-def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=40):
+def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=40, seed0=0, barrier=None):
     """B independent filter instances advanced by ONE launch per stage (rvio_hip_create_batch).  The hand-over
     tables come from `seeds` direct-track sequences (different landmark/noise seeds) run through plain handles first; instance b
     replays sequence b mod seeds.  Reports filter-frames/s and the FP64 rate against W_filter of the tracks actually processed."""
@@ -515,7 +529,7 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
     nf = n_warm + n_timed
     k0 = K0
     tabs, inits, flops = [], [], np.zeros(nf)
-    for sd in range(seeds):
+    for sd in range(seed0, seed0 + seeds):
         seq = rv.synth.SynthSequence(cfg, duration=(k0 + nf + 3) / 20.0 + 1.0, seed=sd)
         wi, ai, ni = seq.init_from_static(k0)
         h = hip.RvioHip(cfg)
@@ -565,10 +579,14 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
         for f in range(n_warm):
             frame(f)
         h.sync()
+        if barrier is not None:
+            barrier()
         t0 = time.perf_counter()
         for f in range(n_warm, nf):
             frame(f)
         h.sync()
+        if barrier is not None:
+            barrier()
         el = time.perf_counter() - t0
         x_last = h.get_state_at(B - 1)[0]
         h.close()

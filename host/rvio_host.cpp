@@ -77,7 +77,15 @@ bool parse_settings(const std::string& text, Settings* out, std::string* err) {
     if (!parse_yaml(text, &y, err)) return false;
     rvio_config& c = out->cfg;
     rvio_config_euroc(&c);
-    auto num = [&](const char* k, double dflt) { auto it = y.num.find(k); return it == y.num.end() ? dflt : it->second; };
+    out->missing.clear();
+    // (Camera.k3, Camera.Fisheye, Camera.nTimeOffset and INI.RecordOutputs are optional upstream too: absent in some of its settings files)
+    auto num = [&](const char* k, double dflt) {
+        auto it = y.num.find(k);
+        if (it != y.num.end()) return it->second;
+        const std::string ks(k);
+        if (ks != "Camera.k3" && ks != "Camera.Fisheye" && ks != "Camera.nTimeOffset" && ks != "INI.RecordOutputs") out->missing.push_back(ks);
+        return dflt;
+    };
     c.imu_rate = num("IMU.dps", c.imu_rate);
     c.sigma_g = num("IMU.sigma_g", c.sigma_g); c.sigma_wg = num("IMU.sigma_wg", c.sigma_wg);
     c.sigma_a = num("IMU.sigma_a", c.sigma_a); c.sigma_wa = num("IMU.sigma_wa", c.sigma_wa);
@@ -90,6 +98,7 @@ bool parse_settings(const std::string& text, Settings* out, std::string* err) {
     c.sigma_px = (float)num("Camera.sigma_px", c.sigma_px); c.sigma_py = (float)num("Camera.sigma_py", c.sigma_py);
     c.fisheye = (int)num("Camera.Fisheye", c.fisheye);
     auto m = y.mat.find("Camera.T_BC0");
+    if (m == y.mat.end()) out->missing.push_back("Camera.T_BC0");
     if (m != y.mat.end()) {
         if (m->second.size() != 16) { if (err) *err = "settings: Camera.T_BC0 must hold 16 values"; return false; }
         for (int i = 0; i < 16; ++i) c.T_bc[i] = m->second[i];
@@ -187,6 +196,10 @@ int System::MonoVIO(PoseLine* pose) {
     static_assert(sizeof(ImuData) == sizeof(rvio_imu), "ImuData mirrors rvio_imu");
     const rvio_imu* pi = reinterpret_cast<const rvio_imu*>(imus.data() + first);
     const int m = (int)(imus.size() - first);
+    // (one call takes up to RVIO_HIP_MAX_IMU = 192 samples, 0.96 s at 200 Hz: a gap of a few dropped images is integrated in one go as
+    // upstream does, PreIntegrator.cc:97.  The robocentric propagation starts from a freshly composed state — q_k = identity, p_k = 0 —
+    // so a longer gap cannot be split into two propagate calls; it is reported.)
+    if (m > RVIO_HIP_MAX_IMU) { err_ = "more than RVIO_HIP_MAX_IMU inertial samples between two images"; return -1; }
     if (image.width != s_.cfg.width || image.height != s_.cfg.height) { err_ = "image size does not match Camera.width/height"; return -1; }
     // the timed body of MonoVIO (System.cc:253-367): track -> propagate -> update -> augment -> compose
     if (rvio_hip_frame(h_, image.px.data(), image.width, pi, m, nullptr, 0) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }

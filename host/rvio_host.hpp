@@ -36,6 +36,8 @@ struct Settings {
     rvio_config cfg;              // everything the hot path needs
     double cam_time_offset = 0;   // Camera.nTimeOffset
     int record_outputs = 0;       // INI.RecordOutputs
+    std::vector<std::string> missing;   // keys the reference reads (cv::FileStorage would yield 0 for them) that the file does not hold:
+                                        // they keep the EuRoC defaults here, and the caller is told (rvio_replay prints them)
 };
 // Parses the OpenCV-YAML (1.0) subset the reference's settings files use: "Key: scalar" lines, '#' comments and
 // "Key: !!opencv-matrix" blocks (rows / cols / dt / data: [ ... ]).  Missing keys keep the EuRoC defaults.

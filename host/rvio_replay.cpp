@@ -21,6 +21,7 @@ using namespace rvio;
 static int check_settings(const char* path) {
     Settings s; std::string err;
     if (!read_settings(path, &s, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    for (const std::string& k : s.missing) std::fprintf(stderr, "settings: %s is missing (upstream would read 0); the EuRoC default is used\n", k.c_str());
     const rvio_config& c = s.cfg;
     std::printf("{\"imu_rate\": %.17g, \"sigma_g\": %.17g, \"sigma_wg\": %.17g, \"sigma_a\": %.17g, \"sigma_wa\": %.17g, \"gravity\": %.17g, "
                 "\"small_angle\": %.17g, \"width\": %d, \"height\": %d, \"fx\": %.9g, \"fy\": %.9g, \"cx\": %.9g, \"cy\": %.9g, "
@@ -73,6 +74,7 @@ int main(int argc, char** argv) {
     }
     Settings s; std::string err;
     if (!read_settings(argv[1], &s, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }   // System.cc:54-58: exit(-1)
+    for (const std::string& k : s.missing) std::fprintf(stderr, "settings: %s is missing (upstream would read 0); the EuRoC default is used\n", k.c_str());
     AslDataset d;
     if (!read_asl(argv[2], &d, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
     System sys(s, device);

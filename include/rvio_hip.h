@@ -32,6 +32,9 @@ extern "C" {
 #endif
 
 #define RVIO_HIP_ABI_VERSION 2
+/* IMU samples one call accepts (0.96 s at 200 Hz: a few dropped images).  The robocentric propagation starts from a freshly
+ * composed state (PreIntegrator.cc:63-70 after System.cc:325-365), so a longer gap cannot be split over two calls. */
+#define RVIO_HIP_MAX_IMU 192
 
 typedef enum rvio_status {
     RVIO_OK = 0,

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define RVIO_MAX_IMU 64      // IMU samples per frame the propagate kernel accepts
+#define RVIO_MAX_IMU 192     // IMU samples per call (= RVIO_HIP_MAX_IMU of the header): RANSAC forms one delta rotation per thread
 #define RVIO_MAX_LEN 32      // max Tracker.nMaxTrackingLength supported (cfg E: 31)
 
 struct DevCfg {

@@ -190,3 +190,16 @@ def test_asl_reader(tmp_path):
     assert got["first_image"].endswith("mav0/cam0/data/%d.pgm" % t0)
     assert abs(got["dt1"] - 0.005) < 1e-6        # stamps are doubles of ~1.4e9 s (ros::Time::toSec): 2.4e-7 s resolution
     assert got["w1"] == [float(v) for v in imu["w"][1]]
+
+
+def test_settings_reader_reports_missing_keys(tmp_path):
+    """a key the reference reads but the file does not hold keeps the EuRoC default AND is reported (upstream's cv::FileStorage would
+    silently yield 0); non-integer block sizes survive (float members upstream, FeatureDetector.h:72-73)"""
+    p = tmp_path / "s.yaml"
+    lines = [ln for ln in EUROC_YAML.splitlines() if not ln.startswith("Tracker.nQualLvl")]
+    p.write_text("\n".join("Tracker.nBlockSizeX: 150.5" if ln.startswith("Tracker.nBlockSizeX") else ln for ln in lines) + "\n")
+    r = subprocess.run([ensure_bin(), "--check-settings", str(p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cfg = json.loads(r.stdout)
+    assert cfg["block_x"] == 150.5 and np.float32(cfg["qual_lvl"]) == np.float32(0.01)
+    assert "Tracker.nQualLvl is missing" in r.stderr and "nBlockSize" not in r.stderr
