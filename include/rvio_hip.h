@@ -40,7 +40,7 @@ typedef enum rvio_status {
     RVIO_OK = 0,
     RVIO_ERR_INVALID = -1,     /* bad argument / size                                   */
     RVIO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error (see last_error)    */
-    RVIO_ERR_UNSUPPORTED = -3, /* e.g. Camera.Fisheye=1                                  */
+    RVIO_ERR_UNSUPPORTED = -3, /* e.g. a cornerSubPix window other than 7 with the device detector */
     RVIO_ERR_STATE = -4        /* call out of sequence (e.g. update before set_state)    */
 } rvio_status;
 
@@ -63,7 +63,7 @@ typedef struct rvio_config {
     float k1, k2, p1, p2, k3;         /* Tracker.cc:51-61                       */
     float sigma_px, sigma_py;         /* Updater.cc:42-44 (sigma_im = max)      */
     double T_bc[16];                  /* Camera.T_BC0, ROW-major 4x4 (Updater.cc:46-53) */
-    int32_t fisheye;                  /* Camera.Fisheye (1 -> RVIO_ERR_UNSUPPORTED) */
+    int32_t fisheye;                  /* Camera.Fisheye: cv::fisheye::undistortPoints with D = (k1,k2,p1,p2) (Tracker.cc:116-119) */
     /* Tracker.* */
     int32_t n_features;               /* Tracker.nFeatures          (Tracker.cc:73)  */
     int32_t max_track_len;            /* Tracker.nMaxTrackingLength (Tracker.cc:78)  */

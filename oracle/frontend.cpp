@@ -276,6 +276,27 @@ void undistort(const rvio_config* c, const float* in, int n, float* out) {
     const double fx = c->fx, fy = c->fy, cx = c->cx, cy = c->cy;
     const double k1 = c->k1, k2 = c->k2, p1 = c->p1, p2 = c->p2, k3 = c->k3;
     const double ifx = 1. / fx, ify = 1. / fy;
+    if (c->fisheye) {
+        // cv::fisheye::undistortPoints (Tracker.cc:118-119; OpenCV 3.3, the version the reference names, README.md:67): D = the four
+        // coefficients the settings file calls k1, k2, p1, p2; ten fixed-point iterations theta <- theta_d / (1 + k theta^2 ...);
+        // no R, no P.  Parity unpinned like the rest of the OpenCV side (OpenCV >= 3.4.2 iterates with Newton steps instead).
+        const double k0 = c->k1, k1f = c->k2, k2f = c->p1, k3f = c->p2;
+        for (int i = 0; i < n; ++i) {
+            const double pwx = ((double)in[2 * i] - cx) / fx, pwy = ((double)in[2 * i + 1] - cy) / fy;
+            double scale = 1.0;
+            const double theta_d = std::sqrt(pwx * pwx + pwy * pwy);
+            if (theta_d > 1e-8) {
+                double theta = theta_d;
+                for (int j = 0; j < 10; ++j) {
+                    const double th2 = theta * theta, th4 = th2 * th2, th6 = th4 * th2, th8 = th6 * th2;
+                    theta = theta_d / (1 + k0 * th2 + k1f * th4 + k2f * th6 + k3f * th8);
+                }
+                scale = std::tan(theta) / theta_d;
+            }
+            out[2 * i] = (float)(pwx * scale); out[2 * i + 1] = (float)(pwy * scale);
+        }
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         double x = in[2 * i], y = in[2 * i + 1];
         x = (x - cx) * ifx; y = (y - cy) * ify;

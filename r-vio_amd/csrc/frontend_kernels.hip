@@ -123,6 +123,22 @@ __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1)
 // ------------------------------------------------------------------ undistort (cv::undistortPoints, 5 fixed iterations)
 __device__ __forceinline__ void undistort_pt(const DevCfg& c, float u, float v, float* ox, float* oy) {
     const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy;
+    if (c.fisheye) {   // cv::fisheye::undistortPoints (Tracker.cc:118-119) with D = (k1, k2, p1, p2): ten fixed-point iterations on theta
+        const double k0 = c.k1, k1 = c.k2, k2 = c.p1, k3 = c.p2;
+        const double pwx = ((double)u - cx) / fx, pwy = ((double)v - cy) / fy;
+        double scale = 1.0;
+        const double theta_d = sqrt(pwx * pwx + pwy * pwy);
+        if (theta_d > 1e-8) {
+            double theta = theta_d;
+            for (int j = 0; j < 10; ++j) {
+                const double th2 = theta * theta, th4 = th2 * th2, th6 = th4 * th2, th8 = th6 * th2;
+                theta = theta_d / (1 + k0 * th2 + k1 * th4 + k2 * th6 + k3 * th8);
+            }
+            scale = tan(theta) / theta_d;
+        }
+        *ox = (float)(pwx * scale); *oy = (float)(pwy * scale);
+        return;
+    }
     const double k1 = c.k1, k2 = c.k2, p1 = c.p1, p2 = c.p2, k3 = c.k3;
     const double ifx = 1. / fx, ify = 1. / fy;
     double x = u, y = v;

@@ -33,6 +33,7 @@ struct DevCfg {
     int ldh;       // row stride (doubles) of stacked [Hx | r] rows = 6*nmax + 1
     int grid_cols, grid_rows;
     int use_sampson;
+    int fisheye;   // Camera.Fisheye: cv::fisheye::undistortPoints instead of cv::undistortPoints (Tracker.cc:116-119)
     int levels;    // pyramid levels actually used (maxLevel+1)
 };
 

@@ -219,6 +219,7 @@ static void fill_devcfg(const rvio_config* c, DevCfg* d) {
     d->off_y = (float)(int)(.5 * (c->height - d->grid_rows * c->block_y));
     d->max_per_block = (d->grid_cols * d->grid_rows > 0) ? (float)(int)((float)c->n_features / (d->grid_cols * d->grid_rows)) : 0.f;
     d->use_sampson = c->use_sampson;
+    d->fisheye = c->fisheye ? 1 : 0;
     // buildOpticalFlowPyramid: stop when a level is not larger than the window
     int w = c->width, hgt = c->height, lv = 1;
     for (int l = 1; l <= 3; ++l) { w = (w + 1) / 2; hgt = (hgt + 1) / 2; if (w <= 15 || hgt <= 15) break; lv++; }
@@ -289,7 +290,6 @@ static int alloc_frontend_slab(rvio_hip* h) {
 static int create_impl(const rvio_config* cfg, int device, int batch, bool front_end, rvio_hip** out) {
     if (!cfg || !out) return RVIO_ERR_INVALID;
     *out = nullptr;
-    if (cfg->fisheye) return RVIO_ERR_UNSUPPORTED;
     if (cfg->max_track_len < 3 || cfg->max_track_len > RVIO_MAX_LEN || cfg->n_features < 2 || cfg->min_track_len < 2) return RVIO_ERR_INVALID;
     if (batch < 1) return RVIO_ERR_INVALID;
     int ndev = 0;

@@ -48,8 +48,6 @@ def test_config_euroc_matches_python_mirror(lib):
 
 def test_create_rejects_bad_configs(lib):
     h = C.c_void_p()
-    bad = abi.config_euroc(enable_equalizer=0, fisheye=1)
-    assert lib.rvio_hip_create(C.byref(bad), 0, C.byref(h)) == -3
     bad = abi.config_euroc(enable_equalizer=0, max_track_len=40)
     assert lib.rvio_hip_create(C.byref(bad), 0, C.byref(h)) == -1
     assert lib.rvio_hip_create(None, 0, C.byref(h)) == -1

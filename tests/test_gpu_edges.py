@@ -133,3 +133,28 @@ def test_find_newer_int_members_on_the_device(gpu_required):
         n_pts, _ = _same_tracker(h, t, case)
         assert n_pts > 50
         h.close()
+
+
+def test_fisheye_camera(gpu_required):
+    """Camera.Fisheye: 1 (Tracker.cc:116-119): the device undistortion against the oracle's on a direct-track sequence — normalised
+    coordinates equal to within one float32 ulp (tan() is the only library call in the path), filter states within 1e-6"""
+    from rvio_amd import hip
+    cfg = abi.config_named("B", enable_equalizer=0, fisheye=1, k1=-0.0137, k2=0.0207, p1=-0.0128, p2=0.0025)
+    seq, recs = S.record_sequence(cfg, n_frames=24)
+    h = hip.RvioHip(cfg)
+    w, a, n = seq.init_from_static(38)
+    h.initialize(w, a, n)
+    worst = 0.0
+    for r in recs:
+        inp = r["inp"]
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        x, P = h.get_state()
+        worst = max(worst, S.state_delta(x, r["x3"]))
+        pts, hl = h.get_points()
+        assert np.array_equal(pts, r["pts"]) and np.array_equal(hl, r["hist_len"])
+        if len(inp["tracked"]):
+            _, un = h.debug_tracked(len(inp["tracked"]))
+            want = O.undistort(cfg, inp["tracked"])
+            assert np.all(np.abs(un - want) <= np.spacing(np.abs(want)).astype(np.float32))
+    h.close()
+    assert recs[-1]["did_update"] and worst <= 1e-6, worst

@@ -190,6 +190,23 @@ def test_undistort_inverts_the_distortion_model():
     assert np.max(np.abs(un - xn)) < 2e-3     # 5 fixed-point iterations (cv::undistortPoints), float32 pixels
 
 
+def test_fisheye_undistort_inverts_the_equidistant_model():
+    """Camera.Fisheye: 1 -> cv::fisheye::undistortPoints with D = (k1, k2, p1, p2) (Tracker.cc:116-119): project rays through
+    theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8) and undistort the pixels again"""
+    cfg = abi.config_named("B", fisheye=1, k1=-0.0137, k2=0.0207, p1=-0.0128, p2=0.0025)
+    rng = np.random.default_rng(3)
+    xn = rng.uniform(-0.9, 0.9, (200, 2))
+    r = np.linalg.norm(xn, axis=1)
+    th = np.arctan(r)
+    k = [float(cfg.k1), float(cfg.k2), float(cfg.p1), float(cfg.p2)]
+    thd = th * (1 + k[0] * th ** 2 + k[1] * th ** 4 + k[2] * th ** 6 + k[3] * th ** 8)
+    xd = xn * (thd / r)[:, None]
+    px = np.stack([float(cfg.fx) * xd[:, 0] + float(cfg.cx), float(cfg.fy) * xd[:, 1] + float(cfg.cy)], 1).astype(np.float32)
+    un = O.undistort(cfg, px)
+    assert np.max(np.abs(un - xn)) < 5e-5      # float32 pixels in, ten fixed-point iterations
+    assert np.array_equal(O.undistort(cfg, np.float32([[cfg.cx, cfg.cy]])), np.zeros((1, 2), np.float32))   # theta_d <= 1e-8: scale 1
+
+
 def test_pyr_down_and_scharr_against_numpy():
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
