@@ -59,7 +59,9 @@ struct rvio_hip {
     rvio_imu* d_imu = nullptr;
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
-    DetDev det = {};                              // device detector (T7), allocated on first use
+    DetDev det = {}, det_b = {};                  // device detector (T7), allocated on first use: two sets of scratch — in run-ahead mode the
+                                                  // detectors of consecutive frames run on two streams, by frame parity
+    int det_set_last = 0;                         // the set the last call used (rvio_hip_get_corners)
     bool det_ready = false, use_det = false;
     hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
     hipStream_t stream_c = nullptr;               // CLAHE stream of the run-ahead mode (frame k+1 is equalised while frame k is still being detected)
@@ -73,9 +75,9 @@ struct rvio_hip {
     // asynchronously from pinned memory.  Slot s may be refilled once evPin[s] (recorded behind its copies) has completed.
     static const int kPin = 3;
     uint8_t* pin[kPin] = {nullptr, nullptr, nullptr};
-    hipEvent_t evPin[kPin] = {nullptr, nullptr, nullptr};
+    hipEvent_t evPin[kPin] = {nullptr, nullptr, nullptr}, evPin2[kPin] = {nullptr, nullptr, nullptr};
     size_t pin_img = 0, pin_imu = 0, pin_bytes = 0;
-    uint8_t *d_eq = nullptr, *d_lut = nullptr;   // CLAHE output image and tile LUTs (enable_equalizer)
+    uint8_t *d_eq = nullptr, *d_lut2[2] = {nullptr, nullptr};   // CLAHE output image and tile LUTs (enable_equalizer), the LUTs by frame parity
     // Buffers the front end of frame k+1 would otherwise overwrite while book-keeping of frame k still reads them (run-ahead of the
     // image chain on the pipelined path, see track_dev_impl): equalised image, detector corner list and its count, by frame parity
     uint8_t* d_eq2[2] = {nullptr, nullptr};
@@ -261,7 +263,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     if (h->cfg.enable_equalizer) {
         DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H);
         h->d_eq = h->d_eq2[0];
-        DALLOC(h, h->d_lut, (size_t)h->cl_tx * h->cl_ty * 256);
+        DALLOC(h, h->d_lut2[0], (size_t)h->cl_tx * h->cl_ty * 256); DALLOC(h, h->d_lut2[1], (size_t)h->cl_tx * h->cl_ty * 256);
     }
     DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
     DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
@@ -448,7 +450,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) hipFree(p);
-    for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); }
+    for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); if (h->evPin2[k]) hipEventDestroy(h->evPin2[k]); }
     if (h->first_mirror) hipHostFree(h->first_mirror);
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
@@ -772,9 +774,8 @@ static int detector_check(rvio_hip* h) {
     if ((int)std::floor(.5 * h->cfg.min_dist) != SP_WIN) { h->err = "device cornerSubPix is built for floor(nMinDist/2) == 7"; return RVIO_ERR_UNSUPPORTED; }
     return RVIO_OK;
 }
-static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a slab)
+static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE detector in flight
     const DevCfg& d = h->dc;
-    DetDev& q = h->det;
     const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist), cell2 = (int)std::nearbyint((double)(2.f * h->cfg.min_dist));
     const size_t npx = (size_t)d.W * d.H;
     q.W = d.W; q.H = d.H; q.F = d.F; q.min_dist = h->cfg.min_dist; q.quality = (double)h->cfg.qual_lvl;
@@ -785,12 +786,19 @@ static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a sla
     q.n_cap = (int)std::min(npx, (size_t)16384);
     DALLOC(h, q.nb, (size_t)q.n_cap * DET_NBCAP); DALLOC(h, q.nb_cnt, (size_t)q.n_cap);
     DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
-    DALLOC(h, q.raw_xy, (size_t)2 * d.F); DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F);
+    DALLOC(h, q.raw_xy, (size_t)2 * d.F);
+    return RVIO_OK;
+}
+static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a slab)
+    const DevCfg& d = h->dc;
+    int rc = detector_alloc_set(h, h->det);
+    if (rc != RVIO_OK) return rc;
+    if ((rc = detector_alloc_set(h, h->det_b)) != RVIO_OK) return rc;
+    DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F);
     DALLOC(h, h->det_nout, 2);
-    q.xy = h->det_xy2[0]; q.n_out = h->det_nout;
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)SP_WW * SP_WW);
-    q.spmask = mask;
+    for (DetDev* q : {&h->det, &h->det_b}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; }
     return RVIO_OK;
 }
 static int detector_init(rvio_hip* h) {
@@ -808,8 +816,9 @@ static int detector_init(rvio_hip* h) {
     }
     HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm, sizeof hm, hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
     std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
-    HIPCHK(h, hipMemcpy2DAsync(q.maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
-                               hipMemcpyHostToDevice, h->stream));
+    for (DetDev* qq : {&h->det, &h->det_b})
+        HIPCHK(h, hipMemcpy2DAsync(qq->maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
+                                   hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
     HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
@@ -824,31 +833,37 @@ static int detector_init(rvio_hip* h) {
 //    except mbIsTheFirstImage (the detector's distance factor), hence one wait on book-keeping(k-1) in front of nms(k).  What
 //    book-keeping(k) still reads while frame k+1 is being detected is double-buffered by frame parity (equalised image, corner list).
 static DetDev det_view(const rvio_hip* h) {
-    DetDev q = h->det;
+    DetDev q = (h->runahead && h->par) ? h->det_b : h->det;
     q.xy = h->det_xy2[h->par]; q.n_out = h->det_nout + h->par;
     return q;
 }
+// the stream CLAHE and the detector of the call in progress run on: in run-ahead mode the image chains of consecutive frames
+// alternate between two streams (each with its own detector scratch and CLAHE LUTs), so that two of them are in flight — the chain is
+// ~150 us long, the longest of the frame, and with one stream it WAS the frame period
+static hipStream_t image_stream(const rvio_hip* h) { return h->runahead ? (h->par ? h->stream_c : h->stream_t) : h->ts; }
 static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs, hipEvent_t first_flag_ready) {
     const DevCfg& d = h->dc;
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
     const DetDev q = det_view(h);
+    const hipStream_t ds = image_stream(h);
+    h->det_set_last = (h->runahead && h->par) ? 1 : 0;
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
     if (h->wide_px)
-        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, h->ts, img, stride, q, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, h->ts, img, stride, q, src_bs, bs);
-    if (first_flag_ready) HIPCHK(h, hipStreamWaitEvent(h->ts, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
+    if (first_flag_ready) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
     if (h->wide_px && d.W % 4 == 0)
-        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, h->ts, q, bs);
+        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
     else
-        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, h->ts, q, bs);
-    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, h->ts, q, bs);
-    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, h->ts, q, bs);
+        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
+    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
+    hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
     if (h->wide_px)
-        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, h->ts, img, stride, q, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, h->ts, img, stride, q, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -865,20 +880,20 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         uint8_t* eq = h->d_eq2[h->par];
         // run-ahead: CLAHE has its own stream, so frame k+1 is equalised while frame k is still being detected.  d_eq2[par] is free
         // once book-keeping(k-2) is done: the pyramid (same stream, earlier) and cornerSubPix (it waited for it) of frame k-2 were its last readers
-        hipStream_t cs = h->runahead ? h->stream_c : h->ts;
+        hipStream_t cs = image_stream(h);
+        uint8_t* lut = h->d_lut2[h->par];
         if (h->runahead && h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
-                           h->cl_clip, h->cl_scale, h->d_lut, src_bs, bs);
+                           h->cl_clip, h->cl_scale, lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
             hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, lut, eq, src_bs, bs);
         else
             hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
-                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, h->d_lut, eq, src_bs, bs);
+                               1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, lut, eq, src_bs, bs);
         d_img = eq; stride = d.W; src_bs = bs;
-        if (h->runahead) {   // both consumers of the equalised image wait for it
+        if (h->runahead) {   // the side stream (pyramid) waits for the equalised image; the detector follows on the image stream itself
             HIPCHK(h, hipEventRecord(h->evC[h->par], cs));
-            HIPCHK(h, hipStreamWaitEvent(h->ts, h->evC[h->par], 0));
             HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->par], 0));
             forked = true;
         }
@@ -887,7 +902,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     if (h->use_det) {   // FeatureDetector::DetectWithSubPix on the image the tracker sees (Tracker.cc:207,350)
         // fork: pyramid / KLT / RANSAC go to the side stream (the image is complete on ts here), the detector stays on ts
         if (!forked) {
-            HIPCHK(h, hipEventRecord(h->evD0, h->ts));
+            HIPCHK(h, hipEventRecord(h->evD0, image_stream(h)));
             HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evD0, 0));
         }
         h->side = h->stream_d;
@@ -902,7 +917,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         const hipEvent_t flag = (h->runahead && h->frame_no >= 1 && !h->first_cleared) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
         const int rc = detect_dev(h, d_img, stride, src_bs, flag);
         if (rc != RVIO_OK) return rc;
-        if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, h->ts));   // corners of frame k ready (book-keeping on the side stream waits for it)
+        if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));   // corners of frame k ready (book-keeping on the side stream waits for it)
     }
     // the whole pyramid in one launch (pyrDown chain + the copy of the frame into level 0); one workgroup per 8x8 tile of level 3
     {
@@ -1103,8 +1118,12 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     if (h->in_frame) { h->err = "rvio_hip_frame_begin_dev without rvio_hip_frame_end"; return RVIO_ERR_INVALID; }
     const int b = (int)(h->frame_no & 1);
     h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
-    if (h->frame_no >= 2) {   // the filter of frame k-2 has consumed this hand-over buffer (book-keeping may run on either front-end stream)
-        HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
+    static const bool no_ra = getenv("RVIO_NO_RUNAHEAD") != nullptr;
+    const bool ra = !d_cand && !h->one_stream && !no_ra;   // run-ahead mode (track_dev_impl): book-keeping runs on the side stream
+    if (h->frame_no >= 2) {   // the filter of frame k-2 has consumed this hand-over buffer: only the stream that runs book-keeping has to know.
+        // (In run-ahead mode the image chains — CLAHE, detector — never touch the hand-over: making them wait here tied image(k) to
+        // filter(k-2) and with it the frame period to image chain + filter chain over two frames.)
+        if (!ra) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
         HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evF[b], 0));
     } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
@@ -1113,7 +1132,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     static double acc[5] = {0, 0, 0, 0, 0}; static long nacc = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg_host ? now() : 0;
-    if (staged) {   // the IMU batch was copied on the tracker stream: propagate (filter stream) and RANSAC (side stream) need it
+    if (staged) {   // the IMU batch was copied on the tracker stream (run-ahead: the side stream): propagate (filter stream) and RANSAC need it
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->evIn[b], 0));
         HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evIn[b], 0));
     }
@@ -1208,6 +1227,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         for (int k = 0; k < rvio_hip::kPin; ++k) {
             HIPCHK(h, hipHostMalloc((void**)&h->pin[k], h->pin_bytes, hipHostMallocDefault));
             HIPCHK(h, hipEventCreateWithFlags(&h->evPin[k], kEvFlags));
+            HIPCHK(h, hipEventCreateWithFlags(&h->evPin2[k], kEvFlags));
         }
     }
     const int b = (int)(h->frame_no & 1);
@@ -1215,20 +1235,36 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     uint8_t* pp = h->pin[ps];
     const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
     HIPCHK(h, hipEventSynchronize(h->evPin[ps]));   // the copies issued from this slot three frames ago are done (no-op before its first use)
+    HIPCHK(h, hipEventSynchronize(h->evPin2[ps]));
     for (int y = 0; y < h->dc.H; ++y) std::memcpy(pp + (size_t)y * h->dc.W, img + (size_t)y * stride, (size_t)h->dc.W);
     if (m > 0) std::memcpy(pp + h->pin_imu, imu, sizeof(rvio_imu) * m);
     if (nc > 0) std::memcpy(pp + pin_cand, cand_xy, sizeof(float) * 2 * nc);
-    if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
-    else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
-    HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
-    // the image goes where its first consumer runs: the CLAHE stream in run-ahead mode (device detector + equaliser), else the tracker stream
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;
-    hipStream_t is = (!cand_xy && h->cfg.enable_equalizer && !h->one_stream && !no_runahead) ? h->stream_c : h->stream_t;
-    if (is != h->stream_t) HIPCHK(h, hipStreamWaitEvent(is, h->evIn[b], 0));   // (so that evPin below also covers the IMU copy)
-    HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
-    if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], pp + pin_cand, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
-    HIPCHK(h, hipEventRecord(h->evPin[ps], is));
+    const bool ra = !cand_xy && !h->one_stream && !no_runahead;
+    if (ra) {
+        // run-ahead mode.  The IMU batch goes to the SIDE stream (RANSAC runs there; propagate on the filter stream waits for evIn): it
+        // has to wait for the filter of frame k-2 (the last reader of hb_imu[b]), and that wait must not sit in front of an image chain.
+        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evF[b], 0));
+        else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_d));
+        HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_d));
+        HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_d));
+        // The image goes to the stream of this frame's image chain (image_stream: tracker stream / fourth stream by parity).  hb_img[b]
+        // was last read by frame k-2: its CLAHE / detector (same stream, earlier) and — without the equaliser — its pyramid on the side
+        // stream, which book-keeping(k-2) followed.
+        hipStream_t is = b ? h->stream_c : h->stream_t;
+        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(is, h->evT[b], 0));
+        HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
+        HIPCHK(h, hipEventRecord(h->evPin2[ps], is));
+    } else {
+        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
+        else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
+        HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
+        HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, h->stream_t));
+        if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], pp + pin_cand, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
+        HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_t));
+    }
     return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
@@ -1280,8 +1316,9 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->par, sizeof cnt, hipMemcpyDeviceToHost));
     if (n) *n = cnt;
     if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->par], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
-    if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, h->det.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
-    if (eig) HIPCHK(h, hipMemcpy(eig, h->det.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
+    const DetDev& ds_ = h->det_set_last ? h->det_b : h->det;
+    if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
+    if (eig) HIPCHK(h, hipMemcpy(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
     return RVIO_OK;
 }
 // pyramid level `level` of the most recent image: u8 image (w*h) and int16 (dx,dy) derivative (w*h*2)
