@@ -338,36 +338,39 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
             lat["augment_compose"].append(evs[3].elapsed_time(evs[4]))
         if i == ncpu - 1:
             x_at, _ = h.get_state()
-    res = {"latency_ms_p50": {k: float(np.median(v)) for k, v in lat.items() if v},
+    p50 = {k: float(np.median(v)) for k, v in lat.items() if v}
+    res = {"latency_ms_p50": p50, "frame_latency_ms_unpipelined": float(sum(p50.values())),
            "latency_ms_p95": {k: float(np.percentile(v, 95)) for k, v in lat.items() if v},
            "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
            "x_at_cpu_frames": x_at, "x_final": h.get_state()[0]}
     # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree)
-    # Dominant kernel by device time: the solve kernel (in-place Gauss-Jordan of T = s2 I + A Pcc, c6 = 6n columns).
-    # Algorithmic FP64 work per launch = c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8).
+    # Dominant kernel by device time: the solve kernel — T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T
+    # (c6 = 6n columns, register tableau).  Algorithmic FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1)
+    # columns x 2 flops (the 2r^3 term of U8).
     n = cfg.max_track_len - 1
     c6 = 6 * n
     F = cfg.n_features
     t_solve = h.time_kernel(0, 20) * 1e-6
     t_klt = h.time_kernel(1, 20) * 1e-6
     t_feat = h.time_kernel(2, 20) * 1e-6
-    fl_solve = 2.0 * c6 * c6 * (c6 + 1)
+    fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
     PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read live, so this is the committed
-    # rocprofv3 --pmc result (profiles/r01_e_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
+    # rocprofv3 --pmc result (profiles/r02_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")) as fh:
-            e = [v for k, v in json.load(fh).items() if k.startswith("solve6_kernel")][0]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            e = [v for k, v in json.load(fh).items() if "solve7_kernel" in k][0]
         traffic = 1024.0 * (e["fetch_kb_mean"] + e["write_kb_mean"])
     except (OSError, IndexError, KeyError, ValueError):
         pass
-    res["roofline"] = {"bound": "mfma", "kernel": "solve6_kernel (W = (s2 I + A Pcc)^-1, one workgroup)",
+    res["roofline"] = {"bound": "mfma", "kernel": "solve7_kernel (T = s2 I + A Pcc, W = T^-1, dx, state injection; one workgroup)",
                        "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
-                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r01_e_pmc_traffic.md)",
+                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r02_pmc_traffic.md)",
                        "avg_us": t_solve * 1e6,
-                       "note": "latency bound: a %dx%d FP64 elimination on ONE CU with one barrier per column; a single 752x480 stream "
-                               "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction" % (c6, c6 + 1)}
+                       "note": "latency bound: a %dx%d FP64 elimination is a chain of %d dependent pivot decisions on ONE CU; a single 752x480 stream "
+                               "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction; update_at_load.roofline "
+                               "prices the whole update at full load, batched_filter the same kernels with the chip full" % (c6, c6 + 1, c6)}
     it_l = 10
     by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10
     res["roofline_other"] = [

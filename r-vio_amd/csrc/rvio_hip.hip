@@ -80,7 +80,8 @@ struct rvio_hip {
     uint8_t *d_eq = nullptr, *d_lut2[2] = {nullptr, nullptr};   // CLAHE output image and tile LUTs (enable_equalizer), the LUTs by frame parity
     // Buffers the front end of frame k+1 would otherwise overwrite while book-keeping of frame k still reads them (run-ahead of the
     // image chain on the pipelined path, see track_dev_impl): equalised image, detector corner list and its count, by frame parity
-    uint8_t* d_eq2[2] = {nullptr, nullptr};
+    uint8_t* d_eq2[3] = {nullptr, nullptr, nullptr};   // three, in rotation: the equalised image IS level 0 of its pyramid, which the KLT of the NEXT frame still reads
+    int eq_slot = 0;
     float* det_xy2[2] = {nullptr, nullptr};
     int* det_nout = nullptr;
     int par = 0;                                  // parity of the call in progress / of the last call (getters)
@@ -261,7 +262,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, h->d_cand, (size_t)2 * d.F);
     DALLOC(h, h->d_img, (size_t)d.W * d.H);
     if (h->cfg.enable_equalizer) {
-        DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H);
+        DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[2], (size_t)d.W * d.H);
         h->d_eq = h->d_eq2[0];
         DALLOC(h, h->d_lut2[0], (size_t)h->cl_tx * h->cl_ty * 256); DALLOC(h, h->d_lut2[1], (size_t)h->cl_tx * h->cl_ty * 256);
     }
@@ -877,9 +878,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     size_t src_bs = h->img_bs;       // the caller's images: instance stride of the call in progress
     bool forked = false;
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
-        uint8_t* eq = h->d_eq2[h->par];
-        // run-ahead: CLAHE has its own stream, so frame k+1 is equalised while frame k is still being detected.  d_eq2[par] is free
-        // once book-keeping(k-2) is done: the pyramid (same stream, earlier) and cornerSubPix (it waited for it) of frame k-2 were its last readers
+        // The equalised image of frame k doubles as level 0 of frame k's pyramid (no copy), so it lives until the KLT of frame k+1 has
+        // matched against it: three buffers in rotation.  Slot k % 3 was last read by KLT(k-2) (as the previous image) and by the
+        // detector / pyramid of frame k-3; in run-ahead mode CLAHE(k) waits for book-keeping(k-2), which followed KLT(k-2) on the side stream
+        h->eq_slot = (h->eq_slot + 1) % 3;
+        uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->par];
         if (h->runahead && h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
@@ -922,7 +925,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     // the whole pyramid in one launch (pyrDown chain + the copy of the frame into level 0); one workgroup per 8x8 tile of level 3
     {
         const int w3 = (((d.W + 1) / 2 + 1) / 2 + 1) / 2, h3 = (((d.H + 1) / 2 + 1) / 2 + 1) / 2;
-        hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, h->side, d_img, stride, p, d.levels, 1, src_bs, bs);
+        PyrDev pv = p;
+        const bool own = h->cfg.enable_equalizer != 0;   // d_img is the handle's equalised image: level 0 without a copy
+        if (own) { h->pyr[b].img[0] = d_img; pv.img[0] = d_img; }
+        hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, h->side, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
     }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
