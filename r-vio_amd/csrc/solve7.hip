@@ -2,10 +2,11 @@
 //
 // One launch replaces gemm_T_kernel + solve6_kernel.  The in-place Gauss-Jordan inversion (partial pivoting, no row swaps,
 // deferred pivot scaling: the algebra of solve4.hip) runs with the tableau in REGISTERS instead of LDS:
-//   * lane <-> row (RPL rows per lane: i = lane + 64 r), wave <-> every NW-th column (column j lives in wave j % NW, register
-//     j / NW); every wave also carries the right-hand side b as one more column, so nobody owns it;
-//   * DATAFLOW instead of barriers: the wave that owns column k+1 eliminates that column first in step k, picks the next pivot and
-//     publishes (pivot row, its reciprocal, the multipliers f_i of every row) into an LDS ring slot, then raises the slot's flag;
+//   * lane <-> row (RPL rows per lane: i = lane + 64 r), wave <-> every NW-th PAIR of columns (columns 2q, 2q+1 live in wave q % NW,
+//     registers 2 (q / NW), + 1); every wave also carries the right-hand side b as one more column, so nobody owns it;
+//   * DATAFLOW instead of barriers: the wave that owns the next pair of columns brings those two up to date first, takes BOTH pivots
+//     (the first one's elimination reaches the second column inside the wave) and publishes (pivot rows, their reciprocals, the
+//     multipliers f_i of every row, twice) into an LDS ring slot, then raises the slot's flag;
 //     every wave consumes the steps in order at its own pace (acquire-load of the flag, one LDS read), so the chain of pivot
 //     decisions is never held up by the other waves' 16 column updates — they run beside it.  With cyclic ownership a wave is the
 //     publisher every NW-th step only and has caught up by then;
@@ -39,13 +40,14 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
                                                          double* __restrict__ Wout, double* __restrict__ x_out, size_t bs) {
     meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Tscr = zoff(Tscr, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
     static_assert(RPL >= 1 && RPL <= 3, "rows per lane");
+    static_assert(CPW % 2 == 0, "a wave owns pairs of columns");
     static_assert(S7_RING >= NW + 2 && (S7_RING & (S7_RING - 1)) == 0, "ring depth");
     constexpr int NT = 64 * NW, NR = 64 * RPL;
     constexpr bool STAGE = (RPL == 1);                  // 6n <= 64: T through LDS
     constexpr int LS = 65;                              // LDS row stride of the staged 64 x 64 operands
     extern __shared__ __align__(16) double s7_dyn[];    // STAGE: As | Ps | Ts (3 x 64 x LS) | Pt (24 x 64); As is reused for the dx partial sums
-    __shared__ double s_f[S7_RING][NR];
-    __shared__ int s_p[S7_RING], s_flag[S7_RING];
+    __shared__ double s_f[S7_RING][2][NR];
+    __shared__ int s_p[S7_RING][2], s_flag[S7_RING];
     __shared__ int s_prow[6 * RVIO_MAX_LEN], s_invp[NR];
     __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
     __shared__ double s_y[6 * RVIO_MAX_LEN];
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
     DBG_T(56);
     if (tid < S7_RING) s_flag[tid] = 0;
     const double s2 = cfg.sigma_im * cfg.sigma_im;
-    double m[RPL][CPW], mb[RPL];
+    double mcol[CPW][RPL], mbv[RPL];                    // the tableau: register column cc of this wave, this lane's RPL rows; the right-hand side
     // ---- T = s2 I + A Pcc on the matrix cores: A = Ab (row-major, ld = ldh), B = Pcc = P[24:,24:] (column-major, ld = dmax)
     if constexpr (STAGE) {
         double* As = s7_dyn; double* Ps = s7_dyn + 64 * LS; double* Ts = s7_dyn + 2 * 64 * LS; double* Pt = s7_dyn + 3 * 64 * LS;
@@ -111,10 +113,10 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         DBG_T(57);
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
-            const int j = cc * NW + wv;
-            m[0][cc] = (lane < c6 && j < c6) ? Ts[lane * LS + j] : 0.0;
+            const int j = 2 * ((cc >> 1) * NW + wv) + (cc & 1);
+            mcol[cc][0] = (lane < c6 && j < c6) ? Ts[lane * LS + j] : 0.0;
         }
-        mb[0] = (lane < c6) ? Ab[(size_t)lane * ldh + c6] : 0.0;
+        mbv[0] = (lane < c6) ? Ab[(size_t)lane * ldh + c6] : 0.0;
     } else {
         const int nt = (c6 + 15) / 16, li = lane & 15, lk = lane >> 4;
         for (int t = wv; t < nt * nt; t += NW) {
@@ -151,24 +153,28 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
             const int i = lane + 64 * r;
 #pragma unroll
             for (int cc = 0; cc < CPW; ++cc) {
-                const int j = cc * NW + wv;
-                m[r][cc] = (i < c6 && j < c6) ? __hip_atomic_load(Tscr + (size_t)i * ldh + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                const int j = 2 * ((cc >> 1) * NW + wv) + (cc & 1);
+                mcol[cc][r] = (i < c6 && j < c6) ? __hip_atomic_load(Tscr + (size_t)i * ldh + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             }
-            mb[r] = (i < c6) ? Ab[(size_t)i * ldh + c6] : 0.0;
+            mbv[r] = (i < c6) ? Ab[(size_t)i * ldh + c6] : 0.0;
         }
     }
     unsigned used = 0;                                  // bit r: row lane + 64 r has been a pivot row
     DBG_T(58);
 
-    // pivot of this wave's register column CC (= column kcol): arg-max over the unused rows, then every row's multiplier; published as step kcol
-    auto publish = [&](auto CCtag, int kcol) {
+    // ---- elimination, TWO columns per publication.  Column j lives in wave (j/2) % NW, register 2*((j/2)/NW) + (j&1): a wave owns
+    // pairs of adjacent columns, so the owner of pair s+1 can take both pivots of that pair back to back — first pivot, its elimination
+    // applied to the pair's second column inside the wave, second pivot — and hand both over with ONE LDS publication: half the
+    // cross-wave round trips on the serial chain of the inversion.
+    // search: arg-max of this wave's register column CC over the unused rows, its reciprocal, every row's multiplier
+    auto search = [&](auto CCtag, double (&fo)[RPL], int& p_o, double& ip_o, bool& sing) {
         constexpr int CC = decltype(CCtag)::value;
         unsigned key = 0;
         double rc[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const int i = lane + 64 * r;
-            const double cv = m[r][CC];
+            const double cv = mcol[CC][r];
             // reciprocal of the candidate: hardware estimate + two Newton steps (full double precision for normal numbers; the
             // IEEE division sequence is three times as long and sits on the serial chain of the elimination)
             double y0 = __builtin_amdgcn_rcp(cv);
@@ -181,89 +187,103 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, 0), b1 = (unsigned)__builtin_amdgcn_readlane((int)b, 16);
         const unsigned b2 = (unsigned)__builtin_amdgcn_readlane((int)b, 32), b3 = (unsigned)__builtin_amdgcn_readlane((int)b, 48);
         const unsigned best = s7_max(s7_max(b0, b1), s7_max(b2, b3));
-        if (kcol == 32) DBG_T(54);
-        const int pi = (best >> 8) ? 255 - (int)(best & 255u) : 0;   // all-zero column: flagged below, keep the indices sane
+        sing = (best >> 8) == 0;
+        const int pi = sing ? 0 : 255 - (int)(best & 255u);          // all-zero column: flagged by the caller, keep the indices sane
         const int lp = pi & 63, rp = pi >> 6;
         double ipiv = readlane_f64(rc[0], lp);
         if (RPL > 1 && rp == 1) ipiv = readlane_f64(rc[RPL > 1 ? 1 : 0], lp);
         if (RPL > 2 && rp == 2) ipiv = readlane_f64(rc[RPL > 2 ? 2 : 0], lp);
-        const int slot = kcol & (S7_RING - 1);
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-            const int i = lane + 64 * r;
-            s_f[slot][i] = (i == pi) ? 0.0 : m[r][CC] * ipiv;
+        for (int r = 0; r < RPL; ++r) fo[r] = (lane + 64 * r == pi) ? 0.0 : mcol[CC][r] * ipiv;
+        p_o = pi; ip_o = ipiv;
+    };
+    // one elimination step on register column CC (or the right-hand side): m -= f * (pivot row's entry)
+    auto elim_v = [&](double (&col)[RPL], const double (&fr)[RPL], int p) {
+        const int lp = p & 63, rp = p >> 6;
+        double pr = readlane_f64(col[0], lp);
+        if (RPL > 1 && rp == 1) pr = readlane_f64(col[RPL > 1 ? 1 : 0], lp);
+        if (RPL > 2 && rp == 2) pr = readlane_f64(col[RPL > 2 ? 2 : 0], lp);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) col[r] -= fr[r] * pr;
+    };
+    // both pivots of the pair held in registers (C0, C0 + 1) = columns (2 sp, 2 sp + 1), published as pair sp
+    auto publish_pair = [&](auto C0tag, int sp) {
+        constexpr int C0 = decltype(C0tag)::value;
+        double fa[RPL], fb[RPL];
+        int pa, pb; double ipa, ipb; bool sa, sb;
+        search(std::integral_constant<int, C0>{}, fa, pa, ipa, sa);
+        if (lane == (pa & 63)) used |= 1u << (pa >> 6);
+        elim_v(mcol[C0 + 1], fa, pa);
+        search(std::integral_constant<int, C0 + 1>{}, fb, pb, ipb, sb);
+        const int slot = sp & (S7_RING - 1);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { s_f[slot][0][lane + 64 * r] = fa[r]; s_f[slot][1][lane + 64 * r] = fb[r]; }
+        if (lane == 0) {
+            s_p[slot][0] = pa; s_p[slot][1] = pb;
+            s_prow[2 * sp] = pa; s_prow[2 * sp + 1] = pb; s_invp[pa] = 2 * sp; s_invp[pb] = 2 * sp + 1; s_ipiv[2 * sp] = ipa; s_ipiv[2 * sp + 1] = ipb;
+            if (sa || sb) meta->err |= 1;
         }
-        if (lane == 0) { s_p[slot] = pi; s_prow[kcol] = pi; s_invp[pi] = kcol; s_ipiv[kcol] = ipiv; if ((best >> 8) == 0) meta->err |= 1; }
-        if (kcol == 32) DBG_T(55);
         // LDS operations of one wave complete in order: the flag becomes visible after the data
-        __hip_atomic_store(&s_flag[slot], kcol + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kcol == 32) DBG_T(63);
+        __hip_atomic_store(&s_flag[slot], sp + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     __syncthreads();                                    // flags cleared, tableau loaded
-    if (wv == 0) publish(std::integral_constant<int, 0>{}, 0);
+    if (wv == 0) publish_pair(std::integral_constant<int, 0>{}, 0);
     DBG_T(59);
 
-    // ---- elimination, step k = cc*NW + w: column k is register cc of wave w.  No barrier: every wave follows the flags.
+    // pair sp = (C/2)*NW + w: registers (C, C+1) of wave w.  No barrier: every wave follows the flags.
+    const int npair = c6 / 2;
     bool done = false;
-    s7_for<0, CPW>([&](auto Ctag) {
-        constexpr int C = decltype(Ctag)::value;
+    s7_for<0, CPW / 2>([&](auto Htag) {
+        constexpr int C = 2 * decltype(Htag)::value;
         for (int w = 0; w < NW && !done; ++w) {
-            const int k = C * NW + w;
-            if (k >= c6) { done = true; break; }
-            if (k == 30) DBG_T(50);
-            if (k == 31) DBG_T(52);
-            const int slot = k & (S7_RING - 1);
-            // flag, pivot row and multipliers are read together; the data is valid if the flag (written last by the publisher) matches
-            int p;
-            double fr[RPL];
+            const int sp = (C / 2) * NW + w;
+            if (sp >= npair) { done = true; break; }
+            if (sp == 15) DBG_T(50);
+            if (sp == 16) DBG_T(52);
+            const int slot = sp & (S7_RING - 1);
+            // flag, pivot rows and multipliers are read together; the data is valid if the flag (written last by the publisher) matches
+            int pa, pb;
+            double fa[RPL], fb[RPL];
             for (;;) {
                 const int fl = __hip_atomic_load(&s_flag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int pp = *(volatile int*)&s_p[slot];
+                const int qa = *(volatile int*)&s_p[slot][0], qb = *(volatile int*)&s_p[slot][1];
 #pragma unroll
-                for (int r = 0; r < RPL; ++r) fr[r] = *(volatile double*)&s_f[slot][lane + 64 * r];
-                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the three reads were issued in this order and complete in order
-                if (__builtin_amdgcn_readfirstlane(fl) == k + 1) { p = __builtin_amdgcn_readfirstlane(pp); break; }
+                for (int r = 0; r < RPL; ++r) { fa[r] = *(volatile double*)&s_f[slot][0][lane + 64 * r]; fb[r] = *(volatile double*)&s_f[slot][1][lane + 64 * r]; }
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the reads were issued in this order and complete in order
+                if (__builtin_amdgcn_readfirstlane(fl) == sp + 1) { pa = __builtin_amdgcn_readfirstlane(qa); pb = __builtin_amdgcn_readfirstlane(qb); break; }
+                if (NW > 4) __builtin_amdgcn_s_sleep(2);   // more than one wave per SIMD: a spinning wave must not take the issue slots of the publisher
             }
-            if (k == 31) DBG_T(53);
-            const int lp = p & 63, rp = p >> 6;
-            if (lane == lp) used |= 1u << rp;
-            auto elim = [&](auto CCtag) {
-                constexpr int CC = decltype(CCtag)::value;
-                double pr = readlane_f64(m[0][CC], lp);
-                if (RPL > 1 && rp == 1) pr = readlane_f64(m[RPL > 1 ? 1 : 0][CC], lp);
-                if (RPL > 2 && rp == 2) pr = readlane_f64(m[RPL > 2 ? 2 : 0][CC], lp);
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) m[r][CC] -= fr[r] * pr;
-            };
-            // column k+1 lives in wave (w+1) % NW, register C (or C+1 when the ownership wraps): that wave brings it up to date first
-            // and publishes the next pivot before it touches its other columns
-            const bool own_next = (k + 1 < c6) && (wv == ((w + 1 < NW) ? w + 1 : 0));
-            const bool next_same = (w + 1 < NW);                       // register C, else register C+1
+            if (lane == (pa & 63)) used |= 1u << (pa >> 6);
+            if (lane == (pb & 63)) used |= 1u << (pb >> 6);
+            auto both = [&](double (&col)[RPL]) { elim_v(col, fa, pa); elim_v(col, fb, pb); };
+            // the next pair lives in wave (w+1) % NW, registers (C, C+1) — or (C+2, C+3) when the ownership wraps: that wave brings
+            // those two columns up to date first and publishes the next two pivots before it touches its other columns
+            const bool own_next = (sp + 1 < npair) && (wv == ((w + 1 < NW) ? w + 1 : 0));
+            const bool next_same = (w + 1 < NW);
             if (own_next) {
-                if (next_same) { elim(std::integral_constant<int, C>{}); publish(std::integral_constant<int, C>{}, k + 1); }
-                else if constexpr (C + 1 < CPW) { elim(std::integral_constant<int, C + 1>{}); publish(std::integral_constant<int, C + 1>{}, k + 1); }
+                if (next_same) { both(mcol[C]); both(mcol[C + 1]); publish_pair(std::integral_constant<int, C>{}, sp + 1); }
+                else if constexpr (C + 3 < CPW) { both(mcol[C + 2]); both(mcol[C + 3]); publish_pair(std::integral_constant<int, C + 2>{}, sp + 1); }
             }
-            // every other column, straight-line (columns beyond 6n hold zeros and stay zero; column k itself is rewritten below)
+            const bool own = (wv == w);
             s7_for<0, CPW>([&](auto Itag) {
                 constexpr int I = decltype(Itag)::value;
-                if constexpr (I == C) { if (!(own_next && next_same)) elim(Itag); }
-                else if constexpr (I == C + 1) { if (!(own_next && !next_same)) elim(Itag); }
-                else elim(Itag);
+                if constexpr (I == C) {
+                    if (own) {   // column 2 sp itself: -f_a (1 in its pivot row, the stored form of 1/piv), then an ordinary column of step b
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) mcol[I][r] = (lane + 64 * r == pa) ? 1.0 : -fa[r];
+                        elim_v(mcol[I], fb, pb);
+                    } else if (!(own_next && next_same)) both(mcol[I]);
+                } else if constexpr (I == C + 1) {
+                    if (own) {   // column 2 sp + 1 (step a reached it when the pair was published): -f_b, 1 in its pivot row
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) mcol[I][r] = (lane + 64 * r == pb) ? 1.0 : -fb[r];
+                    } else if (!(own_next && next_same)) both(mcol[I]);
+                } else if constexpr (I == C + 2 || I == C + 3) {
+                    if (!(own_next && !next_same)) both(mcol[I]);
+                } else both(mcol[I]);
             });
-            {   // the right-hand side
-                double pr = readlane_f64(mb[0], lp);
-                if (RPL > 1 && rp == 1) pr = readlane_f64(mb[RPL > 1 ? 1 : 0], lp);
-                if (RPL > 2 && rp == 2) pr = readlane_f64(mb[RPL > 2 ? 2 : 0], lp);
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) mb[r] -= fr[r] * pr;
-            }
-            // column k itself (its owner): -f_i, and 1 in the pivot row (the stored form of 1/piv)
-            if (wv == w) {
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) m[r][C] = (lane + 64 * r == p) ? 1.0 : -fr[r];
-            }
-            if (k == 30) DBG_T(51);
-            if (k == 31) DBG_T(49);
+            both(mbv);
+            if (sp == 15) DBG_T(51);
         }
     });
     __syncthreads();
@@ -277,17 +297,17 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
             const double ip = s_ipiv[kk];
 #pragma unroll
             for (int cc = 0; cc < CPW; ++cc) {
-                const int j = cc * NW + wv;
-                if (j < c6) Wout[(size_t)kk * ldh + s_prow[j]] = m[r][cc] * ip;
+                const int j = 2 * ((cc >> 1) * NW + wv) + (cc & 1);
+                if (j < c6) Wout[(size_t)kk * ldh + s_prow[j]] = mcol[cc][r] * ip;
             }
-            if (wv == 0) s_y[kk] = mb[r] * ip;
+            if (wv == 0) s_y[kk] = mbv[r] * ip;
         }
     }
     __syncthreads();
     DBG_T(61);
     // dx = K r = Pc y   (Updater.cc:544): NT / d threads per row, each a contiguous share of the columns; partial sums added in a fixed order
     {
-        double* part = STAGE ? s7_dyn : s_f[0];         // (As is idle now; the ring is idle too: NR * S7_RING >= 4096 doubles)
+        double* part = STAGE ? s7_dyn : &s_f[0][0][0];         // (As is idle now; the ring is idle too: NR * S7_RING >= 4096 doubles)
         const int np = max(1, min(4, NT / d)), share = (c6 + np - 1) / np;
         const int pt = tid / d, i = tid - pt * d;
         if (pt < np) {
