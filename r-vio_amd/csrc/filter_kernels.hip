@@ -473,7 +473,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         const int nts = t1 - t0 + 1, nq = nts + ((tr > t1) ? 1 : 0);
         for (int tile = gw; tile < nts * nq; tile += nw) {
             const int pt = t0 + tile / nq, qi = tile % nq, qt = (qi < nts) ? t0 + qi : tr;
-            if (qt < pt) continue;
+            if (HOIST > 4 && qt < pt) continue;   // (batch handles store both triangles: their reduction then has no scattered mirror stores)
             const int p0 = pt * 16, q0 = qt * 16;
             const bool pok = p0 + gi < c6, qok = q0 + gi <= c6;
             d4 acc = {0, 0, 0, 0};
@@ -603,7 +603,6 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2', bits 16..19 / 20..23 the
     // first / last 16-column tile of the feature's range (feat_build_kernel stores a share's tiles inside that range only)
     __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
-    __shared__ int s_off[GRAM_MAX_FEATS];             // f * ldh^2: where the share of list entry t starts (doubles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -621,7 +620,6 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
             const int Lu = t2 ? (L + 1) / 2 : L, lo = t2 ? 0 : 6 * (n - (Lu - 1)), hi = lo + 6 * (Lu - 1);
             const int slot = off + __popcll(mask & ((1ull << lane) - 1ull));
             s_list[slot] = f | (t2 ? (1 << 30) : 0) | ((lo >> 4) << 16) | (((hi - 1) >> 4) << 20);
-            s_off[slot] = f * ldh * ldh;
         }
         __syncthreads();
         if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
@@ -664,27 +662,20 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     // elsewhere its buffer holds stale numbers, which are loaded (no branch) and discarded.  16 loads in flight per round.
     auto accumulate = [&](int e, int pt, int qt, int tb, int te, double& a2, double& a1) {
         const double* pe = partial + e;
-        int t = tb;
-        for (; t + 16 <= te; t += 16) {
+        for (int t = tb; t < te; t += 16) {
             double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = pe[s_off[t + u]];
+            for (int u = 0; u < 16; ++u) v[u] = (t + u < te) ? pe[(size_t)(s_list[t + u] & 0xffff) * gs] : 0.0;     // (uniform predicate: the loads go out back to back)
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int fl = s_list[t + u];
-                const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
-                const bool in = (unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq);
-                const double w = in ? v[u] : 0.0;
-                if (!split) a2 += w;
-                else { const bool is2 = (fl >> 30) & 1; a2 += is2 ? w : 0.0; a1 += is2 ? 0.0 : w; }
-            }
-        }
-        for (; t < te; ++t) {
-            const int fl = s_list[t];
-            const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
-            if ((unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq)) {
-                const double v = pe[s_off[t]];
-                if (!split || ((fl >> 30) & 1)) a2 += v; else a1 += v;
+                if (t + u < te) {
+                    const int fl = s_list[t + u];
+                    const unsigned lo = (fl >> 16) & 15, span = ((fl >> 20) & 15) - lo;
+                    const bool in = (unsigned)pt - lo <= span && ((unsigned)qt - lo <= span || qt == trq);
+                    const double w = in ? v[u] : 0.0;
+                    if (!split) a2 += w;
+                    else { const bool is2 = (fl >> 30) & 1; a2 += is2 ? w : 0.0; a1 += is2 ? 0.0 : w; }
+                }
             }
         }
     };
@@ -692,7 +683,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         if (direct) {
             const double v = a2 + a1;
             S2[e] = v;
-            if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
+            if (wide && qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
         } else { S2[e] = a2; S1[e] = a1; }
     };
     if (wide) {
@@ -718,7 +709,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         // batch handles: one thread per element, every share in list order (few accepted features per instance, many instances)
         for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
             const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
-            if (q > c6 || qt < pt) continue;
+            if (q > c6) continue;                           // (the shares of a batch handle hold both triangles: every element is summed where it lies)
             double a2 = 0, a1 = 0;
             accumulate(e, pt, qt, 0, ng, a2, a1);
             store(e, q, pq, pt, qt, a2, a1);
