@@ -600,6 +600,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
     DBG_T(41);
+    DBG_R(bi.x == 0, 1);
     // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2', bits 16..19 / 20..23 the
     // first / last 16-column tile of the feature's range (feat_build_kernel stores a share's tiles inside that range only)
     __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
@@ -806,6 +807,7 @@ __global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
     const int lds = c6t * 16 + 1;
+    DBG_R(bi.x == 0, 3);
     double* Us = sh; double* Gs = sh + 16 * lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int i0 = bi.x * 16;
@@ -923,6 +925,7 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
     const double s2 = cfg.sigma_im * cfg.sigma_im;
     const int nt = (d + 15) / 16, npair = nt * (nt + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    DBG_R(bi.x == 0, 4);
     const int pr = bi.x * 4 + wave;
     if (pr >= npair) return;
     int I = 0, rem = pr;
@@ -939,6 +942,176 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
     for (int r = 0; r < 4; ++r) {
         const int rr = lk + 4 * r, row = I * 16 + rr, col = J * 16 + li;
         const double v = .5 * (xij[r] + tl[wave][li][rr]);     // X_JI[col_local][row_local]
+        if (row < d && col < d) {
+            Pout[(size_t)row + (size_t)col * ld] = v;
+            if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+        }
+    }
+}
+
+// =============================================================== single instance, 6n <= 64: the same two stages with every operand staged in LDS
+// ug_kernel / final_kernel fetch their MFMA operands from global memory inside the k-loop: 16 dependent rounds of cold loads (the operands
+// were written by another CU a few microseconds earlier) per tile, 14 / 11 us per launch for 2-3 us of matrix-core work.  With one
+// instance per launch the operands of a workgroup fit its LDS: ONE batch of coalesced loads, then every tile from LDS.
+#define UGL_LS 65
+#define UGL_LDS_DOUBLES (2 * 64 * UGL_LS + 88 * UGL_LS + 2 * 16 * UGL_LS)
+// U = Pc W, G = U A, P1 = P - G Pc^T for one 16-row strip (grid: ceil(d / 16) workgroups); same arithmetic and outputs as ug_kernel
+__global__ __launch_bounds__(256) void ug_lds_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W, const double* __restrict__ Ab,
+                                                     double* __restrict__ U, double* __restrict__ G, double* __restrict__ P1) {
+    extern __shared__ __align__(16) double ul[];
+    constexpr int LS = UGL_LS;
+    double* const Wl = ul;                    // W[k][j], zero-padded to 64 x 64
+    double* const Al = Wl + 64 * LS;          // A[k][j]
+    double* const Pcl = Al + 64 * LS;         // Pc[r][k] = P[r][24 + k], r < d (<= 88), k < 64
+    double* const Us = Pcl + 88 * LS;         // 16 x LS
+    double* const Gs = Us + 16 * LS;
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int i0 = blockIdx.x * 16;
+    DBG_R(blockIdx.x == 0, 3);
+    {
+        double vw[16], va[16], vp[22];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * 256, k = e >> 6, j = e & 63;
+            const bool ok = k < c6 && j < c6;
+            vw[u] = ok ? W[(size_t)k * ldh + j] : 0.0;
+            va[u] = ok ? Ab[(size_t)k * ldh + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 22; ++u) {      // column-major source: consecutive threads walk down a column of P
+            const int e = tid + u * 256, k = e / 88, r = e - k * 88;
+            vp[u] = (k < c6 && r < d) ? P[(size_t)r + (size_t)(24 + k) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = tid + u * 256; Wl[(e >> 6) * LS + (e & 63)] = vw[u]; Al[(e >> 6) * LS + (e & 63)] = va[u]; }
+#pragma unroll
+        for (int u = 0; u < 22; ++u) { const int e = tid + u * 256, k = e / 88, r = e - k * 88; if (k < 64) Pcl[r * LS + k] = vp[u]; }
+    }
+    __syncthreads();
+    const int ntj = (c6 + 15) / 16, nti = (d + 15) / 16;
+    const int r = i0 + li;
+    // U strip
+    for (int jt = wave; jt < ntj; jt += 4) {
+        const int c = jt * 16 + li;
+        double av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; av[u] = (r < d) ? Pcl[r * LS + k] : 0.0; bv[u] = Wl[k * LS + c]; }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = lk + 4 * q;
+            Us[row * LS + c] = acc[q];
+            if (i0 + row < d && c < c6) U[(size_t)(i0 + row) * ldh + c] = acc[q];
+        }
+    }
+    __syncthreads();
+    // G strip
+    for (int jt = wave; jt < ntj; jt += 4) {
+        const int c = jt * 16 + li;
+        double av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; av[u] = (k < c6) ? Us[li * LS + k] : 0.0; bv[u] = Al[k * LS + c]; }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = lk + 4 * q;
+            Gs[row * LS + c] = acc[q];
+            if (i0 + row < d && c < c6) G[(size_t)(i0 + row) * ldh + c] = acc[q];
+        }
+    }
+    __syncthreads();
+    // P1 strip = P - G Pc^T
+    for (int jt = wave; jt < nti; jt += 4) {
+        const int c = jt * 16 + li;
+        double av[16], bv[16], p0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = i0 + lk + 4 * q; p0[q] = (row < d && c < d) ? P[(size_t)row + (size_t)c * ld] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; av[u] = (k < c6) ? Gs[li * LS + k] : 0.0; bv[u] = (c < d) ? Pcl[c * LS + k] : 0.0; }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = i0 + lk + 4 * q; if (row < d && c < d) P1[(size_t)row + (size_t)c * ld] = p0[q] - acc[q]; }
+    }
+}
+
+// Joseph form P+ = sym(P1 - P1c G^T + s2 G U^T): one wave per unordered tile pair, four pairs per workgroup; same arithmetic as final_kernel
+#define FNL_LDS_DOUBLES (3 * 88 * UGL_LS + 4 * 16 * 17)
+__global__ __launch_bounds__(256) void final_lds_kernel(DevCfg cfg, int n, const double* __restrict__ P1, const double* __restrict__ G, const double* __restrict__ U,
+                                                        double* __restrict__ Pout) {
+    extern __shared__ __align__(16) double fl[];
+    constexpr int LS = UGL_LS;
+    double* const P1c = fl;                   // P1[r][24 + k]
+    double* const Gl = P1c + 88 * LS;
+    double* const Ul = Gl + 88 * LS;
+    double (*const tl)[16][17] = reinterpret_cast<double (*)[16][17]>(Ul + 88 * LS);
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    DBG_R(blockIdx.x == 0, 4);
+    {
+        double vg[22], vu[22], vp[22];
+#pragma unroll
+        for (int u = 0; u < 22; ++u) {
+            const int e = tid + u * 256;
+            const int rr = e >> 6, k = e & 63;            // row-major sources (G, U)
+            const bool ok = rr < d && k < c6;
+            vg[u] = ok ? G[(size_t)rr * ldh + k] : 0.0;
+            vu[u] = ok ? U[(size_t)rr * ldh + k] : 0.0;
+            const int k2 = e / 88, r2 = e - k2 * 88;      // column-major source (P1)
+            vp[u] = (k2 < c6 && r2 < d) ? P1[(size_t)r2 + (size_t)(24 + k2) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 22; ++u) {
+            const int e = tid + u * 256;
+            const int rr = e >> 6, k = e & 63;
+            if (rr < 88) { Gl[rr * LS + k] = vg[u]; Ul[rr * LS + k] = vu[u]; }
+            const int k2 = e / 88, r2 = e - k2 * 88;
+            if (k2 < 64) P1c[r2 * LS + k2] = vp[u];
+        }
+    }
+    __syncthreads();
+    const int nt = (d + 15) / 16, npair = nt * (nt + 1) / 2;
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= npair) return;
+    int I = 0, rem = pr;
+    while (rem >= nt - I) { rem -= nt - I; ++I; }
+    const int J = I + rem;
+    auto xtile = [&](int i0, int j0) -> d4 {
+        const int r = i0 + li, c = j0 + li;
+        double a1[16], b1[16], p1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = i0 + lk + 4 * q; p1[q] = (row < d && c < d) ? P1[(size_t)row + (size_t)c * ld] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; a1[u] = (r < d) ? P1c[r * LS + k] : 0.0; b1[u] = (c < d) ? Gl[c * LS + k] : 0.0; }
+        d4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; a1[u] = (r < d) ? Gl[r * LS + k] : 0.0; b1[u] = (c < d) ? Ul[c * LS + k] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc2, 0, 0, 0);
+        d4 out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = p1[q] - acc[q] + s2 * acc2[q];
+        return out;
+    };
+    const d4 xij = xtile(I * 16, J * 16);
+    d4 xji = xij;
+    if (I != J) xji = xtile(J * 16, I * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tl[wave][lk + 4 * q][li] = xji[q];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = lk + 4 * q, row = I * 16 + rr, col = J * 16 + li;
+        const double v = .5 * (xij[q] + tl[wave][li][rr]);
         if (row < d && col < d) {
             Pout[(size_t)row + (size_t)col * ld] = v;
             if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
                                                         FilterMeta* meta, const rvio_imu* imu, int m) {
+    DBG_R(blockIdx.x == 0, 0);
     if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
     feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta);
 }
@@ -221,7 +222,9 @@ __device__ __forceinline__ int aug_src2(int a, int n, int nmax, int do_aug) {
     return (cb < nmax - 1) ? a + 6 : 9 + off;
 }
 __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do_aug, const double* __restrict__ x, const double* __restrict__ P,
-                                                       double* __restrict__ x_out, double* __restrict__ P_out, double* __restrict__ pose_out, size_t bs) {
+                                                       double* __restrict__ x_out, double* __restrict__ P_out, double* __restrict__ pose_out, size_t bs,
+                                                       unsigned long long* done) {
+    DBG_R(blockIdx.x == 0, 5);
     x = zoff(x, bs); P = zoff(P, bs); x_out = zoff(x_out, bs); P_out = zoff(P_out, bs); pose_out = zoff(pose_out, bs);
     __shared__ double Vk[24][25];
     __shared__ double P11[24][25];
@@ -311,4 +314,8 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
             P_out[(size_t)a + (size_t)b * ld] = v;
         }
     }
+    DBG_R(blockIdx.x == 0, 6);
+    // done (single instance): every workgroup bumps the device-side completion counter of the filter chain — the frame's filter has
+    // finished when all of them have (bookkeep_kernel of frame k+2 polls it instead of waiting for an event behind this kernel)
+    if (done) tail_signal(done);
 }

@@ -44,6 +44,7 @@ __device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int 
     return (rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6 + 128) >> 8;
 }
 __global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
+    DBG_S(blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, 0);
     src = zoff(src, src_bs); pyr_shift(p, (size_t)blockIdx.z * bs);
     __shared__ uint8_t L0[85 * 88], L1[41 * 44], L2[19 * 20];
     const int tid = threadIdx.x;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
     extern __shared__ __align__(16) unsigned char dsh[];
     __shared__ int s_w[4];
     __shared__ int pairs[16][2];
+    DBG_S(blockIdx.z == 0, 2);
     n_pts_ptr = zoff(n_pts_ptr, bs); tracked = zoff(tracked, bs); un1 = zoff(un1, bs); un2 = zoff(un2, bs); status = zoff(status, bs);
     imu = zoff(imu, imu_bs); rng = zoff(rng, bs); info = zoff(info, bs);
     __shared__ double hyp[16][9];
@@ -335,8 +337,15 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // Dynamic LDS: tfs[F] float2 (new feature order), cds[F] float2 (candidates), cid_t[F] / cid_c[F] short (grid cell
 // of each tracked point / candidate, -1 = outside), cellp[4][F] float2 (per-wave ChessGrid cell).
 // n_cand_dev != NULL: the corner count lives on the device (device detector), n_cand is ignored.
-__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs) {
+// done / done_target (single instance, run-ahead mode): the device-side counter the filter of frame k-2 bumps when its last kernel has
+// finished (tail.hip) — the hand-over tables this kernel rewrites are free then.  A stream-level event in its place costs the FILTER
+// stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
+__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
+                                                       const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     extern __shared__ __align__(16) unsigned char dsh[];
+    DBG_S(blockIdx.z == 0, 3);
+    if (done) tail_wait(done, done_target, meta);
+    DBG_S(blockIdx.z == 0, 4);
     tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
@@ -523,6 +532,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
     __syncthreads();
     const int nOut = nIn + nNew;
     for (int i = tid; i < nOut; i += 256) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
+    DBG_S(blockIdx.z == 0, 5);
     if (tid == 0) {
         *t.n_pts = nOut; *t.n_feat = nMeas;
         t.info->n_tracked_out = nOut; t.info->n_feat_update = nMeas;

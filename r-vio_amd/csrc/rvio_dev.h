@@ -75,10 +75,20 @@ __device__ __forceinline__ BatchIdx batch_plain() { return {(int)blockIdx.x, (in
 struct BatchIn { size_t imu, n_feat, types, len, meas; };
 
 __device__ long long g_dbg[64];
+// (instrumented build only) start stamps of the filter chain's stages, one row of 8 per frame in a ring of 64 frames, on the constant
+// 100 MHz clock all CUs share: tools/chain_clocks.py turns them into the in-situ timeline of the pipelined run
+__device__ long long g_ring[64 * 8];
+__device__ int g_ring_frame;
+__device__ long long g_ring2[64 * 8];   // the same for the side stream's chain (pyramid, KLT, RANSAC, book-keeping)
+__device__ int g_ring2_frame;
 #ifdef RVIO_DBG_CLOCKS
 #define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)
+#define DBG_R(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring_frame = g_ring_frame + 1; g_ring[(g_ring_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
+#define DBG_S(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring2_frame = g_ring2_frame + 1; g_ring2[(g_ring2_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #else
 #define DBG_T(i) do { } while (0)
+#define DBG_R(cond, id) do { } while (0)
+#define DBG_S(cond, id) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------- small math
@@ -219,3 +229,25 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
     v += dpp_i64<0x121>(v);
     return (readlane_i64(v, 0) + readlane_i64(v, 16)) + (readlane_i64(v, 32) + readlane_i64(v, 48));
 }
+
+// ---------------------------------------------------------------- device-side completion counter (augcomp_kernel2 -> bookkeep_kernel)
+struct TailSync { unsigned long long aug; };   // device memory, zero at creation: bumped by every workgroup of the last kernel of a frame's filter chain
+// every thread of the workgroup calls these
+__device__ __forceinline__ void tail_signal(unsigned long long* c) {
+    __threadfence();                         // each wave: its stores written back and performed at agent scope
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tail_wait(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
+    if (threadIdx.x == 0) {
+        int it = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++it > 400000) { atomicOr(&meta->err, 4); break; }   // ~0.5 s: a producer died — say so instead of hanging the queue
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's vector cache and the XCD's L2 drop what the producers have rewritten
+}
+
+

@@ -53,6 +53,8 @@ struct rvio_hip {
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
+    TailSync* tail_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
+    TailSync tail_tgt = {0};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
@@ -69,7 +71,14 @@ struct rvio_hip {
     hipStream_t side = nullptr;                   // stream of pyramid / KLT / RANSAC of the call in progress (stream_d beside the detector, else ts)
     hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
-    rvio_imu* hb_imu[2] = {nullptr, nullptr};
+    rvio_imu* hb_imu[3] = {nullptr, nullptr, nullptr};   // (run-ahead mode rotates three slots: see rvio_hip_frame)
+    hipEvent_t book_wait = nullptr;   // run-ahead: the event book-keeping of the frame in flight has to wait for (filter k-2)
+    // how "the filter of the frame with parity b has finished" is known: 0 = evF[b] was recorded behind it, 1 = the device-side counter
+    // tail_sync->aug reaches fin_target[b] (single instance, run-ahead mode: no marker packet on the filter stream)
+    int fin_mode[2] = {0, 0};
+    unsigned long long fin_target[2] = {0, 0}, book_target = 0;
+    bool book_dev = false;
+    bool last_ra = false;             // the previous rvio_hip_frame call ran in run-ahead mode
     float* hb_cand[2] = {nullptr, nullptr};
     // pinned host ring of rvio_hip_frame: the caller's (pageable) buffers are packed into it on the host, the H2D copies then run
     // asynchronously from pinned memory.  Slot s may be refilled once evPin[s] (recorded behind its copies) has completed.
@@ -93,7 +102,7 @@ struct rvio_hip {
     unsigned char* d_in_st = nullptr;
     // tracker
     TrackerDev t;
-    PyrDev pyr[2];
+    PyrDev pyr[3];   // three in rotation: pyramid(k) (image stream, run-ahead) may be built while KLT(k-1) still matches the other two
     int pyr_cur = 0;
     std::vector<void*> allocs;
     // filter slab: the filter state, the update scratch and the Tracker -> Updater hand-over of ONE instance are carved from one
@@ -240,6 +249,7 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->block, 2 * ldh * ldh);   // [S2 | S1]: the type-'2' and type-'1' sums of the information block (gram_reduce_kernel)
     DALLOC(h, h->Ab, 2 * ldh * ldh);
     DALLOC(h, h->gram_cnt, 8);
+    DALLOC(h, h->tail_sync, 1);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
@@ -277,7 +287,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
     DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
     DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 3; ++b) {
         int w = d.W, hg = d.H;
         for (int l = 0; l < 4; ++l) {
             uint8_t* im = nullptr; short* dx = nullptr;   // (no derivative images: the KLT kernel forms them from its staged patch)
@@ -429,6 +439,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         const size_t c6t = (c6m + 15) / 16;
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
+        HIPCHK(h, hipFuncSetAttribute((const void*)ug_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UGL_LDS_DOUBLES * sizeof(double))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)final_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FNL_LDS_DOUBLES * sizeof(double))));
     }
     if (batch > 1 && !h->solve5_variant && !h->solve7_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -694,9 +706,15 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
     if (!h->solve7_variant) hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     launch_solve(h, n, Ab);
     // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
-    hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
+    static const bool no_ugl = getenv("RVIO_NO_UGL") != nullptr;   // A/B timing
+    if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
+        hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+        hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
+    } else {
+        hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
+        hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
+    }
     HIPCHK(h, hipGetLastError());
     h->cur ^= 1;
     return RVIO_OK;
@@ -755,8 +773,10 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const DevCfg& d = h->dc;
     const int c = h->cur, o = c ^ 1;
     const int cg = 1 + std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256));
+    unsigned long long* done = nullptr;
+    if (h->batch == 1) { done = &h->tail_sync->aug; h->tail_tgt.aug += (unsigned long long)cg; }
     hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
-                       h->slab_bytes);
+                       h->slab_bytes, done);
     HIPCHK(h, hipGetLastError());
     h->cur = o;
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
@@ -854,7 +874,8 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
     else
         hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
-    if (first_flag_ready) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
+    static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
+    if (first_flag_ready && !(dbg_skip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
     if (h->wide_px && d.W % 4 == 0)
         hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
     else
@@ -876,7 +897,15 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
     size_t src_bs = h->img_bs;       // the caller's images: instance stride of the call in progress
-    bool forked = false;
+    bool forked = false, pyramid_done = false;
+    // the whole pyramid in one launch (pyrDown chain + the copy of the frame into level 0); one workgroup per 8x8 tile of level 3
+    auto launch_pyramid = [&](hipStream_t st) {
+        const int w3 = (((d.W + 1) / 2 + 1) / 2 + 1) / 2, h3 = (((d.H + 1) / 2 + 1) / 2 + 1) / 2;
+        PyrDev pv = p;
+        const bool own = h->cfg.enable_equalizer != 0;   // d_img is the handle's equalised image: level 0 without a copy
+        if (own) { h->pyr[b].img[0] = d_img; pv.img[0] = d_img; }
+        hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, st, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
+    };
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
         // The equalised image of frame k doubles as level 0 of frame k's pyramid (no copy), so it lives until the KLT of frame k+1 has
         // matched against it: three buffers in rotation.  Slot k % 3 was last read by KLT(k-2) (as the previous image) and by the
@@ -885,7 +914,8 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->par];
-        if (h->runahead && h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
+        static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
+        if (h->runahead && h->frame_no >= 2 && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
@@ -895,7 +925,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             hipLaunchKernelGGL(clahe_interp_kernel, dim3((d.W + 63) / 64, (d.H + 3) / 4, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                                1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, lut, eq, src_bs, bs);
         d_img = eq; stride = d.W; src_bs = bs;
-        if (h->runahead) {   // the side stream (pyramid) waits for the equalised image; the detector follows on the image stream itself
+        if (h->runahead) {   // the side stream (KLT) waits for the pyramid of the equalised image; the detector follows on the image stream itself
+            // the pyramid rides on the image stream: it needs nothing from the side stream's chain (KLT(k-1), RANSAC, book-keeping), which is
+            // the longest serial chain of the front end — 19 us less of it; the image chain has the slack
+            launch_pyramid(cs);
+            pyramid_done = true;
             HIPCHK(h, hipEventRecord(h->evC[h->par], cs));
             HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->par], 0));
             forked = true;
@@ -922,14 +956,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         if (rc != RVIO_OK) return rc;
         if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));   // corners of frame k ready (book-keeping on the side stream waits for it)
     }
-    // the whole pyramid in one launch (pyrDown chain + the copy of the frame into level 0); one workgroup per 8x8 tile of level 3
-    {
-        const int w3 = (((d.W + 1) / 2 + 1) / 2 + 1) / 2, h3 = (((d.H + 1) / 2 + 1) / 2 + 1) / 2;
-        PyrDev pv = p;
-        const bool own = h->cfg.enable_equalizer != 0;   // d_img is the handle's equalised image: level 0 without a copy
-        if (own) { h->pyr[b].img[0] = d_img; pv.img[0] = d_img; }
-        hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, h->side, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
-    }
+    if (!pyramid_done) launch_pyramid(h->side);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -941,19 +968,26 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
     h->tail = h->ts;
+    const unsigned long long* done = nullptr; unsigned long long done_target = 0;
     if (h->use_det) {   // the detector's corner list replaces the caller's
         const float* xy = h->det_xy2[h->par];
         const int* nout = h->det_nout + h->par;
-        if (h->runahead) {   // book-keeping on the side stream, behind RANSAC, once the corners are there
+        if (h->runahead) {   // book-keeping on the side stream, behind RANSAC, once the corners are there and filter(k-2) has let go of the hand-over
+            static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
+            if (h->book_wait && !(dbg_skip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
+            h->book_wait = nullptr;
+            if (h->book_dev && !(dbg_skip & 4)) { done = &h->tail_sync->aug; done_target = h->book_target; }
+            h->book_dev = false;
             HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
             h->tail = h->side;
         } else {             // join the side stream (long finished when the detector is)
             HIPCHK(h, hipEventRecord(h->evD1, h->side));
             HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
         }
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs);
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs, done, done_target, h->meta);
     } else
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0);
+        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0,
+                           (const unsigned long long*)nullptr, 0ull, h->meta);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -968,7 +1002,7 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->par = piped_call ? (int)(h->frame_no & 1) : 0;
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;   // A/B timing only
     h->runahead = piped_call && h->use_det && !no_runahead;
-    const int nb = h->pyr_cur ^ 1;   // pyramid of the new image; pyr_cur holds mLastImage's
+    const int nb = (h->pyr_cur + 1) % 3;   // pyramid of the new image; pyr_cur holds mLastImage's (slot nb was last read by KLT(k-2))
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
     hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
@@ -1079,6 +1113,12 @@ int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
     return propagate_dev(h, d_imu, m);
 }
 
+// `stream` goes on once the filter of the last frame with parity b has finished (see fin_mode)
+static int wait_filter_done(rvio_hip* h, int b, hipStream_t stream) {
+    if (h->fin_mode[b] == 0) HIPCHK(h, hipStreamWaitEvent(stream, h->evF[b], 0));
+    else HIPCHK(h, hipStreamSynchronize(h->stream));   // (a call that left run-ahead mode: rare, the host waits)
+    return RVIO_OK;
+}
 static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m, bool propagated = false) {
     h->img_count++;
     int rc = propagated ? RVIO_OK : propagate_dev(h, d_imu, m);
@@ -1129,8 +1169,12 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     if (h->frame_no >= 2) {   // the filter of frame k-2 has consumed this hand-over buffer: only the stream that runs book-keeping has to know.
         // (In run-ahead mode the image chains — CLAHE, detector — never touch the hand-over: making them wait here tied image(k) to
         // filter(k-2) and with it the frame period to image chain + filter chain over two frames.)
-        if (!ra) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));
-        HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evF[b], 0));
+        // Run-ahead: of the side stream's chain (pyramid, KLT, RANSAC, book-keeping) only book-keeping writes the hand-over, so the wait
+        // goes right in front of it (post_klt_dev) — at the head of the frame it tied KLT(k) to filter(k-2) and made
+        // [side chain + filter chain] the period of two frames.
+        if (!ra) { int rcw = wait_filter_done(h, b, h->stream_t); if (rcw == RVIO_OK) rcw = wait_filter_done(h, b, h->stream_d); if (rcw != RVIO_OK) return rcw; }
+        else if (h->fin_mode[b] == 0) h->book_wait = h->evF[b];
+        else { h->book_dev = true; h->book_target = h->fin_target[b]; }
     } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
     if (m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
@@ -1155,15 +1199,20 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
     const double t2 = dbg_host ? now() : 0;
+    static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
     HIPCHK(h, hipEventRecord(h->evT[b], h->tail));      // behind book-keeping, on the stream that ran it
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
+    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
     rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
     h->fuse_m = -1;
     const double t4 = dbg_host ? now() : 0;
-    HIPCHK(h, hipEventRecord(h->evF[b], h->stream));
+    // the filter of this frame is finished when ... single instance in run-ahead mode: its last kernel has bumped the device-side counter
+    // (book-keeping of frame k+2 polls it); otherwise an event behind it
+    static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr;
+    if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->tail_tgt.aug; }
+    else { if (!(dbg_skip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
     if (dbg_host) {
         const double t5 = now();
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
@@ -1206,6 +1255,7 @@ int rvio_hip_frame_end(rvio_hip* h) {
     if (!h || !h->in_frame) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventRecord(h->evF[h->frame_no & 1], h->stream));
+    h->fin_mode[h->frame_no & 1] = 0;
     h->frame_no++;
     h->in_frame = false;
     return RVIO_OK;
@@ -1222,6 +1272,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         for (int k = 0; k < 2; ++k) {
             DALLOC(h, h->hb_img[k], (size_t)h->dc.W * h->dc.H);
             DALLOC(h, h->hb_imu[k], (size_t)RVIO_MAX_IMU);
+            if (k == 1) DALLOC(h, h->hb_imu[2], (size_t)RVIO_MAX_IMU);
             DALLOC(h, h->hb_cand[k], (size_t)2 * h->dc.F);
             HIPCHK(h, hipStreamSynchronize(h->stream));   // DALLOC clears on the filter stream
         }
@@ -1247,12 +1298,16 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     if (nc > 0) std::memcpy(pp + pin_cand, cand_xy, sizeof(float) * 2 * nc);
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;
     const bool ra = !cand_xy && !h->one_stream && !no_runahead;
+    int imu_slot = b;
     if (ra) {
         // run-ahead mode.  The IMU batch goes to the SIDE stream (RANSAC runs there; propagate on the filter stream waits for evIn): it
         // has to wait for the filter of frame k-2 (the last reader of hb_imu[b]), and that wait must not sit in front of an image chain.
-        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evF[b], 0));
-        else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_d));
+        // Three IMU slots in rotation: slot k % 3 was last read by filter(k-3) / RANSAC(k-3), and this copy follows book-keeping(k-1) on the
+        // side stream, which waited for filter(k-3) — no wait of its own (one here would again put filter(k-2) in front of KLT(k)).
+        imu_slot = (int)(h->frame_no % 3);
+        if (!h->last_ra && h->frame_no >= 1) { int rcw = wait_filter_done(h, 0, h->stream_d); if (rcw == RVIO_OK && h->frame_no >= 2) rcw = wait_filter_done(h, 1, h->stream_d); if (rcw != RVIO_OK) return rcw; }
+        if (h->frame_no < 2 && !h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[imu_slot], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_d));
         HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_d));
         HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_d));
         // The image goes to the stream of this frame's image chain (image_stream: tracker stream / fourth stream by parity).  hb_img[b]
@@ -1263,7 +1318,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
         HIPCHK(h, hipEventRecord(h->evPin2[ps], is));
     } else {
-        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evF[b], 0));   // filter(k-2) has consumed hb_imu[b]
+        if (h->frame_no >= 2) { const int rcw = wait_filter_done(h, b, h->stream_t); if (rcw != RVIO_OK) return rcw; }   // filter(k-2) has consumed hb_imu[b]
         else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
         if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
         HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
@@ -1271,7 +1326,8 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         if (nc > 0) HIPCHK(h, hipMemcpyAsync(h->hb_cand[b], pp + pin_cand, sizeof(float) * 2 * nc, hipMemcpyHostToDevice, h->stream_t));
         HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_t));
     }
-    return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[b], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
+    h->last_ra = ra;
+    return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[imu_slot], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
 int rvio_hip_frame_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
@@ -1378,7 +1434,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur ^ 1], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
+            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[(h->pyr_cur + 2) % 3], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status, (size_t)0);
         } else if (which == 2) {
             if (h->batch == 1)
@@ -1409,6 +1465,20 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     return RVIO_OK;
 }
 
+int rvio_hip_debug_ring(rvio_hip* h, long long* out512, int* frame) {
+    if (!h || !out512 || !frame) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring), sizeof(long long) * 512));
+    HIPCHK(h, hipMemcpyFromSymbol(frame, HIP_SYMBOL(g_ring_frame), sizeof(int)));
+    return RVIO_OK;
+}
+int rvio_hip_debug_ring2(rvio_hip* h, long long* out512, int* frame) {
+    if (!h || !out512 || !frame) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring2), sizeof(long long) * 512));
+    HIPCHK(h, hipMemcpyFromSymbol(frame, HIP_SYMBOL(g_ring2_frame), sizeof(int)));
+    return RVIO_OK;
+}
 int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {
     if (!h || !out64) return RVIO_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1,0 +1,59 @@
+"""In-situ timeline of the filter chain in the pipelined single-stream run (instrumented build):
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRVIO_DBG_CLOCKS r-vio_amd/csrc/rvio_hip.hip -o r-vio_amd/librvio_dbg.so
+    RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so python tools/chain_clocks.py [frames]
+Every stage's first workgroup stamps the constant 100 MHz clock at its start (DBG_R, rvio_dev.h); printed: the mean start-to-start
+interval of consecutive stages over the last 48 frames (microseconds) = what each stage costs the serial chain, launch gap included,
+and the frame period (feat_prop to feat_prop)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import torch  # noqa: E402
+
+rv, abi = bench.rv, bench.abi
+from rvio_amd import hip  # noqa: E402
+
+cfg = abi.config_named("B", enable_equalizer=1)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+n_frames = 1 + K
+seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt = bench.build_inputs(cfg, n_frames)
+h = hip.RvioHip(cfg)
+d_imgs = torch.from_numpy(imgs).cuda()
+d_imu = torch.from_numpy(imu_arr.view(np.uint8).reshape(n_frames, -1)).cuda()
+torch.cuda.synchronize()
+h.initialize(*seq.init_from_static(bench.K0))
+for i in range(n_frames):
+    h.frame_dev(d_imgs.data_ptr() + i * cfg.width * cfg.height, cfg.width, d_imu.data_ptr() + i * d_imu.shape[1], int(imu_cnt[i]), 0, 0)
+h.sync()
+out = (C.c_longlong * 512)()
+fr = C.c_int(0)
+h.L.rvio_hip_debug_ring(h.h, out, C.byref(fr))
+t = np.array(list(out), dtype=np.int64).reshape(64, 8)
+last = fr.value
+rows = [t[(last - j) & 63] for j in range(48, -1, -1)]    # oldest .. newest
+names = ["feat_prop", "gram", "solve", "ug", "final", "augcomp", "augcomp end", "bookkeep"]
+r = np.array(rows, dtype=np.float64) / 100.0               # microseconds
+print("frames stamped:", last)
+print("period (feat_prop -> feat_prop): %.1f us" % np.mean(np.diff(r[:, 0])))
+for a in range(6):
+    print("%-12s -> %-12s %.1f us" % (names[a], names[a + 1], np.mean(r[1:, a + 1] - r[1:, a])))
+print("augcomp end -> next feat_prop: %.1f us" % np.mean(r[1:, 0] - r[:-1, 6]))
+out2 = (C.c_longlong * 512)()
+fr2 = C.c_int(0)
+h.L.rvio_hip_debug_ring2(h.h, out2, C.byref(fr2))
+t2 = np.array(list(out2), dtype=np.int64).reshape(64, 8)
+rows2 = np.array([t2[(fr2.value - j) & 63] for j in range(48, -1, -1)], dtype=np.float64) / 100.0
+n2 = ["pyramid", "klt", "ransac", "bookkeep (launch)", "bookkeep (after the wait)", "bookkeep end"]
+print("side stream: period (pyramid -> pyramid): %.1f us" % np.mean(np.diff(rows2[:, 0])))
+for a in range(5):
+    print("%-26s -> %-26s %.1f us" % (n2[a], n2[a + 1], np.mean(rows2[1:, a + 1] - rows2[1:, a])))
+print("bookkeep end -> next pyramid: %.1f us" % np.mean(rows2[1:, 0] - rows2[:-1, 5]))
+# how far the side chain runs ahead of the filter: book-keeping(k) end -> feat_prop(k) start (frame numbers: side = fr2, filter = last)
+off = fr2.value - last
+print("side chain frames ahead of the filter at the end:", off)
+h.close()
