@@ -36,6 +36,12 @@ __host__ __device__ inline size_t feat_lds_doubles(int max_len, int ldh, bool tm
     n += (size_t)(rho + 1) * (rho + 1);
     return n;
 }
+// reciprocal of a positive normal double: hardware estimate + two Newton steps (the IEEE division sequence is three times as long)
+__device__ __forceinline__ double fast_rcp(double v) {
+    double y = __builtin_amdgcn_rcp(v);
+    y = fma(fma(-v, y, 1.0), y, y);
+    return fma(fma(-v, y, 1.0), y, y);
+}
 
 // HOIST: k-values whose operand loads are in flight before the first MFMA of a gate tile (16: one stream, latency; 4: batch handles, 128 VGPRs)
 template <int HOIST>
@@ -162,8 +168,9 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                 double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0, cost = 0;
                 if (act) {
                     d3 h = (lane == 0) ? ep : add3(mv33(Rc, ep), scl3(rho, tc));
-                    const double iz = 1 / h.z, iz2 = h.z * h.z;
-                    const double Hp0[3] = {iz, 0, -h.x / iz2}, Hp1[3] = {0, iz, -h.y / iz2};
+                    // (reciprocal by estimate + two Newton steps; the five IEEE divisions of this block were a fifth of the iteration)
+                    const double iz = fast_rcp(h.z);
+                    const double Hp0[3] = {iz, 0, -(h.x * iz) * iz}, Hp1[3] = {0, iz, -(h.y * iz) * iz};
                     double HR0[3], HR1[3];
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
@@ -177,7 +184,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                     H1[1] = HR1[0] * J01 + HR1[2] * J21;
                     if (lane == 0) { H0[2] = 0; H1[2] = 0; }
                     else { H0[2] = Hp0[0] * tc.x + Hp0[2] * tc.z; H1[2] = Hp1[1] * tc.y + Hp1[2] * tc.z; }
-                    const float px = (float)(h.x / h.z), py = (float)(h.y / h.z);  // cv::Point2f rounding (Updater.cc:197-202)
+                    const float px = (float)(h.x * iz), py = (float)(h.y * iz);    // cv::Point2f rounding (Updater.cc:197-202)
                     const double e0 = (double)(mx - px), e1 = (double)(my - py);
                     cost = (e0 * ri) * e0 + (e1 * ri) * e1;
                     c00 = (H0[0] * ri) * H0[0] + (H1[0] * ri) * H1[0];
@@ -205,9 +212,9 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                     // damped normal equations, SPD 3x3: Cholesky solve (reference: colPivHouseholderQr, Updater.cc:239)
                     // L D L^T (square-root free): 3 reciprocals instead of 3 sqrt + 9 divisions
                     const double a00 = c00 + lambda * c00, a11 = c11 + lambda * c11, a22 = c22 + lambda * c22;
-                    const double i0 = 1.0 / a00, l10 = c01 * i0, l20 = c02 * i0;
-                    const double dd1 = a11 - l10 * c01, i1 = 1.0 / dd1, l21 = (c12 - l20 * c01) * i1;
-                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = 1.0 / dd2;
+                    const double i0 = fast_rcp(a00), l10 = c01 * i0, l20 = c02 * i0;
+                    const double dd1 = a11 - l10 * c01, i1 = fast_rcp(dd1), l21 = (c12 - l20 * c01) * i1;
+                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = fast_rcp(dd2);
                     const double z0 = g0, z1 = g1 - l10 * z0, z2 = g2 - l20 * z0 - l21 * z1;
                     const double d2 = z2 * i2, d1 = z1 * i1 - l21 * d2, d0 = z0 * i0 - l10 * d1 - l20 * d2;
                     phi += d0; psi += d1; rho += d2;
@@ -430,6 +437,11 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     // one rank-1 update step per barrier, every element touched once per step.
     double gam = 0;
     {
+        // TWO pivots per barrier: a rank-1 step is latency (an LDS round trip, a reciprocal, a barrier: ~1000 cycles whatever the size), so
+        // columns k and k+1 go together.  With a = S[k][k], b = S[k+1][k], c' = S[k+1][k+1] - b^2 / a and u_i = S[i][k+1] - S[i][k] b / a:
+        //   S[i][j] -= S[i][k] S[j][k] / a + u_i u_j / c'        gamma += w_k^2 / a + u_w^2 / c'
+        // — the two sequential steps written out.  All loads of a step are issued before its first store (the elements are distinct, but
+        // the compiler cannot know and would otherwise order every slot's store before the next slot's loads).
         double gsum = 0;
         const int tot = (rr + 1) * rr;
         int ei[4], ej[4];
@@ -440,18 +452,40 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
             const bool low = e < tot && j <= (i < rr ? i : rr - 1);
             ei[q] = low ? i : -1; ej[q] = j;
         }
-        for (int k = 0; k < rr; ++k) {
-            const double dk = S[k * lds_s + k];
-            const double rd = 1.0 / (dk > 0 ? dk : 1e-300);
-            if (tid == 0) { const double w = S[rr * lds_s + k]; gsum += w * (w * rd); }
+        int k = 0;
+        for (; k + 1 < rr; k += 2) {
+            const double a = S[k * lds_s + k], b = S[(k + 1) * lds_s + k], c = S[(k + 1) * lds_s + k + 1];
+            double sv[4], si0[4], si1[4], sj0[4], sj1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = ei[q] > k + 1 && ej[q] > k + 1;
+                sv[q] = on ? S[ei[q] * lds_s + ej[q]] : 0.0;
+                si0[q] = on ? S[ei[q] * lds_s + k] : 0.0; si1[q] = on ? S[ei[q] * lds_s + k + 1] : 0.0;
+                sj0[q] = on ? S[ej[q] * lds_s + k] : 0.0; sj1[q] = on ? S[ej[q] * lds_s + k + 1] : 0.0;
+            }
+            const double ra = fast_rcp(a > 0 ? a : 1e-300), ba = b * ra, c2 = c - b * ba, rc = fast_rcp(c2 > 0 ? c2 : 1e-300);
+            if (tid == 0) {
+                const double w0 = S[rr * lds_s + k], w1 = S[rr * lds_s + k + 1] - w0 * ba;
+                gsum += w0 * (w0 * ra) + w1 * (w1 * rc);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (ei[q] > k && ej[q] > k) S[ei[q] * lds_s + ej[q]] -= (S[ei[q] * lds_s + k] * rd) * S[ej[q] * lds_s + k];
+                if (ei[q] > k + 1 && ej[q] > k + 1) {
+                    const double ui = si1[q] - si0[q] * ba, uj = sj1[q] - sj0[q] * ba;
+                    S[ei[q] * lds_s + ej[q]] = (sv[q] - (si0[q] * ra) * sj0[q]) - (ui * rc) * uj;
+                }
             for (int e = tid + 4 * T; e < tot; e += T) {     // long tracks on narrow workgroups
                 const int i = e / rr, j = e - i * rr;
-                if (i > k && j > k && j <= (i < rr ? i : rr - 1)) S[i * lds_s + j] -= (S[i * lds_s + k] * rd) * S[j * lds_s + k];
+                if (i > k + 1 && j > k + 1 && j <= (i < rr ? i : rr - 1)) {
+                    const double ui = S[i * lds_s + k + 1] - S[i * lds_s + k] * ba, uj = S[j * lds_s + k + 1] - S[j * lds_s + k] * ba;
+                    S[i * lds_s + j] = (S[i * lds_s + j] - (S[i * lds_s + k] * ra) * S[j * lds_s + k]) - (ui * rc) * uj;
+                }
             }
             __syncthreads();
+        }
+        if (k < rr && tid == 0) {     // odd count: the last pivot only feeds gamma
+            const double dk = S[k * lds_s + k], w = S[rr * lds_s + k];
+            gsum += w * (w * fast_rcp(dk > 0 ? dk : 1e-300));
         }
         if (tid == 0) misc[8] = fabs(gsum);
     }

@@ -44,7 +44,6 @@ __device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int 
     return (rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6 + 128) >> 8;
 }
 __global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
-    DBG_S(blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, 0);
     src = zoff(src, src_bs); pyr_shift(p, (size_t)blockIdx.z * bs);
     __shared__ uint8_t L0[85 * 88], L1[41 * 44], L2[19 * 20];
     const int tid = threadIdx.x;

@@ -43,7 +43,7 @@ __device__ __forceinline__ void klt3_stage_j(uint8_t* Jr, const uint8_t* __restr
 
 __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int levels, const int* __restrict__ n_pts_ptr,
                                                   const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status, size_t bs) {
-    DBG_S(blockIdx.x == 0 && blockIdx.z == 0, 1);
+    DBG_S(blockIdx.x == 0 && blockIdx.z == 0, 0);
     pyr_shift(prev, (size_t)blockIdx.z * bs); pyr_shift(next, (size_t)blockIdx.z * bs);
     n_pts_ptr = zoff(n_pts_ptr, bs); pts = zoff(pts, bs); out = zoff(out, bs); status = zoff(status, bs);
     __shared__ uint8_t Ip[4][18 * 18 + 4];   // (Y0 - 1 .. Y0 + 16) x (X0 - 1 .. X0 + 16), reflect-101 coordinates

@@ -48,11 +48,12 @@ fr2 = C.c_int(0)
 h.L.rvio_hip_debug_ring2(h.h, out2, C.byref(fr2))
 t2 = np.array(list(out2), dtype=np.int64).reshape(64, 8)
 rows2 = np.array([t2[(fr2.value - j) & 63] for j in range(48, -1, -1)], dtype=np.float64) / 100.0
-n2 = ["pyramid", "klt", "ransac", "bookkeep (launch)", "bookkeep (after the wait)", "bookkeep end"]
-print("side stream: period (pyramid -> pyramid): %.1f us" % np.mean(np.diff(rows2[:, 0])))
-for a in range(5):
-    print("%-26s -> %-26s %.1f us" % (n2[a], n2[a + 1], np.mean(rows2[1:, a + 1] - rows2[1:, a])))
-print("bookkeep end -> next pyramid: %.1f us" % np.mean(rows2[1:, 0] - rows2[:-1, 5]))
+n2 = {0: "klt", 2: "ransac", 3: "bookkeep (launch)", 4: "bookkeep (after the wait)", 5: "bookkeep end"}
+print("side stream: period (klt -> klt): %.1f us" % np.mean(np.diff(rows2[:, 0])))
+ids = [0, 2, 3, 4, 5]
+for a, b in zip(ids[:-1], ids[1:]):
+    print("%-26s -> %-26s %.1f us" % (n2[a], n2[b], np.mean(rows2[1:, b] - rows2[1:, a])))
+print("bookkeep end -> next klt: %.1f us" % np.mean(rows2[1:, 0] - rows2[:-1, 5]))
 # how far the side chain runs ahead of the filter: book-keeping(k) end -> feat_prop(k) start (frame numbers: side = fr2, filter = last)
 off = fr2.value - last
 print("side chain frames ahead of the filter at the end:", off)
