@@ -49,14 +49,14 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                                                 const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                 int shard_rank, int shard_world,
                                                 double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
+                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta, const int f) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
     ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
     if (tm_global) tm_global = zoffi(tm_global, bs, bi.z);
     n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, bi.z); types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z); meas = zoffi(meas, bin.meas, bi.z);
-    const int tid = threadIdx.x, T = blockDim.x, f = bi.x;
+    const int tid = threadIdx.x, T = blockDim.x;   // f: the feature slot of this pass
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
     // carve LDS
     const int ML = cfg.max_len, M2max = 2 * ML, rhomax = 2 * ML - 2;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(HOIST > 4 ? 256 : 1024) void feat_build_kernel(DevC
                                   double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
     feat_build_body<HOIST>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
-                           tm_global, bs, bin, meta);
+                           tm_global, bs, bin, meta, (int)blockIdx.x);
 }
 
 // =============================================================== U7 compression, information form (reduction stage)

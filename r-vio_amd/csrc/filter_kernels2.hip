@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
                                                          double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
     propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
 }
+// batch handles: two workgroups per CU (256 VGPRs, part of the working set in scratch) — throughput, not latency
+__global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                                             double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+    propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+}
 
 // PreIntegrator::propagate and the per-feature stage of Updater::update in ONE launch (single instance, pipelined whole-frame path):
 // U1-U5 read only the clone states and P[24:,24:], which propagation does not touch (it rewrites the IMU state, P[0:24,0:24] and the
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         FilterMeta* meta, const rvio_imu* imu, int m) {
     DBG_R(blockIdx.x == 0, 0);
     if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
-    feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta);
+    feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta, (int)blockIdx.x);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition

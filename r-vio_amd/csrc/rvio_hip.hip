@@ -591,6 +591,11 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 
 // ------------------------------------------------------------------ P1
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0) {   // imu_bs = 0: every instance integrates the same samples
+    static const bool prop_b = getenv("RVIO_NO_PROP_B") == nullptr;   // A/B timing
+    if (h->batch > 8 && prop_b)
+        hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
+                           h->slab_bytes, imu_bs);
+    else
     hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                        h->slab_bytes, imu_bs);
     HIPCHK(h, hipGetLastError());
