@@ -32,7 +32,8 @@ struct rvio_hip {
     hipStream_t stream = nullptr;     // filter stream (and the stream of every non-pipelined call)
     hipStream_t stream_t = nullptr;   // tracker stream of the pipelined whole-frame path
     hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
-    hipEvent_t evT[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
+    hipEvent_t evT[4] = {nullptr, nullptr, nullptr, nullptr};   // book-keeping(k) done: a ring by frame number (the image chain of frame k waits for frame k-3's)
+    hipEvent_t evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
     long frame_no = 0;
     bool piped = false, in_frame = false;
     struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[2];
@@ -89,9 +90,10 @@ struct rvio_hip {
     uint8_t *d_eq = nullptr, *d_lut2[2] = {nullptr, nullptr};   // CLAHE output image and tile LUTs (enable_equalizer), the LUTs by frame parity
     // Buffers the front end of frame k+1 would otherwise overwrite while book-keeping of frame k still reads them (run-ahead of the
     // image chain on the pipelined path, see track_dev_impl): equalised image, detector corner list and its count, by frame parity
-    uint8_t* d_eq2[3] = {nullptr, nullptr, nullptr};   // three, in rotation: the equalised image IS level 0 of its pyramid, which the KLT of the NEXT frame still reads
+    uint8_t* d_eq2[4] = {nullptr, nullptr, nullptr, nullptr};   // four, in rotation: the equalised image IS level 0 of its pyramid, which the KLT of the NEXT frame still reads
     int eq_slot = 0;
-    float* det_xy2[2] = {nullptr, nullptr};
+    float* det_xy2[3] = {nullptr, nullptr, nullptr};   // corner lists: by parity, in run-ahead mode three in rotation (dslot)
+    int dslot = 0;
     int* det_nout = nullptr;
     int par = 0;                                  // parity of the call in progress / of the last call (getters)
     hipStream_t tail = nullptr;                   // stream that ran book-keeping in the call in progress (the hand-over event is recorded there)
@@ -102,7 +104,7 @@ struct rvio_hip {
     unsigned char* d_in_st = nullptr;
     // tracker
     TrackerDev t;
-    PyrDev pyr[3];   // three in rotation: pyramid(k) (image stream, run-ahead) may be built while KLT(k-1) still matches the other two
+    PyrDev pyr[4];   // four in rotation: pyramid(k) (image stream, run-ahead) may be built while KLT(k-2), KLT(k-1) still match the others
     int pyr_cur = 0;
     std::vector<void*> allocs;
     // filter slab: the filter state, the update scratch and the Tracker -> Updater hand-over of ONE instance are carved from one
@@ -273,6 +275,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, h->d_img, (size_t)d.W * d.H);
     if (h->cfg.enable_equalizer) {
         DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[2], (size_t)d.W * d.H);
+        DALLOC(h, h->d_eq2[3], (size_t)d.W * d.H);
         h->d_eq = h->d_eq2[0];
         DALLOC(h, h->d_lut2[0], (size_t)h->cl_tx * h->cl_ty * 256); DALLOC(h, h->d_lut2[1], (size_t)h->cl_tx * h->cl_ty * 256);
     }
@@ -287,7 +290,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
     DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
     DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 4; ++b) {
         int w = d.W, hg = d.H;
         for (int l = 0; l < 4; ++l) {
             uint8_t* im = nullptr; short* dx = nullptr;   // (no derivative images: the KLT kernel forms them from its staged patch)
@@ -333,6 +336,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->ts = h->stream;
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evT[b + 2], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], kEvFlags));
     }
@@ -470,7 +474,8 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
     if (h->stream_c && !h->one_stream) hipStreamDestroy(h->stream_c);
     for (int b = 0; b < 2; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
-    for (int b = 0; b < 2; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
+    for (int b = 0; b < 4; ++b) if (h->evT[b]) hipEventDestroy(h->evT[b]);
+    for (int b = 0; b < 2; ++b) { if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
     if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -820,8 +825,8 @@ static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a sla
     int rc = detector_alloc_set(h, h->det);
     if (rc != RVIO_OK) return rc;
     if ((rc = detector_alloc_set(h, h->det_b)) != RVIO_OK) return rc;
-    DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F);
-    DALLOC(h, h->det_nout, 2);
+    DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F); DALLOC(h, h->det_xy2[2], (size_t)2 * d.F);
+    DALLOC(h, h->det_nout, 3);
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)SP_WW * SP_WW);
     for (DetDev* q : {&h->det, &h->det_b}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; }
@@ -860,7 +865,7 @@ static int detector_init(rvio_hip* h) {
 //    book-keeping(k) still reads while frame k+1 is being detected is double-buffered by frame parity (equalised image, corner list).
 static DetDev det_view(const rvio_hip* h) {
     DetDev q = (h->runahead && h->par) ? h->det_b : h->det;
-    q.xy = h->det_xy2[h->par]; q.n_out = h->det_nout + h->par;
+    q.xy = h->det_xy2[h->dslot]; q.n_out = h->det_nout + h->dslot;
     return q;
 }
 // the stream CLAHE and the detector of the call in progress run on: in run-ahead mode the image chains of consecutive frames
@@ -913,14 +918,16 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
     };
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
         // The equalised image of frame k doubles as level 0 of frame k's pyramid (no copy), so it lives until the KLT of frame k+1 has
-        // matched against it: three buffers in rotation.  Slot k % 3 was last read by KLT(k-2) (as the previous image) and by the
-        // detector / pyramid of frame k-3; in run-ahead mode CLAHE(k) waits for book-keeping(k-2), which followed KLT(k-2) on the side stream
-        h->eq_slot = (h->eq_slot + 1) % 3;
+        // matched against it: four buffers in rotation (like the pyramids, and three corner lists).  Slot k % 4 was last read by KLT(k-3)
+        // (as the previous image) and by the detector / pyramid of frame k-4; in run-ahead mode CLAHE(k) waits for book-keeping(k-3), which
+        // followed KLT(k-3) on the side stream and was the last reader of corner list k % 3.  (With three / three / two buffers the wait
+        // was for book-keeping(k-2): an image chain is ~190 us long, so it started late enough to hold book-keeping(k) up.)
+        h->eq_slot = (h->eq_slot + 1) % 4;
         uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->par];
         static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
-        if (h->runahead && h->frame_no >= 2 && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[h->par], 0));
+        if (h->runahead && h->frame_no >= 3 && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[(h->frame_no - 3) & 3], 0));
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
@@ -956,7 +963,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             for (int i = 0; i < h->batch && all0; ++i) all0 = ((volatile int*)h->first_mirror)[i] == 0;
             h->first_cleared = all0;
         }
-        const hipEvent_t flag = (h->runahead && h->frame_no >= 1 && !h->first_cleared) ? h->evT[(h->frame_no - 1) & 1] : nullptr;
+        const hipEvent_t flag = (h->runahead && h->frame_no >= 1 && !h->first_cleared) ? h->evT[(h->frame_no - 1) & 3] : nullptr;
         const int rc = detect_dev(h, d_img, stride, src_bs, flag);
         if (rc != RVIO_OK) return rc;
         if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));   // corners of frame k ready (book-keeping on the side stream waits for it)
@@ -975,8 +982,8 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     h->tail = h->ts;
     const unsigned long long* done = nullptr; unsigned long long done_target = 0;
     if (h->use_det) {   // the detector's corner list replaces the caller's
-        const float* xy = h->det_xy2[h->par];
-        const int* nout = h->det_nout + h->par;
+        const float* xy = h->det_xy2[h->dslot];
+        const int* nout = h->det_nout + h->dslot;
         if (h->runahead) {   // book-keeping on the side stream, behind RANSAC, once the corners are there and filter(k-2) has let go of the hand-over
             static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
             if (h->book_wait && !(dbg_skip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
@@ -1007,7 +1014,8 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->par = piped_call ? (int)(h->frame_no & 1) : 0;
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;   // A/B timing only
     h->runahead = piped_call && h->use_det && !no_runahead;
-    const int nb = (h->pyr_cur + 1) % 3;   // pyramid of the new image; pyr_cur holds mLastImage's (slot nb was last read by KLT(k-2))
+    h->dslot = h->runahead ? (int)(h->frame_no % 3) : h->par;
+    const int nb = (h->pyr_cur + 1) % 4;   // pyramid of the new image; pyr_cur holds mLastImage's (slot nb was last read by KLT(k-3))
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
     hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
@@ -1205,8 +1213,8 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     if (rc != RVIO_OK) return rc;
     const double t2 = dbg_host ? now() : 0;
     static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
-    HIPCHK(h, hipEventRecord(h->evT[b], h->tail));      // behind book-keeping, on the stream that ran it
-    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[b], 0));
+    HIPCHK(h, hipEventRecord(h->evT[h->frame_no & 3], h->tail));      // behind book-keeping, on the stream that ran it
+    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
@@ -1319,7 +1327,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         // was last read by frame k-2: its CLAHE / detector (same stream, earlier) and — without the equaliser — its pyramid on the side
         // stream, which book-keeping(k-2) followed.
         hipStream_t is = b ? h->stream_c : h->stream_t;
-        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(is, h->evT[b], 0));
+        if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(is, h->evT[(h->frame_no - 2) & 3], 0));
         HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
         HIPCHK(h, hipEventRecord(h->evPin2[ps], is));
     } else {
@@ -1380,9 +1388,9 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     SYNC_FRONT(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int cnt = 0;
-    HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->par, sizeof cnt, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->dslot, sizeof cnt, hipMemcpyDeviceToHost));
     if (n) *n = cnt;
-    if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->par], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
+    if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->dslot], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
     const DetDev& ds_ = h->det_set_last ? h->det_b : h->det;
     if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
     if (eig) HIPCHK(h, hipMemcpy(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
@@ -1439,7 +1447,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[(h->pyr_cur + 2) % 3], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
+            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[(h->pyr_cur + 3) % 4], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status, (size_t)0);
         } else if (which == 2) {
             if (h->batch == 1)
