@@ -340,4 +340,5 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
         for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
     }
+    DBG_R(true, 7);
 }

@@ -42,6 +42,7 @@ print("frames stamped:", last)
 print("period (feat_prop -> feat_prop): %.1f us" % np.mean(np.diff(r[:, 0])))
 for a in range(6):
     print("%-12s -> %-12s %.1f us" % (names[a], names[a + 1], np.mean(r[1:, a + 1] - r[1:, a])))
+print("solve start -> solve end (thread 0): %.1f us; solve end -> ug start: %.1f us" % (np.mean(r[1:, 7] - r[1:, 2]), np.mean(r[1:, 3] - r[1:, 7])))
 print("augcomp end -> next feat_prop: %.1f us" % np.mean(r[1:, 0] - r[:-1, 6]))
 out2 = (C.c_longlong * 512)()
 fr2 = C.c_int(0)
