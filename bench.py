@@ -199,7 +199,7 @@ def main():
                    "parallelism": ("1 process/GPU; feature-sharded updater + 1 all-gather/frame (%s)"
                                    % ("ncclAllGather on the filter stream" if comm is not None else "torch.distributed")) if sharded else "single GPU"},
         "gpu_ms_per_step_events": gpu_ms / K, "host_enqueue_ms_per_step": 1e3 * t_enq / K,
-        "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")},
+        "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated", "device_error")},
     }
 
     if sharded and not args.no_streams:

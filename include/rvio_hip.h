@@ -115,7 +115,8 @@ typedef struct rvio_frame_info {
     int32_t updated;           /* 1 if the EKF update was applied               */
     int32_t n_tracked_out;     /* mnFeatsToTrack leaving track() (after refill) */
     int32_t ransac_winner;     /* nWinnerHypothesisIdx                          */
-    int32_t reserved[5];       /* [0]: sticky device-side error flag */
+    int32_t reserved[5];       /* [0]: sticky device-side error flag: 1 = singular pivot in the solve, 2 = a track the window cannot hold was
+                                * dropped, 4 = a device-side stage counter (filter done -> book-keeping) timed out */
     int32_t rank_truncated_at; /* Updater.cc:516-529: nRank when the leading-row scan cut informative rows off (the type-'1'
                                 * features' rows, dropped from this update), -1 otherwise */
 } rvio_frame_info;

@@ -51,7 +51,10 @@ class rvio_frame_info(C.Structure):
                [("reserved", C.c_int32 * 5), ("rank_truncated_at", C.c_int32)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        if hasattr(self, "reserved"):
+            d["device_error"] = int(self.reserved[0])   # sticky: 1 singular pivot, 2 track the window cannot hold, 4 a device-side stage counter timed out
+        return d
 
 
 # Camera.T_BC0 of config/rvio_euroc.yaml:55-62 (row-major)

@@ -117,6 +117,7 @@ def test_long_image_sequence_tracks_the_literal_oracle(gpu_required):
         gi = h.frame_info()
         for key in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated"):
             assert gi[key] == oi[key], (k, key)
+        assert gi["device_error"] == 0, (k, gi["device_error"])    # no singular pivot, no dropped track, no device-side counter timeout
         xa, Pa = h.get_state()
         xl, Pl = lit.get_state()
         worst = max(worst, S.state_delta(xa, xl))
@@ -151,5 +152,5 @@ def test_whole_frame_with_device_detector(gpu_required):
     xb, _ = s.get_state()
     info = h.frame_info()
     h.close()
-    assert info["updated"] == 1
+    assert info["updated"] == 1 and info["device_error"] == 0
     assert S.state_delta(xa, xb) <= 1e-6
