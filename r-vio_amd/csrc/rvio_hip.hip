@@ -1306,7 +1306,8 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
     HIPCHK(h, hipEventSynchronize(h->evPin[ps]));   // the copies issued from this slot three frames ago are done (no-op before its first use)
     HIPCHK(h, hipEventSynchronize(h->evPin2[ps]));
-    for (int y = 0; y < h->dc.H; ++y) std::memcpy(pp + (size_t)y * h->dc.W, img + (size_t)y * stride, (size_t)h->dc.W);
+    if (stride == h->dc.W) std::memcpy(pp, img, npx);   // (a continuous cv::Mat: one copy)
+    else for (int y = 0; y < h->dc.H; ++y) std::memcpy(pp + (size_t)y * h->dc.W, img + (size_t)y * stride, (size_t)h->dc.W);
     if (m > 0) std::memcpy(pp + h->pin_imu, imu, sizeof(rvio_imu) * m);
     if (nc > 0) std::memcpy(pp + pin_cand, cand_xy, sizeof(float) * 2 * nc);
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;
