@@ -927,7 +927,8 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->par];
         static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
-        if (h->runahead && h->frame_no >= 3 && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[(h->frame_no - 3) & 3], 0));
+        static const int ra_depth = getenv("RVIO_RA_DEPTH") ? std::max(1, std::min(3, atoi(getenv("RVIO_RA_DEPTH")))) : 3;   // A/B timing: 2 = the image chain waits for book-keeping(k-2)
+        if (h->runahead && h->frame_no >= (uint64_t)ra_depth && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[(h->frame_no - ra_depth) & 3], 0));
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
