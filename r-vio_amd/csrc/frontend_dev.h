@@ -27,6 +27,7 @@ struct TrackerDev {
     unsigned char* status;  // vInlierFlag               [F]
     float* tmp_feats; float* tmp_un; int* tmp_slot;      // next-frame order being built
     int* cand_acc;          // FindNewer accept flags    [F]
+    int* mid;               // book-keeping, hand-over half -> refill half: {first image?, survivors nIn, nMeas}
     float* cell_pts;        // ChessGrid cells           [cells][2F][2]
     // outputs: mvFeatTypesForUpdate / mvlFeatMeasForUpdate
     int* n_feat;
@@ -49,6 +50,6 @@ __device__ __forceinline__ void pyr_shift(PyrDev& p, size_t off) {
 __device__ __forceinline__ void tracker_shift(TrackerDev& t, size_t off) {
     zmove(t.first, off); zmove(t.n_pts, off); zmove(t.feats, off); zmove(t.un1, off); zmove(t.slot, off); zmove(t.hist, off); zmove(t.hist_len, off);
     zmove(t.tracked, off); zmove(t.un2, off); zmove(t.status, off); zmove(t.tmp_feats, off); zmove(t.tmp_un, off); zmove(t.tmp_slot, off);
-    zmove(t.cand_acc, off); zmove(t.cell_pts, off); zmove(t.n_feat, off); zmove(t.types, off); zmove(t.len, off); zmove(t.meas, off); zmove(t.info, off);
+    zmove(t.cand_acc, off); zmove(t.mid, off); zmove(t.cell_pts, off); zmove(t.n_feat, off); zmove(t.types, off); zmove(t.len, off); zmove(t.meas, off); zmove(t.info, off);
 }
 #endif

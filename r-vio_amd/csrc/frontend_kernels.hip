@@ -5,7 +5,7 @@
 //   pyramid_kernel    every level of the image pyramid in one launch (cv::pyrDown chain + the copy of the frame into level 0)
 //   (klt_kernel3      LKTrackerInvoker, all levels, one wave per feature — klt3.hip; CLAHE — clahe.hip; detector — detector.hip)
 //   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
-//   bookkeep_kernel   track book-keeping + FindNewer + refill        (Tracker.cc:271-393, FeatureDetector.cc:78-150)
+//   bookkeep_a_kernel, bookkeep_b_kernel   track book-keeping: the Updater's hand-over / FindNewer + refill (Tracker.cc:271-393, FeatureDetector.cc:78-150)
 #include "rvio_dev.h"
 #include "frontend_dev.h"
 #include "../../include/rvio_hip.h"
@@ -336,56 +336,35 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // Dynamic LDS: tfs[F] float2 (new feature order), cds[F] float2 (candidates), cid_t[F] / cid_c[F] short (grid cell
 // of each tracked point / candidate, -1 = outside), cellp[4][F] float2 (per-wave ChessGrid cell).
 // n_cand_dev != NULL: the corner count lives on the device (device detector), n_cand is ignored.
+// Track book-keeping in two launches (Tracker.cc:271-393):
+//   bookkeep_a_kernel   lost tracks -> type '1', tracks at the maximum length -> type '2', history roll, survivors in the new order:
+//                       everything the UPDATER needs (mvFeatTypesForUpdate / mvlFeatMeasForUpdate).  Needs KLT + RANSAC only.
+//   bookkeep_b_kernel   FindNewer / ChessGrid refill with the detector's corners, the list of features to track next (and the seeding of
+//                       the first image).  Needs the detector — which is the long pole of the front end (CLAHE + GFTT + cornerSubPix
+//                       ~160 us against ~90 us for pyramid + KLT + RANSAC): with the hand-over out before it finishes, the filter of a frame
+//                       starts ~70 us earlier (pose latency), and in the pipelined path it no longer depends on the image chain at all.
 // done / done_target (single instance, run-ahead mode): the device-side counter the filter of frame k-2 bumps when its last kernel has
-// finished (tail.hip) — the hand-over tables this kernel rewrites are free then.  A stream-level event in its place costs the FILTER
-// stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
-__global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
-                                                       const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
-    extern __shared__ __align__(16) unsigned char dsh[];
+// finished (rvio_dev.h TailSync) — the hand-over tables the first kernel rewrites are free then.  A stream-level event in its place costs the
+// FILTER stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
+__global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev t, size_t bs,
+                                                         const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     DBG_S(blockIdx.z == 0, 3);
     if (done) tail_wait(done, done_target, meta);
     DBG_S(blockIdx.z == 0, 4);
-    tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
+    tracker_shift(t, (size_t)blockIdx.z * bs);
     __shared__ int s_w[4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, Fu = cfg.Fu, ML = cfg.max_len;
-    float2* tfs = (float2*)dsh;
-    float2* cds = tfs + F;
-    short* cid_t = (short*)(cds + F);
-    short* cid_c = cid_t + F;
-    float2* cellp = (float2*)(dsh + (((size_t)20 * F + 7) & ~(size_t)7));        // 8-byte aligned
+    const int tid = threadIdx.x, Fu = cfg.Fu, ML = cfg.max_len;
     const int N = *t.n_pts;
     const int first = *t.first;
     float2* hist = (float2*)t.hist;
     float2* meas = (float2*)t.meas;
     const float2* tr2 = (const float2*)t.tracked;
     const float2* un2 = (const float2*)t.un2;
-    float2* feats = (float2*)t.feats;
-    float2* un1 = (float2*)t.un1;
+    float2* tfs = (float2*)t.tmp_feats;
     float2* tu = (float2*)t.tmp_un;
-    if (n_cand_dev) n_cand = *n_cand_dev;
-    const int nc = n_cand < F ? n_cand : F;
-    for (int c = tid; c < nc; c += 256) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
     int nMeas = 0;
-    if (first) {
-        // first image, Tracker.cc:204-234: seed every slot with a detector corner
-        __syncthreads();
-        const int n0 = nc;
-        for (int i = tid; i < F; i += 256) {
-            if (i < n0) {
-                float ux, uy;
-                undistort_pt(cfg, cds[i].x, cds[i].y, &ux, &uy);
-                feats[i] = cds[i];
-                un1[i] = make_float2(ux, uy);
-                hist[(size_t)i * ML] = make_float2(ux, uy);
-                t.hist_len[i] = 1; t.slot[i] = i;
-            } else t.hist_len[i] = 0;
-        }
-        if (tid == 0) {
-            *t.n_pts = n0; *t.n_feat = 0;
-            if (n0 > 0) { *t.first = 0; if (t.first_host) t.first_host[blockIdx.z] = 0; }
-            t.info->n_tracked_in = 0; t.info->n_klt_ok = 0; t.info->n_ransac_inliers = 0; t.info->ransac_winner = 0;
-            t.info->n_tracked_out = n0; t.info->n_feat_update = 0;
-        }
+    if (first) {   // first image (Tracker.cc:204-234): nothing to hand over, the refill half seeds the slots
+        if (tid == 0) { t.mid[0] = 1; t.mid[1] = 0; t.mid[2] = 0; *t.n_feat = 0; t.info->n_feat_update = 0; }
         return;
     }
     // ---- lost tracks -> type '1' (Tracker.cc:279-303), in feature order
@@ -434,6 +413,50 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
         nMeas = (nMeas + tot2 < Fu) ? nMeas + tot2 : Fu;
         nIn += totT;
     }
+    if (tid == 0) { t.mid[0] = 0; t.mid[1] = nIn; t.mid[2] = nMeas; *t.n_feat = nMeas; t.info->n_feat_update = nMeas; }
+}
+
+__global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs) {
+    extern __shared__ __align__(16) unsigned char dsh[];
+    tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, ML = cfg.max_len;
+    float2* tfs = (float2*)dsh;
+    float2* cds = tfs + F;
+    short* cid_t = (short*)(cds + F);
+    short* cid_c = cid_t + F;
+    float2* cellp = (float2*)(dsh + (((size_t)20 * F + 7) & ~(size_t)7));        // 8-byte aligned
+    const int first = t.mid[0], nIn = t.mid[1];
+    float2* hist = (float2*)t.hist;
+    float2* feats = (float2*)t.feats;
+    float2* un1 = (float2*)t.un1;
+    float2* tu = (float2*)t.tmp_un;
+    if (n_cand_dev) n_cand = *n_cand_dev;
+    const int nc = n_cand < F ? n_cand : F;
+    for (int c = tid; c < nc; c += 256) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
+    if (first) {
+        // first image, Tracker.cc:204-234: seed every slot with a detector corner
+        __syncthreads();
+        const int n0 = nc;
+        for (int i = tid; i < F; i += 256) {
+            if (i < n0) {
+                float ux, uy;
+                undistort_pt(cfg, cds[i].x, cds[i].y, &ux, &uy);
+                feats[i] = cds[i];
+                un1[i] = make_float2(ux, uy);
+                hist[(size_t)i * ML] = make_float2(ux, uy);
+                t.hist_len[i] = 1; t.slot[i] = i;
+            } else t.hist_len[i] = 0;
+        }
+        if (tid == 0) {
+            *t.n_pts = n0;
+            if (n0 > 0) { *t.first = 0; if (t.first_host) t.first_host[blockIdx.z] = 0; }
+            t.info->n_tracked_in = 0; t.info->n_klt_ok = 0; t.info->n_ransac_inliers = 0; t.info->ransac_winner = 0;
+            t.info->n_tracked_out = n0;
+        }
+        return;
+    }
+    for (int i = tid; i < nIn; i += 256) tfs[i] = ((const float2*)t.tmp_feats)[i];   // the survivors, in the order the first half gave them
     __syncthreads();
     // ---- refill (Tracker.cc:344-387) through FindNewer/ChessGrid (FeatureDetector.cc:78-150)
     int nNew = 0;
@@ -532,10 +555,7 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(DevCfg cfg, TrackerDev t,
     const int nOut = nIn + nNew;
     for (int i = tid; i < nOut; i += 256) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
     DBG_S(blockIdx.z == 0, 5);
-    if (tid == 0) {
-        *t.n_pts = nOut; *t.n_feat = nMeas;
-        t.info->n_tracked_out = nOut; t.info->n_feat_update = nMeas;
-    }
+    if (tid == 0) { *t.n_pts = nOut; t.info->n_tracked_out = nOut; }
 }
 
 // direct-track mode: the caller supplies vFeatsTracked / vInlierFlag (the KLT result)

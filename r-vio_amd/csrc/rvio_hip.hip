@@ -33,6 +33,7 @@ struct rvio_hip {
     hipStream_t stream_t = nullptr;   // tracker stream of the pipelined whole-frame path
     hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
     hipEvent_t evT[4] = {nullptr, nullptr, nullptr, nullptr};   // book-keeping(k) done: a ring by frame number (the image chain of frame k waits for frame k-3's)
+    hipEvent_t evH[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-over of frame k written (bookkeep_a_kernel): what the filter of frame k waits for
     hipEvent_t evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
     long frame_no = 0;
     bool piped = false, in_frame = false;
@@ -79,6 +80,7 @@ struct rvio_hip {
     int fin_mode[2] = {0, 0};
     unsigned long long fin_target[2] = {0, 0}, book_target = 0;
     bool book_dev = false;
+    bool handover_evt = false;        // frame in flight: evH was recorded behind the hand-over half of book-keeping
     bool last_ra = false;             // the previous rvio_hip_frame call ran in run-ahead mode
     float* hb_cand[2] = {nullptr, nullptr};
     // pinned host ring of rvio_hip_frame: the caller's (pageable) buffers are packed into it on the host, the H2D copies then run
@@ -286,7 +288,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, t.hist, (size_t)2 * d.F * d.max_len); DALLOC(h, t.hist_len, d.F);
     DALLOC(h, t.tracked, (size_t)2 * d.F); DALLOC(h, t.un2, (size_t)2 * d.F); DALLOC(h, t.status, d.F);
     DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
-    DALLOC(h, t.cand_acc, d.F);
+    DALLOC(h, t.cand_acc, d.F); DALLOC(h, t.mid, 4);
     DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
     DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
     DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
@@ -337,6 +339,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b + 2], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evH[b], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evH[b + 2], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], kEvFlags));
     }
@@ -408,7 +412,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
         if (h->solve_use_lds) {
             HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -474,7 +478,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
     if (h->stream_c && !h->one_stream) hipStreamDestroy(h->stream_c);
     for (int b = 0; b < 2; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
-    for (int b = 0; b < 4; ++b) if (h->evT[b]) hipEventDestroy(h->evT[b]);
+    for (int b = 0; b < 4; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evH[b]) hipEventDestroy(h->evH[b]); }
     for (int b = 0; b < 2; ++b) { if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
     if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -981,26 +985,32 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
     h->tail = h->ts;
+    h->handover_evt = false;
     const unsigned long long* done = nullptr; unsigned long long done_target = 0;
     if (h->use_det) {   // the detector's corner list replaces the caller's
         const float* xy = h->det_xy2[h->dslot];
         const int* nout = h->det_nout + h->dslot;
-        if (h->runahead) {   // book-keeping on the side stream, behind RANSAC, once the corners are there and filter(k-2) has let go of the hand-over
+        if (h->runahead) {   // book-keeping on the side stream, behind RANSAC: the hand-over half once filter(k-2) has let go of the tables, the refill half once the corners are there
             static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
             if (h->book_wait && !(dbg_skip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
             h->book_wait = nullptr;
             if (h->book_dev && !(dbg_skip & 4)) { done = &h->tail_sync->aug; done_target = h->book_target; }
             h->book_dev = false;
-            HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
             h->tail = h->side;
+            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta);
+            HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));   // the Updater's input is complete: the filter of this frame waits for THIS
+            h->handover_evt = true;
+            HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
         } else {             // join the side stream (long finished when the detector is)
             HIPCHK(h, hipEventRecord(h->evD1, h->side));
             HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
+            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta);
         }
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs, done, done_target, h->meta);
-    } else
-        hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0,
-                           (const unsigned long long*)nullptr, 0ull, h->meta);
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs);
+    } else {
+        hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1), dim3(256), 0, h->ts, h->dc, h->t, (size_t)0, (const unsigned long long*)nullptr, 0ull, h->meta);
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0);
+    }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -1215,7 +1225,8 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const double t2 = dbg_host ? now() : 0;
     static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
     HIPCHK(h, hipEventRecord(h->evT[h->frame_no & 3], h->tail));      // behind book-keeping, on the stream that ran it
-    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evT[h->frame_no & 3], 0));
+    // the filter needs the hand-over, not the refill: in run-ahead mode it waits for the first half of book-keeping only
+    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
