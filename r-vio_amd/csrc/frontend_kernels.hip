@@ -222,10 +222,9 @@ __device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  /
 // UndistortAndNormalize of the tracked points + Ransac::FindInliers.  One workgroup, 256 threads.
 // un1: previous-frame normalised coords (mPoints1ForRansac, z = 1), un2: output for this frame.
 // Dynamic LDS: cand[F] ints + used[F] bytes.
-__global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
-                                                     unsigned char* status, const rvio_imu* imu, int m, int* rng,
-                                                     rvio_frame_info* info, size_t bs, size_t imu_bs) {
-    extern __shared__ __align__(16) unsigned char dsh[];
+__device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
+                                            unsigned char* status, const rvio_imu* imu, int m, int* rng,
+                                            rvio_frame_info* info, size_t bs, size_t imu_bs, unsigned char* dsh) {
     __shared__ int s_w[4];
     __shared__ int pairs[16][2];
     DBG_S(blockIdx.z == 0, 2);
@@ -329,6 +328,12 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
     __syncthreads();
     if (tid == 0) { info->n_ransac_inliers = nc - s_newout; info->ransac_winner = s_winner; }
 }
+__global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
+                                                     unsigned char* status, const rvio_imu* imu, int m, int* rng,
+                                                     rvio_frame_info* info, size_t bs, size_t imu_bs) {
+    extern __shared__ __align__(16) unsigned char dsh_r[];
+    ransac_body(cfg, n_pts_ptr, tracked, un1, un2, status, imu, m, rng, info, bs, imu_bs, dsh_r);
+}
 
 // ------------------------------------------------------------------ T6 book-keeping + refill
 // One workgroup, 256 threads.  Track histories are per-slot arrays hist[F][max_len] (float2) with
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // done / done_target (single instance, run-ahead mode): the device-side counter the filter of frame k-2 bumps when its last kernel has
 // finished (rvio_dev.h TailSync) — the hand-over tables the first kernel rewrites are free then.  A stream-level event in its place costs the
 // FILTER stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
-__global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev t, size_t bs,
-                                                         const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
+__device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t, size_t bs,
+                                                const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     DBG_S(blockIdx.z == 0, 3);
     if (done) tail_wait(done, done_target, meta);
     DBG_S(blockIdx.z == 0, 4);
@@ -414,6 +419,20 @@ __global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev 
         nIn += totT;
     }
     if (tid == 0) { t.mid[0] = 0; t.mid[1] = nIn; t.mid[2] = nMeas; *t.n_feat = nMeas; t.info->n_feat_update = nMeas; }
+}
+__global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev t, size_t bs,
+                                                         const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
+    bookkeep_a_body(cfg, t, bs, done, done_target, meta);
+}
+// RANSAC and the hand-over half of book-keeping in ONE launch (both are one-workgroup stages of the side stream's serial chain, nothing
+// separates them since the hand-over does not wait for the detector): one launch boundary less before the filter may start
+__global__ __launch_bounds__(256) void ransac_book_a_kernel(DevCfg cfg, TrackerDev t, const rvio_imu* imu, int m, int* rng, size_t bs, size_t imu_bs,
+                                                            const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
+    extern __shared__ __align__(16) unsigned char dsh_ra[];
+    ransac_body(cfg, t.n_pts, t.tracked, t.un1, t.un2, t.status, imu, m, rng, t.info, bs, imu_bs, dsh_ra);
+    __threadfence_block();
+    __syncthreads();
+    bookkeep_a_body(cfg, t, bs, done, done_target, meta);
 }
 
 __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs) {

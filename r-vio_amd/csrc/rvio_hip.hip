@@ -982,6 +982,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
 static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
+    // run-ahead mode: RANSAC rides in the launch of book-keeping's hand-over half (both one workgroup, back to back on the side stream)
+    static const bool no_ra_fuse = getenv("RVIO_NO_FUSED_RANSAC") != nullptr;
+    const bool fused = h->use_det && h->runahead && !no_ra_fuse;
+    if (!fused)
     hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
     h->tail = h->ts;
@@ -997,6 +1001,10 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             if (h->book_dev && !(dbg_skip & 4)) { done = &h->tail_sync->aug; done_target = h->book_target; }
             h->book_dev = false;
             h->tail = h->side;
+            if (fused)
+                hipLaunchKernelGGL(ransac_book_a_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
+                                   done, done_target, h->meta);
+            else
             hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta);
             HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));   // the Updater's input is complete: the filter of this frame waits for THIS
             h->handover_evt = true;
