@@ -188,6 +188,39 @@ def test_frame_begin_end_split_equals_frame_dev(gpu_required, frames):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def test_pose_is_final_before_the_refill(gpu_required, frames):
+    """rvio_hip_get_pose waits for the filter stream only; in run-ahead mode (device detector) the filter of a frame starts behind the
+    hand-over half of book-keeping, before the detector and the refill half have finished.  The pose read right after the call must be the
+    pose read after a full synchronisation, and the run must end in the same state as one that synchronises after every frame."""
+    from rvio_amd import hip
+    import torch
+    cfg, seq, ks, imgs = frames
+    w, a, n = seq.init_from_static(38)
+    res = []
+    for sync_each in (False, True):
+        h = hip.RvioHip(cfg)
+        h.initialize(w, a, n)
+        keep = []
+        for k, img in zip(ks, imgs):
+            imu = seq.imu_between(k)
+            d_img = torch.from_numpy(img).cuda()
+            d_imu = torch.from_numpy(imu.view(np.uint8)).cuda()
+            keep += [d_img, d_imu]
+            torch.cuda.synchronize()
+            h.frame_dev(d_img.data_ptr(), img.shape[1], d_imu.data_ptr(), len(imu), 0, 0)     # NULL corner list: device detector, run-ahead
+            p0, q0 = h.pose()
+            if sync_each:
+                h.sync()
+                p1, q1 = h.pose()
+                assert np.array_equal(p0, p1) and np.array_equal(q0, q1), k
+        h.sync()
+        info = h.frame_info()
+        res.append(h.get_state())
+        h.close()
+        assert info["device_error"] == 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_whole_frame_with_images(gpu_required, frames):
     """System::MonoVIO body on images: HIP vs oracle states within 1e-6 over the sequence."""
     from rvio_amd import hip
