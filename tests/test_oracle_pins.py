@@ -603,3 +603,33 @@ def test_klt_against_an_independent_numpy_lucas_kanade():
         x, y, s = _lk_numpy(Ip, Dp, Jp, p)
         assert s == st[i], i
         assert np.float32(x) == want[i, 0] and np.float32(y) == want[i, 1], (i, x, y, want[i])
+
+
+def test_triangulation_reaches_the_minimum_of_the_reprojection_cost():
+    """U2 (Updater.cc:143-269): the inverse-depth LM estimate (phi, psi, rho) of a type-'1' feature (every observation enters both the
+    triangulation and the residual) is a stationary point of the reprojection cost — Hf^T r = 0 to the noise floor of the float32
+    residual — and scipy's trust-region least squares, started from a perturbed triple and using only the residual function, ends at the
+    same point.  Independent of the oracle's own normal equations, damping schedule and stopping rule.  (Tracks: the hand-over of a
+    simulated sequence, i.e. geometrically consistent observations with pixel noise.)"""
+    from scipy.optimize import least_squares
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq, recs = S.record_sequence(cfg, n_frames=30)
+    done = 0
+    for rec in recs[-6:]:
+        if rec.get("types") is None:
+            continue
+        x, types, lens, meas = rec["x1"], rec["types"], rec["lens"], rec["meas"]
+        for f in range(len(types)):
+            if types[f] != ord("1") or lens[f] < 5 or done >= 12:
+                continue
+            r0, _, Hf, pf = O.feature_model(cfg, x, types[f], meas[f], lens[f])
+            g = Hf.T @ r0
+            assert np.linalg.norm(g) <= 1e-4 * np.linalg.norm(Hf) * np.linalg.norm(r0), (f, g)
+            if done < 4:
+                fun = lambda p: O.feature_model(cfg, x, types[f], meas[f], lens[f], p)[0]            # noqa: E731
+                sol = least_squares(fun, pf * np.array([1.02, 0.98, 1.3]) + np.array([1e-3, -1e-3, 0.0]), method="trf", diff_step=1e-5,
+                                    xtol=1e-12, ftol=1e-12, gtol=1e-12)
+                assert np.abs(sol.x[:2] - pf[:2]).max() < 2e-4 and abs(sol.x[2] - pf[2]) < 2e-3 * max(abs(pf[2]), 1e-3), (f, sol.x, pf)
+                assert np.linalg.norm(fun(sol.x)) >= np.linalg.norm(r0) * (1 - 1e-4)           # scipy finds nothing better
+            done += 1
+    assert done >= 8
