@@ -679,7 +679,13 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         else hipLaunchKernelGGL((solve7_kernel<1, 16, 4>), gb, dim3(256), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
         return;
     }
-    case 2: hipLaunchKernelGGL((solve7_kernel<2, 12, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+    case 2: {
+        static const int nw2 = getenv("RVIO_S7_V2") ? atoi(getenv("RVIO_S7_V2")) : 12;   // waves of the 6n <= 96 form (measured at 6n = 84: 8 -> 109 us, 12 -> 102, 16 -> 119)
+        if (nw2 == 16) hipLaunchKernelGGL((solve7_kernel<2, 6, 16>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        else if (nw2 == 12) hipLaunchKernelGGL((solve7_kernel<2, 8, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        else hipLaunchKernelGGL((solve7_kernel<2, 12, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
+        return;
+    }
     case 3: hipLaunchKernelGGL((solve7_kernel<2, 16, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     case 4: hipLaunchKernelGGL((solve7_kernel<3, 16, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     default: break;
