@@ -8,7 +8,10 @@
 //   gemm_T_kernel        FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
 //   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG)
 //   final_kernel         P+ = sym( P1 - P1c G^T + s2 G U^T )   (Joseph form, Updater.cc:615-619)
-// (propagate / augmentation + composition: filter_kernels2.hip; W = T^-1, dx, state injection: solve6.hip / solve4.hip)
+//   ug_lds_kernel, final_lds_kernel
+//                        the same two stages for ONE instance with 6n <= 64: every operand of a workgroup staged in LDS by one batch of loads
+// (propagate / augmentation + composition: filter_kernels2.hip; T, W = T^-1, dx, state injection: solve7.hip — solve6.hip / solve4.hip behind
+//  gemm_T_kernel for batch handles and as A/B forms)
 //
 // Design rules learnt from the first profile (profiles/r01_a): every kernel front-loads its
 // global reads in one batch (a dependent global load after a kernel boundary costs 1-2 us),

@@ -1,5 +1,7 @@
-// filter_kernels2.hip — single-workgroup kernels of the filter path (propagate, augmentation + composition) and the
-// MFMA Gram kernel of the compression.
+// filter_kernels2.hip — the filter path's kernels around the update:
+//   propagate_kernel3 / propagate_kernel3b   PreIntegrator::propagate, one workgroup per instance (b: two workgroups per CU, batch handles)
+//   feat_prop_kernel                          feat_build_kernel<16> + propagate as one more workgroup (pipelined single-stream path)
+//   augcomp_kernel2                           augmentation / slide + composition (System.cc:279-365); bumps the filter's completion counter
 // Rules applied (profiles/r01_*): no dynamic indexing of register arrays (it lands in scratch),
 // __restrict__ on every pointer, sparsity of Phi / Vk exploited (the LDS port of ONE CU is the
 // limiter), no loops over dependent global loads.

@@ -4,7 +4,8 @@
 //
 //   pyramid_kernel    every level of the image pyramid in one launch (cv::pyrDown chain + the copy of the frame into level 0)
 //   (klt_kernel3      LKTrackerInvoker, all levels, one wave per feature — klt3.hip; CLAHE — clahe.hip; detector — detector.hip)
-//   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247)
+//   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247); ransac_book_a_kernel = the same
+//                     + bookkeep_a_kernel's body in one launch (run-ahead path)
 //   bookkeep_a_kernel, bookkeep_b_kernel   track book-keeping: the Updater's hand-over / FindNewer + refill (Tracker.cc:271-393, FeatureDetector.cc:78-150)
 #include "rvio_dev.h"
 #include "frontend_dev.h"
