@@ -324,5 +324,5 @@ __global__ __launch_bounds__(256) void augcomp_kernel2(DevCfg cfg, int n, int do
     DBG_R(blockIdx.x == 0, 6);
     // done (single instance): every workgroup bumps the device-side completion counter of the filter chain — the frame's filter has
     // finished when all of them have (bookkeep_a_kernel of frame k+2 polls it instead of waiting for an event behind this kernel)
-    if (done) tail_signal(done);
+    if (done) stage_signal(done);
 }

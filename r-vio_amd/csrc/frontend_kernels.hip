@@ -350,12 +350,12 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 //                       ~160 us against ~90 us for pyramid + KLT + RANSAC): with the hand-over out before it finishes, the filter of a frame
 //                       starts ~70 us earlier (pose latency), and in the pipelined path it no longer depends on the image chain at all.
 // done / done_target (single instance, run-ahead mode): the device-side counter the filter of frame k-2 bumps when its last kernel has
-// finished (rvio_dev.h TailSync) — the hand-over tables the first kernel rewrites are free then.  A stream-level event in its place costs the
+// finished (rvio_dev.h StageSync) — the hand-over tables the first kernel rewrites are free then.  A stream-level event in its place costs the
 // FILTER stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
 __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t, size_t bs,
                                                 const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     DBG_S(blockIdx.z == 0, 3);
-    if (done) tail_wait(done, done_target, meta);
+    if (done) stage_wait(done, done_target, meta);
     DBG_S(blockIdx.z == 0, 4);
     tracker_shift(t, (size_t)blockIdx.z * bs);
     __shared__ int s_w[4];

@@ -231,14 +231,14 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
 }
 
 // ---------------------------------------------------------------- device-side completion counter (augcomp_kernel2 -> bookkeep_kernel)
-struct TailSync { unsigned long long aug; };   // device memory, zero at creation: bumped by every workgroup of the last kernel of a frame's filter chain
+struct StageSync { unsigned long long aug; };   // device memory, zero at creation: bumped by every workgroup of the last kernel of a frame's filter chain
 // every thread of the workgroup calls these
-__device__ __forceinline__ void tail_signal(unsigned long long* c) {
+__device__ __forceinline__ void stage_signal(unsigned long long* c) {
     __threadfence();                         // each wave: its stores written back and performed at agent scope
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tail_wait(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
+__device__ __forceinline__ void stage_wait(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
     if (threadIdx.x == 0) {
         int it = 0;
         while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {

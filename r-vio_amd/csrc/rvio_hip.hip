@@ -55,8 +55,8 @@ struct rvio_hip {
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
-    TailSync* tail_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
-    TailSync tail_tgt = {0};
+    StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
+    StageSync stage_tgt = {0};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
@@ -76,7 +76,7 @@ struct rvio_hip {
     rvio_imu* hb_imu[3] = {nullptr, nullptr, nullptr};   // (run-ahead mode rotates three slots: see rvio_hip_frame)
     hipEvent_t book_wait = nullptr;   // run-ahead: the event book-keeping of the frame in flight has to wait for (filter k-2)
     // how "the filter of the frame with parity b has finished" is known: 0 = evF[b] was recorded behind it, 1 = the device-side counter
-    // tail_sync->aug reaches fin_target[b] (single instance, run-ahead mode: no marker packet on the filter stream)
+    // stage_sync->aug reaches fin_target[b] (single instance, run-ahead mode: no marker packet on the filter stream)
     int fin_mode[2] = {0, 0};
     unsigned long long fin_target[2] = {0, 0}, book_target = 0;
     bool book_dev = false;
@@ -253,7 +253,7 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->block, 2 * ldh * ldh);   // [S2 | S1]: the type-'2' and type-'1' sums of the information block (gram_reduce_kernel)
     DALLOC(h, h->Ab, 2 * ldh * ldh);
     DALLOC(h, h->gram_cnt, 8);
-    DALLOC(h, h->tail_sync, 1);
+    DALLOC(h, h->stage_sync, 1);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
@@ -794,7 +794,7 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const int c = h->cur, o = c ^ 1;
     const int cg = 1 + std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256));
     unsigned long long* done = nullptr;
-    if (h->batch == 1) { done = &h->tail_sync->aug; h->tail_tgt.aug += (unsigned long long)cg; }
+    if (h->batch == 1) { done = &h->stage_sync->aug; h->stage_tgt.aug += (unsigned long long)cg; }
     hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
                        h->slab_bytes, done);
     HIPCHK(h, hipGetLastError());
@@ -1004,7 +1004,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
             if (h->book_wait && !(dbg_skip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
             h->book_wait = nullptr;
-            if (h->book_dev && !(dbg_skip & 4)) { done = &h->tail_sync->aug; done_target = h->book_target; }
+            if (h->book_dev && !(dbg_skip & 4)) { done = &h->stage_sync->aug; done_target = h->book_target; }
             h->book_dev = false;
             h->tail = h->side;
             if (fused)
@@ -1250,7 +1250,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     // the filter of this frame is finished when ... single instance in run-ahead mode: its last kernel has bumped the device-side counter
     // (book-keeping of frame k+2 polls it); otherwise an event behind it
     static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr;
-    if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->tail_tgt.aug; }
+    if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->stage_tgt.aug; }
     else { if (!(dbg_skip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
     if (dbg_host) {
         const double t5 = now();
