@@ -66,6 +66,77 @@ class DeviceArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+class FrameSet:
+    """A rendered input sequence resident in HBM + the only place where a frame index becomes a device pointer: `args(i)` checks
+    0 <= i < n before any arithmetic (a bad device pointer cannot be caught afterwards — the GPU faults and the process aborts)."""
+
+    def __init__(self, torch, cfg, imgs, imu_arr, imu_cnt, cand_arr=None, cand_cnt=None):
+        self.n = int(len(imgs))
+        self.cfg = cfg
+        self.imgs, self.imu_arr, self.imu_cnt = imgs, imu_arr, np.asarray(imu_cnt)
+        self.cand_arr = cand_arr
+        self.cand_cnt = np.zeros(self.n, np.int32) if cand_arr is None else np.asarray(cand_cnt)
+        assert len(imu_arr) == self.n and len(self.imu_cnt) == self.n and len(self.cand_cnt) == self.n
+        self.d_imgs = torch.from_numpy(imgs).cuda()
+        self.d_imu = torch.from_numpy(imu_arr.view(np.uint8).reshape(self.n, -1)).cuda()
+        self.d_cand = None if cand_arr is None else torch.from_numpy(cand_arr).cuda()
+        self.isb = cfg.width * cfg.height
+        self.msb = int(self.d_imu.shape[1])
+        self.csb = 0 if cand_arr is None else cfg.n_features * 2 * 4
+        self.p_img, self.p_imu = self.d_imgs.data_ptr(), self.d_imu.data_ptr()
+        self.p_cand = 0 if cand_arr is None else self.d_cand.data_ptr()
+        assert self.d_imgs.numel() == self.n * self.isb
+
+    @classmethod
+    def fake(cls, cfg, n, m=10, base=1 << 40):
+        """no device: made-up base addresses, for the CPU test that walks every leg's index arithmetic (tests/test_bench_helpers.py)"""
+        self = cls.__new__(cls)
+        self.n, self.cfg = int(n), cfg
+        self.imgs = np.zeros((n, 1, 1), np.uint8)
+        self.imu_arr = np.zeros((n, m), dtype=abi.IMU_DTYPE)
+        self.imu_cnt = np.full(n, m, np.int32)
+        self.cand_arr, self.cand_cnt = None, np.zeros(n, np.int32)
+        self.isb, self.msb, self.csb = cfg.width * cfg.height, m * abi.IMU_DTYPE.itemsize, 0
+        self.p_img, self.p_imu, self.p_cand = base, 2 * base, 0
+        return self
+
+    def check(self, i):
+        i = int(i)
+        if not 0 <= i < self.n:
+            raise IndexError("frame index %d outside the resident sequence [0, %d)" % (i, self.n))
+        return i
+
+    def args(self, i):
+        """(d_img, stride, d_imu, m, d_cand, n_cand) of frame i for rvio_hip_frame_dev / rvio_hip_track_dev"""
+        i = self.check(i)
+        return (self.p_img + i * self.isb, self.cfg.width, self.p_imu + i * self.msb, int(self.imu_cnt[i]),
+                self.p_cand + i * self.csb, int(self.cand_cnt[i]))
+
+    def host(self, i):
+        """(img, imu, cand) of frame i as host arrays for rvio_hip_frame"""
+        i = self.check(i)
+        return self.imgs[i], self.imu_arr[i, : self.imu_cnt[i]], None if self.cand_arr is None else self.cand_arr[i, : self.cand_cnt[i]]
+
+
+def pose_latency_plan(n_frames, max_track_len, want=60, min_timed=8):
+    """(n_warm, n_timed) of the pose-latency leg for a resident sequence of n_frames frames, or None when the sequence is too short to
+    fill the window first (the leg then runs on the longer parity sequence).  0 <= n_warm, n_warm + n_timed <= n_frames always."""
+    n_warm = 3 * max_track_len + 10
+    if n_frames < n_warm + min_timed:
+        return None
+    return n_warm, min(want, n_frames - n_warm)
+
+
+def safe_leg(out, key, fn, *a, **kw):
+    """A secondary leg never costs the headline: a Python-level failure becomes {"error": ...} in its object."""
+    try:
+        out[key] = fn(*a, **kw)
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out[key] = {"error": repr(e)[:300], "where": traceback.format_exc().strip().splitlines()[-3:][0].strip()[:200]}
+    return out[key]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,23 +181,18 @@ def main():
     # Tracker.EnableEqualizer: 1 in the stock config (config/rvio_euroc.yaml): CLAHE runs on every frame
     cfg = abi.config_named(args.config, enable_equalizer=0 if args.no_equalizer else 1)
     K, W = args.steps, args.warmup
+    if K < 1 or W < 0:
+        raise SystemExit("--steps >= 1 and --warmup >= 0")
     n_frames = 1 + W + K   # first image (seed) + warmup + timed
     seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt = build_inputs(cfg, n_frames)
+    if not args.host_corners:
+        # stock behaviour: FeatureDetector::DetectWithSubPix runs inside the library (NULL corner list), also in the CPU baseline
+        cand_arr, cand_cnt = None, np.zeros_like(cand_cnt)
 
     h = hip.RvioHip(cfg, device=local_rank)
     stream = torch.cuda.ExternalStream(h.stream(), device=torch.device("cuda", local_rank))
-    d_imgs = torch.from_numpy(imgs).cuda()
-    d_imu = torch.from_numpy(imu_arr.view(np.uint8).reshape(n_frames, -1)).cuda()
-    d_cand = torch.from_numpy(cand_arr).cuda()
+    fs = FrameSet(torch, cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt)
     torch.cuda.synchronize()
-    img_stride_b = cfg.width * cfg.height
-    imu_stride_b = d_imu.shape[1]
-    cand_stride_b = cfg.n_features * 2 * 4
-    p_img, p_imu, p_cand = d_imgs.data_ptr(), d_imu.data_ptr(), d_cand.data_ptr()
-    if not args.host_corners:
-        # stock behaviour: FeatureDetector::DetectWithSubPix runs inside the library (NULL corner list), also in the CPU baseline
-        p_cand, cand_stride_b, cand_arr = 0, 0, None
-        cand_cnt = np.zeros_like(cand_cnt)
 
     wi, ai, ni = seq.init_from_static(K0)
     h.initialize(wi, ai, ni)
@@ -149,11 +215,10 @@ def main():
 
     def frame(i):
         if not sharded:
-            h.frame_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
+            h.frame_dev(*fs.args(i))
         else:
             # pipelined like N=1; the all-gather is enqueued on the handle's filter stream (no host synchronisation per frame)
-            h.frame_sharded_piped(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b,
-                                  int(cand_cnt[i]), rank, world, gathered, dist, DeviceArray, torch, stream, force_collective=args.force_sharded, comm=comm)
+            h.frame_sharded_piped(*fs.args(i), rank, world, gathered, dist, DeviceArray, torch, stream, force_collective=args.force_sharded, comm=comm)
 
     for i in range(1 + W):
         frame(i)
@@ -202,91 +267,119 @@ def main():
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated", "device_error")},
     }
 
-    if sharded and not args.no_streams:
-        # beside the sharded figure: every rank ALSO runs the same K frames as an independent camera stream on its own handle (N cameras
-        # on N GPUs, no collective) — the weak-scaling counterpart of `value`, reported in its own object
-        h2 = hip.RvioHip(cfg, device=local_rank)
-        h2.initialize(wi, ai, ni)
+    # the long sequence the parity leg, the CPU baseline and (when --steps is short) the pose-latency leg run on: >= PARITY_FRAMES
+    # frames whatever --steps says (the reference's rank truncation first bites at frame 51 of the stock sequence: a 26-frame
+    # comparison would not see it, and a 10-clone window is not even full after 26 frames)
+    long_in = None
 
-        def frame2(i):
-            h2.frame_dev(p_img + i * img_stride_b, cfg.width, p_imu + i * imu_stride_b, int(imu_cnt[i]), p_cand + i * cand_stride_b, int(cand_cnt[i]))
-        for i in range(1 + W):
-            frame2(i)
-        h2.sync()
+    def long_inputs():
+        nonlocal long_in
+        if long_in is None:
+            if n_frames >= PARITY_FRAMES:
+                long_in = (imgs, imu_arr, imu_cnt, cand_arr, cand_cnt)
+            else:
+                _, pi, pa, pc, pca, pcc = build_inputs(cfg, PARITY_FRAMES)
+                long_in = (pi, pa, pc, pca, pcc) if args.host_corners else (pi, pa, pc, None, np.zeros_like(pcc))
+        return long_in
+
+    if sharded and not args.no_streams:
+        def side_modes():
+            # beside the sharded figure: every rank ALSO runs the same K frames as an independent camera stream on its own handle (N cameras
+            # on N GPUs, no collective) — the weak-scaling counterpart of `value`, reported in its own object
+            h2 = hip.RvioHip(cfg, device=local_rank)
+            h2.initialize(wi, ai, ni)
+            for i in range(1 + W):
+                h2.frame_dev(*fs.args(i))
+            h2.sync()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(1 + W, n_frames):
+                h2.frame_dev(*fs.args(i))
+            h2.sync()
+            if world > 1:
+                dist.barrier()
+            el2 = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el2 = float(tt.item())
+            h2.close()
+            out["independent_streams"] = {"value": world * K / el2, "unit": "frames/s", "scaling": "weak",
+                                          "note": "one camera stream per GPU, no collective; `value` above is ONE stream with its updater sharded over the GPUs"}
+            # the multi-GPU mode that pays at this window size: a FLEET of filter instances sharded by instance —
+            # rank r owns instances r, r + N, ... of a fixed fleet, one batch handle per GPU, no collective at all (strong scaling of the fleet)
+            fleet = 2048
+            per = max(1, fleet // world)
+            leg = batched_filter_leg(cfg, torch, [per], name=args.config, seed0=4 * rank, barrier=(dist.barrier if world > 1 else None))
+            el3 = torch.tensor([leg["sizes"][0]["ms_per_batched_frame"]], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+            ms = float(el3.item())
+            out["instance_sharded_fleet"] = {"instances_total": per * world, "instances_per_gpu": per, "ms_per_fleet_frame": ms,
+                                             "filter_frames_per_s": per * world / (ms * 1e-3), "scaling": "strong", "collectives_per_frame": 0,
+                                             "algorithmic_mflop_per_filter_frame": leg["algorithmic_mflop_per_filter_frame"],
+                                             "achieved_tflops_fp64_per_gpu": leg["algorithmic_mflop_per_filter_frame"] * 1e6 * per / (ms * 1e-3) / 1e12,
+                                             "note": "rvio_hip_create_batch per GPU, instances r, r+N, ... of a %d-instance fleet on rank r; max over ranks of the batched-frame time" % (per * world)}
         if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for i in range(1 + W, n_frames):
-            frame2(i)
-        h2.sync()
-        if world > 1:
-            dist.barrier()
-        el2 = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-        h2.close()
-        out["independent_streams"] = {"value": world * K / el2, "unit": "frames/s", "scaling": "weak",
-                                      "note": "one camera stream per GPU, no collective; `value` above is ONE stream with its updater sharded over the GPUs"}
-        # the multi-GPU mode that pays at this window size: a FLEET of filter instances sharded by instance —
-        # rank r owns instances r, r + N, ... of a fixed fleet, one batch handle per GPU, no collective at all (strong scaling of the fleet)
-        fleet = 2048
-        per = max(1, fleet // world)
-        leg = batched_filter_leg(cfg, torch, [per], name=args.config, seed0=4 * rank, barrier=(dist.barrier if world > 1 else None))
-        el3 = torch.tensor([leg["sizes"][0]["ms_per_batched_frame"]], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(el3, op=dist.ReduceOp.MAX)
-        ms = float(el3.item())
-        out["instance_sharded_fleet"] = {"instances_total": per * world, "instances_per_gpu": per, "ms_per_fleet_frame": ms,
-                                         "filter_frames_per_s": per * world / (ms * 1e-3), "scaling": "strong", "collectives_per_frame": 0,
-                                         "algorithmic_mflop_per_filter_frame": leg["algorithmic_mflop_per_filter_frame"],
-                                         "achieved_tflops_fp64_per_gpu": leg["algorithmic_mflop_per_filter_frame"] * 1e6 * per / (ms * 1e-3) / 1e12,
-                                         "note": "rvio_hip_create_batch per GPU, instances r, r+N, ... of a %d-instance fleet on rank r; max over ranks of the batched-frame time" % (per * world)}
+            side_modes()          # (collectives inside: a one-sided failure would dead-lock the group anyway)
+        else:
+            try:
+                side_modes()
+            except Exception as e:   # noqa: BLE001
+                out["independent_streams"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_streams:
         # (first of the extra legs: a process normally owns ONE handle.  HIP multiplexes its streams onto 4 hardware queues in creation
         # order; a handle created after dozens of other streams — the later legs — can find two of its three streams on one queue and
         # loses their overlap: 2.3 k instead of 4.1 k frames/s were measured for this leg when it ran last)
-        out["host_buffers"] = host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, 1 + W)
+        safe_leg(out, "host_buffers", host_buffer_leg, cfg, fs, wi, ai, ni, 1 + W)
     if rank == 0 and not args.no_latency:
         # (also at N>1: the per-kernel roofline is a property of one GPU; the other ranks wait in the barrier below)
-        out.update(latency_pass(h, cfg, torch, stream, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand,
-                                img_stride_b, imu_stride_b, cand_stride_b, K0, wi, ai, ni, device=local_rank))
-        x_single = out.pop("x_final")
+        x_single = None
+        try:
+            out.update(latency_pass(cfg, torch, fs, wi, ai, ni, device=local_rank, name=args.config))
+            x_single = out.pop("x_final")
+        except Exception as e:   # noqa: BLE001
+            out["latency_pass"] = {"error": repr(e)[:300]}
         if not sharded:
-            out["pose_latency_unpipelined"] = pose_latency_leg(cfg, n_frames, p_img, p_imu, imu_cnt, img_stride_b, imu_stride_b, wi, ai, ni, local_rank)
-        if sharded:   # the sharded updater against the same frames through the one-GPU updater (block sums in rank order: rounding only)
+            def pose_leg():
+                plan = pose_latency_plan(fs.n, cfg.max_track_len)
+                if plan is not None:
+                    return pose_latency_leg(cfg, fs, plan, wi, ai, ni, local_rank)
+                li = long_inputs()
+                plan = pose_latency_plan(len(li[0]), cfg.max_track_len)
+                if plan is None:
+                    return {"skipped": "window of %d clones needs %d frames to fill; %d resident" % (cfg.max_track_len - 1, 3 * cfg.max_track_len + 18, len(li[0]))}
+                fl = FrameSet(torch, cfg, *li)
+                return dict(pose_latency_leg(cfg, fl, plan, wi, ai, ni, local_rank), sequence="the %d-frame parity sequence (--steps too short to fill the window)" % fl.n)
+            safe_leg(out, "pose_latency_unpipelined", pose_leg)
+        if sharded and x_single is not None:   # the sharded updater against the same frames through the one-GPU updater (block sums in rank order: rounding only)
             out["max_state_delta_sharded_vs_single_gpu"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(x_single))))
-        if world > 1:
-            out.pop("x_at_cpu_frames", None)
+        out.pop("x_at_cpu_frames", None)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:
         if not args.no_streams:
-            out["multi_stream"] = multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, img_stride_b, imu_stride_b, cand_stride_b,
-                                               wi, ai, ni, n_frames, 1 + W, streams=args.streams, threads=args.stream_threads)
+            safe_leg(out, "multi_stream", multi_stream, cfg, fs, wi, ai, ni, 1 + W, streams=args.streams, threads=args.stream_threads)
         if not args.no_latency:
-            out["update_at_load"] = update_at_load_leg(cfg, torch, name=args.config)
+            safe_leg(out, "update_at_load", update_at_load_leg, cfg, torch, name=args.config)
         if args.batch_streams:
-            out["batched_streams"] = batched_streams_leg(cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
+            safe_leg(out, "batched_streams", batched_streams_leg, cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
         if args.batch:
-            out["batched_filter"] = batched_filter_leg(cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
+            safe_leg(out, "batched_filter", batched_filter_leg, cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
             _CFG_NAME[0] = args.config
-            # parity + CPU baseline on a sequence of >= PARITY_FRAMES frames, whatever --steps says (the reference's rank truncation
-            # first bites at frame 90 of the stock sequence: a 26-frame comparison would not see it)
-            if n_frames >= PARITY_FRAMES:
-                pin = (imgs, imu_arr, imu_cnt, cand_arr, cand_cnt)
-            else:
-                _, pi, pa, pc, pca, pcc = build_inputs(cfg, PARITY_FRAMES)
-                pin = (pi, pa, pc, None, np.zeros_like(pcc)) if not args.host_corners else (pi, pa, pc, pca, pcc)
-            npar = min(len(pin[0]), 240)
-            out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, npar)
-            if _MULTI[0] is not None:
-                out["cpu_baseline_multicore"] = _MULTI[0]
-            out["parity"] = parity_leg(cfg, torch, pin, wi, ai, ni, npar, cpu_states)
-            out["max_state_delta_vs_cpu"] = out["parity"]["max_state_delta"]
-        out.pop("x_at_cpu_frames", None)
+            try:
+                pin = long_inputs()
+                npar = min(len(pin[0]), 240)
+                out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, npar)
+                if _MULTI[0] is not None:
+                    out["cpu_baseline_multicore"] = _MULTI[0]
+                out["parity"] = parity_leg(cfg, torch, pin, wi, ai, ni, npar, cpu_states)
+                out["max_state_delta_vs_cpu"] = out["parity"]["max_state_delta"]
+            except Exception as e:   # noqa: BLE001
+                out.setdefault("cpu_baseline", {"error": repr(e)[:300]})
+                out.setdefault("parity", {"error": repr(e)[:300]})
     h.close()
     if sharded:
         if comm is not None:
@@ -306,22 +399,24 @@ def _qfix(x):
     return x
 
 
-def pose_latency_leg(cfg, n_frames, p_img, p_imu, imu_cnt, isb, msb, wi, ai, ni, device):
+def pose_latency_leg(cfg, fs, plan, wi, ai, ni, device):
     """What a 20 Hz camera sees: host wall clock from handing ONE frame over (rvio_hip_frame_dev, nothing else in flight) until its pose is
     on the host (rvio_hip_get_pose: the filter stream only).  The Updater's hand-over leaves book-keeping before the detector has finished
     (bookkeep_a_kernel / bookkeep_b_kernel), so the pose does not wait for CLAHE + GFTT + cornerSubPix, the long pole of the front end; the
-    refill for the NEXT frame finishes behind it (the next call would find it done at any real frame rate)."""
+    refill for the NEXT frame finishes behind it (the next call would find it done at any real frame rate).
+    `plan` = pose_latency_plan(fs.n, ...): every index below goes through fs.args, which refuses anything outside the resident sequence."""
     from rvio_amd import hip
+    n_warm, n_timed = plan
     h = hip.RvioHip(cfg, device=device)
     h.initialize(wi, ai, ni)
-    n_warm = min(n_frames - 40, 3 * cfg.max_track_len + 10)
     for i in range(n_warm):
-        h.frame_dev(p_img + i * isb, cfg.width, p_imu + i * msb, int(imu_cnt[i]), 0, 0)
+        h.frame_dev(*fs.args(i))
     h.sync()
     ts = []
-    for i in range(n_warm, min(n_frames, n_warm + 60)):
+    for i in range(n_warm, n_warm + n_timed):
+        a = fs.args(i)
         t0 = time.perf_counter()
-        h.frame_dev(p_img + i * isb, cfg.width, p_imu + i * msb, int(imu_cnt[i]), 0, 0)
+        h.frame_dev(*a)
         h.pose()
         ts.append(1e3 * (time.perf_counter() - t0))
         h.sync()                                  # the refill half of book-keeping, the next frame's image chain inputs ...
@@ -331,8 +426,7 @@ def pose_latency_leg(cfg, n_frames, p_img, p_imu, imu_cnt, isb, msb, wi, ai, ni,
             "note": "host wall clock, frame handed over (frames resident in HBM) -> pose on the host, one frame in flight; includes the host's enqueue time"}
 
 
-def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, k0, wi, ai, ni,
-                 device=0):
+def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     """Second, untimed-for-throughput pass on a fresh handle: per-stage device latencies with HIP events on the
     handle's stream (p50 EKF-update ms of the metric), the dominant kernel's roofline, and the state after
     `cpu_frames` frames for the parity figure."""
@@ -340,24 +434,23 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
     h = hip.RvioHip(cfg, device=device)
     st = torch.cuda.ExternalStream(h.stream(), device=torch.device("cuda", device))
     h.initialize(wi, ai, ni)
-    n = len(imgs)
-    L = h.L
-    import ctypes as C
+    n = fs.n
     names = ["track", "propagate", "update", "augment_compose"]
     lat = {k: [] for k in names}
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     x_at = None
     ncpu = min(120, n)
+    skip = min(20, max(0, n - 4))     # (short runs: keep at least the last frames)
     for i in range(n):
-        m, nc = int(imu_cnt[i]), int(cand_cnt[i])
+        a = fs.args(i)
         with torch.cuda.stream(st):
             evs[0].record()
-        h.track_dev(p_img + i * isb, cfg.width, p_imu + i * msb, m, p_cand + i * csb, nc)
+        h.track_dev(*a)
         with torch.cuda.stream(st):
             evs[1].record()
-        did_update = h.frame_tail_staged(p_imu + i * msb, m, evs, st, torch)
+        did_update = h.frame_tail_staged(a[2], a[3], evs, st, torch)
         h.sync()
-        if i > 20:
+        if i >= skip:
             lat["track"].append(evs[0].elapsed_time(evs[1]))
             lat["propagate"].append(evs[1].elapsed_time(evs[2]))
             if did_update:
@@ -370,44 +463,61 @@ def latency_pass(h0, cfg, torch, stream0, seq, imgs, imu_arr, imu_cnt, cand_arr,
            "latency_ms_p95": {k: float(np.percentile(v, 95)) for k, v in lat.items() if v},
            "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
            "x_at_cpu_frames": x_at, "x_final": h.get_state()[0]}
-    # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree)
-    # Dominant kernel by device time: the solve kernel — T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T
-    # (c6 = 6n columns, register tableau).  Algorithmic FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1)
-    # columns x 2 flops (the 2r^3 term of U8).
+    # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree).
+    # Candidates = the four longest kernels of the frame in profiles/*_kernel_stats.md, each timed by rvio_hip_debug_time_kernel in the very
+    # form the handle launches, on the operands the last frame left in HBM; the DOMINANT one (largest live average) is `roofline`, the
+    # others go to `roofline_other`.
     n = cfg.max_track_len - 1
     c6 = 6 * n
     F = cfg.n_features
+    PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
     t_solve = h.time_kernel(0, 20) * 1e-6
     t_klt = h.time_kernel(1, 20) * 1e-6
     t_feat = h.time_kernel(2, 20) * 1e-6
+    t_subpix = h.time_kernel(6, 20) * 1e-6
+    # solve: T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T (c6 = 6n columns, register tableau).  Algorithmic
+    # FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8)
     fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
-    PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
-    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read live, so this is the committed
-    # rocprofv3 --pmc result (profiles/r02_pmc_traffic.md: FETCH_SIZE + WRITE_SIZE as reported, separate passes)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-            e = [v for k, v in json.load(fh).items() if "solve7_kernel" in k][0]
-        traffic = 1024.0 * (e["fetch_kb_mean"] + e["write_kb_mean"])
-    except (OSError, IndexError, KeyError, ValueError):
-        pass
-    res["roofline"] = {"bound": "mfma", "kernel": "solve7_kernel (T = s2 I + A Pcc, W = T^-1, dx, state injection; one workgroup)",
-                       "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s",
-                       "frac": fl_solve / t_solve / 1e12 / PEAK_F64, "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r02_pmc_traffic.md)",
-                       "avg_us": t_solve * 1e6,
-                       "note": "latency bound: a %dx%d FP64 elimination is a chain of %d dependent pivot decisions on ONE CU; a single 752x480 stream "
-                               "offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1%% of either roof by construction; update_at_load.roofline "
-                               "prices the whole update at full load, batched_filter the same kernels with the chip full" % (c6, c6 + 1, c6)}
     it_l = 10
-    by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10
-    res["roofline_other"] = [
-        {"bound": "hbm", "kernel": "klt_kernel3", "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s",
-         "frac": by_klt / t_klt / 1e9 / 8000.0, "avg_us": t_klt * 1e6},
-        {"bound": "mfma", "kernel": "feat_build_kernel (U1-U5, FP64 MFMA gate)", "achieved": None, "peak": PEAK_F64, "unit": "TFLOP/s",
-         "frac": None, "avg_us": t_feat * 1e6},
+    by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10: template + it_l bilinear windows per level
+    by_subpix = F * (4.0 * 17 * 17) * 5                          # cornerSubPix: a 17x17 float window re-sampled per iteration, ~5 iterations per corner
+    cands = [
+        {"bound": "mfma", "kernel": "solve7_kernel (T = s2 I + A Pcc, W = T^-1, dx, state injection; one workgroup)", "match": "solve7_kernel",
+         "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_solve * 1e6,
+         "note": "latency bound: a %dx%d FP64 elimination is a chain of %d dependent pivot decisions on ONE CU" % (c6, c6 + 1, c6)},
+        {"bound": "hbm", "kernel": "klt_kernel3 (4-level pyramidal LK, one wave per feature)", "match": "klt_kernel3",
+         "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_klt * 1e6,
+         "note": "timed matching the current image back onto the previous one from the current feature positions (the forward match's displacements, "
+                 "reversed): the frame's own inputs are gone once book-keeping has moved the features"},
+        {"bound": "mfma", "kernel": "feat_build_kernel (U1-U5, FP64 MFMA gate)", "match": "feat_", "achieved": None, "peak": PEAK_F64, "unit": "TFLOP/s",
+         "avg_us": t_feat * 1e6},
+        {"bound": "hbm", "kernel": "subpix_kernel (cornerSubPix, 4 waves per corner)", "match": "subpix_kernel", "achieved": by_subpix / t_subpix / 1e9, "peak": 8000.0,
+         "unit": "GB/s", "avg_us": t_subpix * 1e6},
     ]
+    for c in cands:
+        c["frac"] = None if c["achieved"] is None else c["achieved"] / c["peak"]
+        # HBM-side bytes per launch: PMC counters cannot be read live, so this is the committed rocprofv3 --pmc result OF THIS CONFIGURATION
+        # (profiles/r03_pmc_traffic_cfg<name>.json: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
+        c["traffic"], c["traffic_unit"] = pmc_traffic(name, c.pop("match"))
+    cands.sort(key=lambda c: -c["avg_us"])
+    res["roofline"] = dict(cands[0], dominant_by="largest live average among the frame's four longest kernels (rvio_hip_debug_time_kernel)",
+                           context="a single 752x480 stream offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1% of either roof by construction; "
+                                   "update_at_load.roofline prices the whole update at full load, batched_filter / batched_streams the same kernels with the chip full")
+    res["roofline_other"] = cands[1:]
     h.close()
     return res
+
+
+def pmc_traffic(cfg_name, kernel_substr):
+    """(bytes per launch, source) of a kernel from the committed rocprofv3 --pmc summary of THIS configuration, or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg%s.json" % cfg_name)
+    try:
+        with open(path) as fh:
+            e = [v for k, v in json.load(fh).items() if kernel_substr in k]
+        e.sort(key=lambda v: -v.get("dispatches", 0))
+        return 1024.0 * (e[0]["fetch_kb_mean"] + e[0]["write_kb_mean"]), "bytes/launch (profiles/%s)" % os.path.basename(path)
+    except (OSError, IndexError, KeyError, ValueError):
+        return None, "no committed PMC pass for cfg%s" % cfg_name
 
 
 def update_at_load_leg(cfg, torch, name="B", reps=60):
@@ -467,23 +577,23 @@ def update_at_load_leg(cfg, torch, name="B", reps=60):
     return {"workload": "cfg%s, window full (%d clones, 6n = %d), one stream: rvio_hip_update_tracked on full loads" % (name, n, c6), **res}
 
 
-def multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, isb, msb, csb, wi, ai, ni, n_frames, n_warm, streams=8, threads=1):
+def multi_stream(cfg, fs, wi, ai, ni, n_warm, streams=8, threads=1):
     """Aggregate throughput of `streams` independent filter instances (own handle, own HIP streams) fed the same resident
     frames: kernels of different instances overlap on the 256 CUs.  `threads` host threads issue the launches (each drives
     streams/threads instances; the C-ABI calls release the GIL)."""
     import threading
     from rvio_amd import hip
+    n_frames = fs.n
+    n_warm = max(0, min(n_warm, n_frames - 1))
     hs = [hip.RvioHip(cfg) for _ in range(streams)]
     for h in hs:
         h.initialize(wi, ai, ni)
 
-    def frame(h, i):
-        h.frame_dev(p_img + i * isb, cfg.width, p_imu + i * msb, int(imu_cnt[i]), p_cand + i * csb, int(cand_cnt[i]))
-
     def run(mine, lo, hi):
         for i in range(lo, hi):
+            a = fs.args(i)
             for h in mine:
-                frame(h, i)
+                h.frame_dev(*a)
         for h in mine:
             h.sync()
 
@@ -507,27 +617,25 @@ def multi_stream(cfg, torch, seq, imu_cnt, cand_cnt, p_img, p_imu, p_cand, isb, 
             "note": "independent handles (3 streams each) issued from one host thread onto HIP's 4 hardware queues: superseded by batch handles (batched_streams)"}
 
 
-def host_buffer_leg(cfg, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, ni, n_warm):
+def host_buffer_leg(cfg, fs, wi, ai, ni, n_warm):
     """PCIe-inclusive rate: the same frames handed over as HOST buffers (rvio_hip_frame: image + IMU + corners copied H2D on
     the tracker stream every frame).  Reported beside `value`, never as `value`."""
     from rvio_amd import hip
     h = hip.RvioHip(cfg)
     h.initialize(wi, ai, ni)
-    n = len(imgs)
-
-    def frame(i):
-        h.frame(imgs[i], imu_arr[i, : imu_cnt[i]], None if cand_arr is None else cand_arr[i, : cand_cnt[i]])
+    n = fs.n
+    n_warm = max(0, min(n_warm, n - 1))
     for i in range(n_warm):
-        frame(i)
+        h.frame(*fs.host(i))
     h.sync()
     t0 = time.perf_counter()
     for i in range(n_warm, n):
-        frame(i)
+        h.frame(*fs.host(i))
     h.sync()
     el = time.perf_counter() - t0
     h.close()
     return {"value": (n - n_warm) / el, "unit": "frames/s",
-            "bytes_h2d_per_frame": int(imgs[0].nbytes + imu_arr[0].nbytes + (0 if cand_arr is None else cand_arr[0].nbytes)),
+            "bytes_h2d_per_frame": int(fs.imgs[0].nbytes + fs.imu_arr[0].nbytes + (0 if fs.cand_arr is None else fs.cand_arr[0].nbytes)),
             "note": "caller's pageable buffers, packed into the library's pinned ring on the host, asynchronous H2D on the tracker stream"}
 
 

@@ -292,8 +292,9 @@ int rvio_hip_debug_pyramid(rvio_hip* h, int level, int32_t* w, int32_t* hgt, uin
 int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy);
 /* Measurement hook for bench.py's roofline object: average device time (us, HIP events on the handle's stream)
  * of `iters` back-to-back launches of one hot kernel on the operands the last frame left in HBM.
- * which: 0 = solve kernel, 1 = KLT kernel, 2 = per-feature Jacobian/nullspace/gate kernel, 3 = reduction of the per-feature
- * information shares (+ rank truncation), 4 = U/G/P1 strips, 5 = Joseph-form kernel. */
+ * which: 0 = solve kernel, 1 = KLT kernel (the current image matched back onto the previous one from the current feature positions),
+ * 2 = per-feature Jacobian/nullspace/gate kernel, 3 = reduction of the per-feature information shares (+ rank truncation),
+ * 4 = U/G/P1 strips, 5 = Joseph-form kernel (4, 5: in the form this handle launches), 6 = cornerSubPix on the last corner list. */
 int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us);
 
 #ifdef __cplusplus

@@ -10,15 +10,19 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librvio_hip.so")
-SOURCES = ["rvio_hip.hip", "filter_kernels.hip", "filter_kernels2.hip", "solve4.hip", "solve6.hip", "frontend_kernels.hip", "klt3.hip", "clahe.hip", "detector.hip", "rvio_dev.h", "frontend_dev.h",
-           "chi2_table.inc", os.path.join("..", "..", "include", "rvio_hip.h")]
+
+
+def sources():
+    """Everything the one hipcc call reads: every file under csrc/ (rvio_hip.hip includes the other kernel files) + the C header."""
+    fs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))]
+    return fs + [os.path.join(HERE, "..", "include", "rvio_hip.h")]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    return any(os.path.getmtime(f) > t for f in sources())
 
 
 def build(force=False, verbose=False):

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t, size_t bs,
                                                 const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     DBG_S(blockIdx.z == 0, 3);
-    if (done) stage_wait(done, done_target, meta);
+    if (done && !stage_wait(done, done_target, meta)) return;   // (timed out: error bit 4 is set, nothing is rewritten)
     DBG_S(blockIdx.z == 0, 4);
     tracker_shift(t, (size_t)blockIdx.z * bs);
     __shared__ int s_w[4];

@@ -238,16 +238,26 @@ __device__ __forceinline__ void stage_signal(unsigned long long* c) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void stage_wait(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
+// Returns false when the counter has not arrived within STAGE_WAIT_TICKS of the constant 100 MHz clock (30 s: the producer's queue is
+// dead or starved beyond anything a shared / preempted GPU does).  The caller then must NOT rewrite what the producer may still read:
+// it leaves, and the sticky error bit 4 makes the next rvio_hip_sync / rvio_hip_get_frame_info fail (RVIO_ERR_STATE).
+#define STAGE_WAIT_TICKS 3000000000ull
+__device__ __forceinline__ bool stage_wait(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
+    __shared__ int s_stage_ok;
     if (threadIdx.x == 0) {
-        int it = 0;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++it > 400000) { atomicOr(&meta->err, 4); break; }   // ~0.5 s: a producer died — say so instead of hanging the queue
+        int ok = 1;
+        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > STAGE_WAIT_TICKS) { atomicOr(&meta->err, 4); ok = 0; break; }
+            }
         }
+        s_stage_ok = ok;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's vector cache and the XCD's L2 drop what the producers have rewritten
+    return s_stage_ok != 0;
 }
 
 

@@ -137,6 +137,15 @@ struct rvio_hip {
 // hipStreamSynchronize): no timing, and no system-scope fence when they are recorded — that fence writes the dirty L2 lines of the
 // recording queue back before the NEXT kernel of that queue may start (measured: a 35 us hole in the tracker stream per frame)
 static const unsigned kEvFlags = getenv("RVIO_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+// Timing experiments that DROP correctness-critical stream waits exist only in an instrumented build (-DRVIO_DBG_CLOCKS, tools/chain_clocks.py):
+// a stray environment variable must not be able to turn the shipping pipeline racy.
+#ifdef RVIO_DBG_CLOCKS
+static const int kDbgSkip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
+static const int kRaDepth = getenv("RVIO_RA_DEPTH") ? std::max(1, std::min(3, atoi(getenv("RVIO_RA_DEPTH")))) : 3;   // 2 = the image chain waits for book-keeping(k-2)
+#else
+static constexpr int kDbgSkip = 0;
+static constexpr int kRaDepth = 3;
+#endif
 #define HIPCHK(h, call)                                                                          \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
@@ -492,6 +501,10 @@ int rvio_hip_sync(rvio_hip* h) {
     if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d));
     HIPCHK(h, hipStreamSynchronize(h->stream_t));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // a device-side stage counter that timed out (stage_wait, rvio_dev.h) left the frame sequence broken: a hard error, not a flag to poll
+    int e = 0;
+    HIPCHK(h, hipMemcpy(&e, &h->meta->err, sizeof e, hipMemcpyDeviceToHost));
+    if (e & 4) { h->err = "a device-side stage counter timed out (filter -> book-keeping): the frame sequence is invalid, re-initialise"; return RVIO_ERR_STATE; }
     return RVIO_OK;
 }
 
@@ -706,6 +719,23 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
 }
 
+// U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
+static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bool ug, bool fin) {
+    const DevCfg& d = h->dc;
+    const int c6 = 6 * n, dd = 24 + c6, B = h->batch;
+    const size_t bs = h->slab_bytes;
+    double* Pc = h->P[h->cur];
+    const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
+    static const bool no_ugl = getenv("RVIO_NO_UGL") != nullptr;   // A/B timing
+    if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
+        if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+        if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
+    } else {
+        if (ug) hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
+        if (fin) hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
+    }
+}
+
 // combined: d_blocks is the handle's own block, already turned into [A|b] by gram_reduce_kernel (unsharded update)
 static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, bool combined) {
     const DevCfg& d = h->dc;
@@ -725,16 +755,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
     const int tt = (c6 + 31) / 32;
     if (!h->solve7_variant) hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     launch_solve(h, n, Ab);
-    // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
-    const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
-    static const bool no_ugl = getenv("RVIO_NO_UGL") != nullptr;   // A/B timing
-    if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
-        hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
-        hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
-    } else {
-        hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
-        hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
-    }
+    launch_ug_final(h, n, Ab, Pn, true, true);
     HIPCHK(h, hipGetLastError());
     h->cur ^= 1;
     return RVIO_OK;
@@ -894,8 +915,7 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
     else
         hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
-    static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
-    if (first_flag_ready && !(dbg_skip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
+    if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
     if (h->wide_px && d.W % 4 == 0)
         hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
     else
@@ -926,6 +946,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         if (own) { h->pyr[b].img[0] = d_img; pv.img[0] = d_img; }
         hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, st, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
     };
+    // Run-ahead mode: the image chain of frame k (CLAHE, detector; with the equaliser also the pyramid) rewrites buffers that book-keeping /
+    // KLT of earlier frames read — equalised image k % 4, corner list and count k % 3 — so it starts behind book-keeping(k-3), with or
+    // without the equaliser (the detector alone rewrites det_xy2[k % 3] / det_nout[k % 3], which bookkeep_b(k-3) reads).
+    if (h->runahead && h->frame_no >= (long)kRaDepth && !(kDbgSkip & 1))
+        HIPCHK(h, hipStreamWaitEvent(image_stream(h), h->evT[(h->frame_no - kRaDepth) & 3], 0));
     if (h->cfg.enable_equalizer) {   // clahe->apply(im, im), Tracker.cc:198-202
         // The equalised image of frame k doubles as level 0 of frame k's pyramid (no copy), so it lives until the KLT of frame k+1 has
         // matched against it: four buffers in rotation (like the pyramids, and three corner lists).  Slot k % 4 was last read by KLT(k-3)
@@ -936,9 +961,6 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->par];
-        static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
-        static const int ra_depth = getenv("RVIO_RA_DEPTH") ? std::max(1, std::min(3, atoi(getenv("RVIO_RA_DEPTH")))) : 3;   // A/B timing: 2 = the image chain waits for book-keeping(k-2)
-        if (h->runahead && h->frame_no >= (uint64_t)ra_depth && !(dbg_skip & 1)) HIPCHK(h, hipStreamWaitEvent(cs, h->evT[(h->frame_no - ra_depth) & 3], 0));
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, lut, src_bs, bs);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
@@ -1001,10 +1023,9 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
         const float* xy = h->det_xy2[h->dslot];
         const int* nout = h->det_nout + h->dslot;
         if (h->runahead) {   // book-keeping on the side stream, behind RANSAC: the hand-over half once filter(k-2) has let go of the tables, the refill half once the corners are there
-            static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;
-            if (h->book_wait && !(dbg_skip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
+            if (h->book_wait && !(kDbgSkip & 4)) HIPCHK(h, hipStreamWaitEvent(h->side, h->book_wait, 0));
             h->book_wait = nullptr;
-            if (h->book_dev && !(dbg_skip & 4)) { done = &h->stage_sync->aug; done_target = h->book_target; }
+            if (h->book_dev && !(kDbgSkip & 4)) { done = &h->stage_sync->aug; done_target = h->book_target; }
             h->book_dev = false;
             h->tail = h->side;
             if (fused)
@@ -1237,10 +1258,9 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->ts = h->stream;
     if (rc != RVIO_OK) return rc;
     const double t2 = dbg_host ? now() : 0;
-    static const int dbg_skip = getenv("RVIO_DBG_SKIP") ? atoi(getenv("RVIO_DBG_SKIP")) : 0;   // timing experiments only
     HIPCHK(h, hipEventRecord(h->evT[h->frame_no & 3], h->tail));      // behind book-keeping, on the stream that ran it
     // the filter needs the hand-over, not the refill: in run-ahead mode it waits for the first half of book-keeping only
-    if (!(dbg_skip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
+    if (!(kDbgSkip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
@@ -1251,7 +1271,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     // (book-keeping of frame k+2 polls it); otherwise an event behind it
     static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr;
     if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->stage_tgt.aug; }
-    else { if (!(dbg_skip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
+    else { if (!(kDbgSkip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
     if (dbg_host) {
         const double t5 = now();
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
@@ -1388,6 +1408,7 @@ int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     info->n_clones = h->n_clones_host; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
     info->reserved[0] = m.err;
     info->rank_truncated_at = m.updated ? m.trunc_at : -1;
+    if (m.err & 4) { h->err = "a device-side stage counter timed out (filter -> book-keeping): the frame sequence is invalid, re-initialise"; return RVIO_ERR_STATE; }
     return RVIO_OK;
 }
 int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]) {
@@ -1473,8 +1494,11 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         if (which == 0) {
             launch_solve(h, n, h->block);
         } else if (which == 1) {
+            // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT
+            // image back onto the PREVIOUS one from the current feature positions instead — the same displacement magnitudes, reversed, the
+            // refilled corners included (they exist in the previous image too).  Outputs land in t.tracked / t.status (scratch between frames).
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[(h->pyr_cur + 3) % 4], h->pyr[h->pyr_cur], d.levels, h->t.n_pts, h->t.feats,
+            hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[(h->pyr_cur + 3) % 4], d.levels, h->t.n_pts, h->t.feats,
                                h->t.tracked, h->t.status, (size_t)0);
         } else if (which == 2) {
             if (h->batch == 1)
@@ -1488,11 +1512,14 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
             hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + (h->batch == 1 ? 63 : 255)) / (h->batch == 1 ? 64 : 256))), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
                                h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);
-        } else if (which == 4) {   // U, G, P1 strips on the operands of the last update (outputs to scratch)
-            hipLaunchKernelGGL(ug_kernel, dim3((24 + 6 * n + 15) / 16, 1, h->batch), dim3(256), h->ug_lds, h->stream, d, n, h->P[h->cur], h->W, h->block, h->U, h->G, h->Pt1, h->slab_bytes);
-        } else if (which == 5) {   // Joseph form, written to the spare covariance buffer (overwritten by the next stage anyway)
-            const int nt = (24 + 6 * n + 15) / 16, npair = nt * (nt + 1) / 2;
-            hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, h->batch), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, h->P[h->cur ^ 1], h->slab_bytes);
+        } else if (which == 4 || which == 5) {   // U, G, P1 strips / the Joseph form on the operands of the last update, in the form the handle launches
+            launch_ug_final(h, n, h->block, h->P[h->cur ^ 1], which == 4, which == 5);   // (outputs: scratch / the spare covariance buffer, overwritten by the next stage anyway)
+        } else if (which == 6) {   // cornerSubPix on the corners of the last detector call (reads raw_xy, rewrites xy with the same values)
+            if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
+            const DetDev q = [&] { DetDev v = h->det_set_last ? h->det_b : h->det; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
+            const uint8_t* im = h->pyr[h->pyr_cur].img[0];   // level 0 of the current pyramid = the image the detector saw
+            if (h->wide_px) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
         } else return RVIO_ERR_INVALID;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));

@@ -68,7 +68,7 @@ __device__ __forceinline__ void solve4_body(const DevCfg& cfg, FilterMeta* __res
         if (k == 30) DBG_T(51);
         const int prow = pr * ldm;
         const double ipiv = 1.0 / M[prow + k];
-        if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if (!(best > 0)) meta->err |= 1; }
+        if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if (!(best > 0)) atomicOr(&meta->err, 1); }
         double prv[NCH];
 #pragma unroll
         for (int u = 0; u < NCH; ++u) { const int j = lane + 64 * u; prv[u] = (j < NC) ? M[prow + j] : 0.0; }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void solve6_kernel(DevCfg cfg, FilterMeta*
             double prv[NCH];
 #pragma unroll
             for (int u = 0; u < NCH; ++u) prv[u] = M[pr * LDM + lane + 64 * u];
-            if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if ((kb >> 7) == 0) meta->err |= 1; }
+            if (tid == 0) { s_prow[k] = pr; s_invp[pr] = k; s_ipiv[k] = ipiv; if ((kb >> 7) == 0) atomicOr(&meta->err, 1); }
             qpr = ((pr & (NW - 1)) == wv) ? (pr >> WSH) : -1;
             if (qpr >= 0) usedmask |= 1u << qpr;
             // multipliers, lane <-> row: f_i = M[i][k]/piv, 0 for the pivot row

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         if (lane == 0) {
             s_p[slot][0] = pa; s_p[slot][1] = pb;
             s_prow[2 * sp] = pa; s_prow[2 * sp + 1] = pb; s_invp[pa] = 2 * sp; s_invp[pb] = 2 * sp + 1; s_ipiv[2 * sp] = ipa; s_ipiv[2 * sp + 1] = ipb;
-            if (sa || sb) meta->err |= 1;
+            if (sa || sb) atomicOr(&meta->err, 1);
         }
         // LDS operations of one wave complete in order: the flag becomes visible after the data
         __hip_atomic_store(&s_flag[slot], sp + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -37,7 +37,14 @@ def _ramp(t, t0=2.0, t1=4.0):
 
 class SynthSequence:
     def __init__(self, cfg, n_landmarks=4000, cam_hz=20.0, duration=20.0, seed=0,
-                 pixel_noise=None, drop_prob=0.02, motion_scale=1.0):
+                 pixel_noise=None, drop_prob=0.02, motion_scale=1.0, motion="sinus", scene="room"):
+        """motion: "sinus" (the default 6-DoF sinusoids), "stationary" (the platform never moves: zero parallax), "rotation" (pure rotation
+        about the CAMERA centre: zero parallax with changing views), "line" (constant-velocity straight line without rotation once the
+        ramp has ended: the motion a monocular window cannot scale).  scene: "room" (landmarks on the shell of a room) or "sphere" (every
+        landmark 4 m from the start position: one common depth).  The non-default modes exist to stress the rank truncation of the
+        measurement compression (tests/test_truncation.py) with windows its structural form was not derived for."""
+        assert motion in ("sinus", "stationary", "rotation", "line") and scene in ("room", "sphere")
+        self.motion, self.scene = motion, scene
         self.cfg = cfg
         self.cam_hz = cam_hz
         self.imu_hz = float(cfg.imu_rate)
@@ -63,6 +70,9 @@ class SynthSequence:
             L[m, ax] = sgn * half[ax]
             L[m, others[0]] = u[m, 0] * half[others[0]]
             L[m, others[1]] = u[m, 1] * half[others[1]]
+        if scene == "sphere":
+            v = rng.standard_normal((n, 3))
+            L = 4.0 * v / np.linalg.norm(v, axis=1, keepdims=True)
         self.landmarks = L
         self.amps = np.random.default_rng(11 + seed).uniform(80, 200, n)
         self._imu_cache = None
@@ -74,11 +84,17 @@ class SynthSequence:
     def pose(self, t):
         """(R_wb, p_w) at time t."""
         s = float(_ramp(np.asarray(t, dtype=float))) * self.motion_scale
+        if self.motion == "stationary":
+            return self._R0, np.zeros(3)
+        if self.motion == "line":      # (t - 2) ramp(t) is C^2 at the start and exactly linear in t behind the ramp
+            return self._R0, s * (t - 2.0) * np.array([0.3, 0.4, 0.05])
         p = s * np.array([2 * math.sin(0.5 * t), 1.5 * math.sin(0.7 * t + 1), 0.5 * math.sin(0.9 * t + 2)])
-        p0 = np.array([0.0, 1.5 * math.sin(1.0), 0.5 * math.sin(2.0)]) * 0.0
         th = s * np.array([0.2 * math.sin(0.6 * t), 0.15 * math.sin(0.8 * t), 0.3 * math.sin(0.4 * t)])
         # base attitude: camera looks roughly along world +x
-        return self._R0 @ _expm_so3(th), p + p0
+        R = self._R0 @ _expm_so3(th)
+        if self.motion == "rotation":  # the camera centre p + R t_bc stays where it was at rest
+            return R, self._R0 @ self.t_bc - R @ self.t_bc
+        return R, p
 
     @property
     def _R0(self):

@@ -1,6 +1,11 @@
-"""bench.py's algorithmic-work model (W_filter) — the figure `batched_filter.achieved_tflops_fp64` is priced with."""
+"""bench.py's host logic, without a GPU: the algorithmic-work model (W_filter) the batched figures are priced with, and —
+after round 2's driver run died of a negative frame index turned into a device pointer — every leg's index arithmetic, walked with a
+fake handle that refuses any pointer outside the resident sequence."""
 import os
 import sys
+
+import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,3 +28,91 @@ def test_filter_flops_matches_the_survey_figures():
     a = bench.filter_flops(cfg, 10, [11], [ord("2")], 0)
     b = bench.filter_flops(cfg, 10, [6], [ord("1")], 0)
     assert a == b
+
+
+class FakeHandle:
+    """stands in for rvio_amd.hip.RvioHip: records the frames it is handed and refuses a pointer that is not frame i of the FrameSet"""
+    fs = None
+    seen = None
+
+    def __init__(self, cfg, device=0, **kw):
+        self.cfg = cfg
+
+    def _ck(self, p_img, stride, p_imu, m, p_cand, n_cand):
+        fs = FakeHandle.fs
+        off = p_img - fs.p_img
+        assert off >= 0 and off % fs.isb == 0 and off // fs.isb < fs.n, "image pointer outside the resident sequence"
+        i = off // fs.isb
+        assert p_imu == fs.p_imu + i * fs.msb and 0 <= m <= fs.imu_arr.shape[1] and p_cand == 0 and n_cand == 0
+        FakeHandle.seen.append(int(i))
+
+    def frame_dev(self, *a):
+        self._ck(*a)
+
+    def track_dev(self, *a):
+        self._ck(*a)
+
+    def frame(self, img, imu, cand):
+        FakeHandle.seen.append(-1)
+
+    def initialize(self, *a):
+        pass
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+    def pose(self):
+        return np.zeros(3), np.zeros(4)
+
+    def frame_info(self):
+        return {"updated": 1}
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (1, 0), (200, 40), (8, 0), (60, 2)])
+@pytest.mark.parametrize("name", ["B", "E"])
+def test_every_leg_stays_inside_the_resident_sequence(monkeypatch, steps, warmup, name):
+    from rvio_amd import hip
+    monkeypatch.setattr(hip, "RvioHip", FakeHandle)
+    cfg = bench.abi.config_named(name)
+    n_frames = 1 + warmup + steps
+    fs = bench.FrameSet.fake(cfg, n_frames)
+    FakeHandle.fs, FakeHandle.seen = fs, []
+    # the checked accessor itself
+    for bad in (-1, -14, n_frames, n_frames + 3):
+        with pytest.raises(IndexError):
+            fs.args(bad)
+        with pytest.raises(IndexError):
+            fs.host(bad)
+    assert fs.args(n_frames - 1)[0] == fs.p_img + (n_frames - 1) * fs.isb
+    # pose latency: a plan exists only when the window can be filled first, and it never leaves [0, n)
+    plan = bench.pose_latency_plan(n_frames, cfg.max_track_len)
+    if plan is None:
+        assert n_frames < 3 * cfg.max_track_len + 10 + 8
+        long_plan = bench.pose_latency_plan(bench.PARITY_FRAMES, cfg.max_track_len)   # the leg then runs on the parity sequence
+        assert long_plan is not None and long_plan[0] + long_plan[1] <= bench.PARITY_FRAMES
+    else:
+        n_warm, n_timed = plan
+        assert 0 <= n_warm and n_timed >= 8 and n_warm + n_timed <= n_frames
+        FakeHandle.seen = []
+        r = bench.pose_latency_leg(cfg, fs, plan, None, None, 0, 0)
+        assert FakeHandle.seen == list(range(n_warm + n_timed)) and r["frames"] == n_timed
+    # host buffers / multi stream: warm-up clamped, every frame exactly once per handle
+    FakeHandle.seen = []
+    r = bench.host_buffer_leg(cfg, fs, None, None, 0, 1 + warmup)
+    assert len(FakeHandle.seen) == n_frames and r["value"] > 0
+    FakeHandle.seen = []
+    r = bench.multi_stream(cfg, fs, None, None, 0, 1 + warmup, streams=3)
+    assert sorted(FakeHandle.seen) == sorted(list(range(n_frames)) * 3)
+    assert r["frames_per_stream"] == n_frames - min(1 + warmup, n_frames - 1)
+
+
+def test_a_failing_secondary_leg_becomes_an_error_object():
+    out = {"value": 1.0}
+
+    def boom():
+        raise RuntimeError("leg died")
+    bench.safe_leg(out, "pose_latency_unpipelined", boom)
+    assert out["value"] == 1.0 and "leg died" in out["pose_latency_unpipelined"]["error"]

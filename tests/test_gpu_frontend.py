@@ -250,3 +250,45 @@ def test_whole_frame_with_images(gpu_required, frames):
         worst = max(worst, S.state_delta(xa, xb))
     h.close()
     assert worst <= 1e-6, worst
+
+
+def test_runahead_without_equalizer_long_sequence(gpu_required):
+    """Run-ahead mode (device detector, no host synchronisation between frames) with Tracker.EnableEqualizer: 0: the image chain of frame k
+    (here: the detector alone) rewrites corner list k % 3, which the refill half of book-keeping(k-3) reads — it has to start behind that
+    book-keeping with or without CLAHE (round-2 advisor finding: the ring wait sat inside the equaliser branch).  60 free-running frames
+    from device-resident images against the oracle: bit-exact feature lists at the end, states within 1e-6, twice with the same result."""
+    from rvio_amd import hip
+    import scenarios as S
+    import torch
+    cfg = abi.config_named("B", enable_equalizer=0)
+    seq = rv.synth.SynthSequence(cfg, duration=8.0)
+    ks = list(range(39, 39 + 60))
+    imgs = np.stack([seq.render(k) for k in ks])
+    imus = [seq.imu_between(k) for k in ks]
+    w, a, n = seq.init_from_static(38)
+    s = O.System(cfg)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    s.set_state(x0, P0)
+    for img, imu in zip(imgs, imus):
+        s.frame(imu, None, img=img)
+    xb, _ = s.get_state()
+    pb, hb = s.tracker().get_points()
+    d_imgs = torch.from_numpy(imgs).cuda()
+    d_imus = [torch.from_numpy(i.view(np.uint8)).cuda() for i in imus]
+    torch.cuda.synchronize()
+    res = []
+    for rep in range(2):
+        h = hip.RvioHip(cfg)
+        h.initialize(w, a, n)
+        for i in range(len(ks)):
+            h.frame_dev(d_imgs[i].data_ptr(), cfg.width, d_imus[i].data_ptr(), len(imus[i]), 0, 0)
+        h.sync()
+        xa, Pa = h.get_state()
+        pa, ha = h.get_points()
+        info = h.frame_info()
+        h.close()
+        assert info["device_error"] == 0 and info["updated"] == 1
+        assert np.array_equal(pa, pb) and np.array_equal(ha, hb), rep
+        assert S.state_delta(xa, xb) <= 1e-6, rep
+        res.append((xa, Pa))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

@@ -1,0 +1,90 @@
+"""The device's structural form of the reference's rank truncation (Updater.cc:516-529; filter_kernels.hip trunc_finish) on the motions it
+was NOT derived for, free-running on the GPU against the LITERAL oracle (sequential Givens QR + leading-row scan): a platform at rest,
+pure rotation about the camera centre, a constant-velocity straight line, a scene of one common depth — on rendered images (stock
+configuration: CLAHE + device detector) and on direct tracks with many lost features.  tests/test_truncation.py holds the CPU mirror
+of the same rule against the same literal code on the same sequences."""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+MOTIONS = [dict(motion="stationary"), dict(motion="rotation"), dict(motion="line"), dict(scene="sphere")]
+IDS = ["stationary", "rotation", "line", "sphere"]
+COUNTERS = ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")
+
+
+@pytest.mark.parametrize("kw", MOTIONS, ids=IDS)
+def test_degenerate_motion_on_images_tracks_the_literal_oracle(gpu_required, kw):
+    from rvio_amd import hip
+    cfg = abi.config_named("B", enable_equalizer=1)
+    n = 80
+    seq = rv.synth.SynthSequence(cfg, duration=(38 + n + 4) / 20.0, seed=2, **kw)
+    w, a, ni = seq.init_from_static(38)
+    x0, P0 = O.initialize(cfg, w, a, ni)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, ni)
+    lit = O.System(cfg)
+    lit.set_state(x0, P0)
+    worst, updates, early = 0.0, 0, 0
+    for k in range(39, 39 + n):
+        img, imu = seq.render(k), seq.imu_between(k)
+        oi = lit.frame(imu, None, img=img)[0]
+        h.frame(img, imu, None)
+        h.sync()
+        gi = h.frame_info()
+        for key in COUNTERS:
+            assert gi[key] == oi[key], (k, key, gi[key], oi[key])
+        assert gi["device_error"] == 0, (k, gi["device_error"])
+        xa, Pa = h.get_state()
+        xl, Pl = lit.get_state()
+        worst = max(worst, S.state_delta(xa, xl))
+        assert worst <= 1e-6, (k, worst)
+        assert np.max(np.abs(Pa - Pl)) <= 1e-9 * max(1.0, np.max(np.abs(Pl))), k
+        if gi["updated"]:
+            updates += 1
+            c6 = 6 * min(k - 39, cfg.max_track_len - 1)
+            early += 0 <= lit.last_rank() < min(gi["n_rows"], c6)
+        if gi["rank_truncated_at"] >= 0:
+            assert gi["rank_truncated_at"] == lit.last_rank(), k
+    h.close()
+    assert updates >= 15 and early >= updates // 2, (updates, early)     # the literal scan does stop early in these windows
+
+
+@pytest.mark.parametrize("kw", MOTIONS, ids=IDS)
+def test_degenerate_motion_on_direct_tracks(gpu_required, kw):
+    """direct-track mode with 15 % random drops: a dozen type-'1' features of every length per frame beside the type-'2' ones"""
+    from rvio_amd import hip
+    cfg = abi.config_named("B", enable_equalizer=0)
+    n = 100
+    seq = rv.synth.SynthSequence(cfg, duration=(38 + n + 4) / 20.0, seed=4, drop_prob=0.15, **kw)
+    w, a, ni = seq.init_from_static(38)
+    x0, P0 = O.initialize(cfg, w, a, ni)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, ni)
+    lit = O.System(cfg)
+    lit.set_state(x0, P0)
+    drv = rv.synth.DirectTrackDriver(seq)
+    worst, updates = 0.0, 0
+    for k in range(39, 39 + n):
+        inp = drv.inputs(k)
+        oi = lit.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])[0]
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        pts = h.get_points()[0]
+        assert np.array_equal(pts, lit.tracker().get_points()[0]), k
+        drv.after(pts)
+        gi = h.frame_info()
+        for key in ("n_feat_update", "n_feat_accepted", "n_rows", "updated"):
+            assert gi[key] == oi[key], (k, key, gi[key], oi[key])
+        xa, _ = h.get_state()
+        xl, _ = lit.get_state()
+        worst = max(worst, S.state_delta(xa, xl))
+        assert worst <= 1e-6, (k, worst)
+        updates += gi["updated"]
+        if gi["rank_truncated_at"] >= 0:
+            assert gi["rank_truncated_at"] == lit.last_rank(), k
+    h.close()
+    assert updates >= 80
