@@ -4,6 +4,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -152,7 +153,21 @@ System::System(const Settings& s, int device) : s_(s) {
         if (h_) { rvio_hip_destroy(h_); h_ = nullptr; }
     }
 }
-System::~System() { if (h_) rvio_hip_destroy(h_); }
+System::~System() {
+    delete static_cast<std::ofstream*>(f_pose_);
+    delete static_cast<std::ofstream*>(f_time_);
+    if (h_) rvio_hip_destroy(h_);
+}
+
+bool System::record_to(const std::string& dir, bool force) {
+    if (!s_.record_outputs && !force) return true;
+    auto* fp = new std::ofstream(dir + "/stamped_pose_ests.dat", std::ofstream::out);   // System.cc:86-87
+    auto* ft = new std::ofstream(dir + "/time_cost.dat", std::ofstream::out);
+    if (!*fp || !*ft) { delete fp; delete ft; err_ = "cannot write the record files in " + dir; return false; }
+    delete static_cast<std::ofstream*>(f_pose_); delete static_cast<std::ofstream*>(f_time_);
+    f_pose_ = fp; f_time_ = ft; rec_ = true;
+    return true;
+}
 
 int System::MonoVIO(PoseLine* pose) {
     ImageData image;
@@ -196,18 +211,45 @@ int System::MonoVIO(PoseLine* pose) {
     static_assert(sizeof(ImuData) == sizeof(rvio_imu), "ImuData mirrors rvio_imu");
     const rvio_imu* pi = reinterpret_cast<const rvio_imu*>(imus.data() + first);
     const int m = (int)(imus.size() - first);
-    // (one call takes up to RVIO_HIP_MAX_IMU = 192 samples, 0.96 s at 200 Hz: a gap of a few dropped images is integrated in one go as
-    // upstream does, PreIntegrator.cc:97.  The robocentric propagation starts from a freshly composed state — q_k = identity, p_k = 0 —
-    // so a longer gap cannot be split into two propagate calls; it is reported.)
-    if (m > RVIO_HIP_MAX_IMU) { err_ = "more than RVIO_HIP_MAX_IMU inertial samples between two images"; return -1; }
+    // (any number of samples: a gap of a few dropped images is integrated in one go as upstream does, PreIntegrator.cc:96-97; beyond
+    // RVIO_HIP_MAX_IMU = 192 the library grows its staging once)
     if (image.width != s_.cfg.width || image.height != s_.cfg.height) { err_ = "image size does not match Camera.width/height"; return -1; }
     // the timed body of MonoVIO (System.cc:253-367): track -> propagate -> update -> augment -> compose
-    if (rvio_hip_frame(h_, image.px.data(), image.width, pi, m, nullptr, 0) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }
-    if (pose) {
-        pose->t = image.t;
-        if (rvio_hip_get_pose(h_, pose->p, pose->q) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }
+    if (!rec_) {
+        if (rvio_hip_frame(h_, image.px.data(), image.width, pi, m, nullptr, 0) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }
+        if (pose) {
+            pose->t = image.t;
+            if (rvio_hip_get_pose(h_, pose->p, pose->q) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }
+        }
+        return 1;
     }
+    // INI.RecordOutputs: the same body stage by stage with the host waiting behind each, t1 / t2 / t3 taken where upstream takes them
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto fail = [&] { err_ = rvio_hip_last_error(h_); return -1; };
+    const double t1 = now();
+    if (rvio_hip_track(h_, image.px.data(), image.width, pi, m, nullptr, 0) != RVIO_OK || rvio_hip_sync(h_) != RVIO_OK) return fail();   // System.cc:258
+    const double t2 = now();
+    int do_update = 0, do_augment = 0;
+    if (rvio_hip_frame_plan(h_, &do_update, &do_augment) != RVIO_OK) return fail();
+    if (rvio_hip_propagate(h_, pi, m) != RVIO_OK) return fail();                          // System.cc:263
+    if (do_update && rvio_hip_update_tracked(h_) != RVIO_OK) return fail();               // System.cc:266-268
+    if (rvio_hip_augment_compose(h_, do_augment) != RVIO_OK) return fail();               // System.cc:279-365
+    PoseLine pl;
+    pl.t = image.t;
+    if (rvio_hip_get_pose(h_, pl.p, pl.q) != RVIO_OK) return fail();                      // (waits for the filter stream)
+    const double t3 = now();
+    auto& fp = *static_cast<std::ofstream*>(f_pose_);
+    auto& ft = *static_cast<std::ofstream*>(f_time_);
+    fp << format_pose(pl); fp.flush();
+    ft << format_time_cost(n_img_, t2 - t1, t3 - t2); ft.flush();
+    if (pose) *pose = pl;
     return 1;
+}
+
+std::string format_time_cost(int n_img, double track_ms, double filter_ms) {   // nImageCountAfterInit, 1e3 (t2-t1), 1e3 (t3-t2); setprecision(19)
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "%d %.19g %.19g\n", n_img, track_ms, filter_ms);
+    return buf;
 }
 
 std::string format_pose(const PoseLine& p) {

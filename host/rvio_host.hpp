@@ -73,6 +73,12 @@ public:
     // System::MonoVIO.  Returns 1 if a frame went through the filter (pose valid), 0 if nothing was processed or the filter is
     // still waiting for motion, <0 on a library error.
     int MonoVIO(PoseLine* pose);
+    // INI.RecordOutputs (System.cc:81-88): open <dir>/stamped_pose_ests.dat and <dir>/time_cost.dat (upstream: the package directory).
+    // While recording, a frame runs stage by stage like upstream — Tracker::track, then propagate / update / augment / compose, the host
+    // waiting behind each — so that the two spans of time_cost.dat (System.cc:254-260,367: t2-t1 and t3-t2, milliseconds) mean what they
+    // mean there; without it the frame is one pipelined rvio_hip_frame call.  No-op unless the settings ask for it (or `force`).
+    bool record_to(const std::string& dir, bool force = false);
+    bool recording() const { return rec_; }
     bool is_ready() const { return ready_; }
     int frames_after_init() const { return n_img_; }
     rvio_hip* handle() { return h_; }
@@ -85,6 +91,9 @@ private:
     bool moving_ = false, ready_ = false;
     double wm_[3] = {0, 0, 0}, am_[3] = {0, 0, 0};
     int n_imu_ = 0, n_img_ = 0;
+    bool rec_ = false;
+    void* f_pose_ = nullptr;      // std::ofstream* (kept out of the header)
+    void* f_time_ = nullptr;
 };
 
 // 8-bit grayscale PNG (non-interlaced) or binary PGM (P5, maxval 255)
@@ -98,5 +107,6 @@ struct AslDataset {
 bool read_asl(const std::string& root, AslDataset* out, std::string* err);
 
 std::string format_pose(const PoseLine& p);               // one line of stamped_pose_ests.dat, setprecision(19)
+std::string format_time_cost(int n_img, double track_ms, double filter_ms);   // one line of time_cost.dat (System.cc:376-378)
 
 }  // namespace rvio

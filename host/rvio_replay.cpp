@@ -62,14 +62,17 @@ int main(int argc, char** argv) {
     if (argc >= 3 && !std::strcmp(argv[1], "--check-dataset")) return check_dataset(argv[2]);
     if (argc >= 3 && !std::strcmp(argv[1], "--check-image")) return check_image(argv[2]);
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <settings.yaml> <asl_root> [<poses_out.dat>] [--device N] [--max-frames K]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <settings.yaml> <asl_root> [<poses_out.dat>] [--device N] [--max-frames K] [--record-dir DIR] [--record]\n", argv[0]);
         return 2;
     }
     const char* out_path = nullptr;
     int device = 0; long max_frames = -1;
+    const char* record_dir = "."; bool force_record = false;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--max-frames") && i + 1 < argc) max_frames = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--record-dir") && i + 1 < argc) record_dir = argv[++i];   // where INI.RecordOutputs: 1 writes its two files
+        else if (!std::strcmp(argv[i], "--record")) force_record = true;                          // as if the settings said INI.RecordOutputs: 1
         else out_path = argv[i];
     }
     Settings s; std::string err;
@@ -79,6 +82,7 @@ int main(int argc, char** argv) {
     if (!read_asl(argv[2], &d, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
     System sys(s, device);
     if (!sys.ok()) { std::fprintf(stderr, "%s\n", sys.error().c_str()); return 1; }
+    if (!sys.record_to(record_dir, force_record)) { std::fprintf(stderr, "%s\n", sys.error().c_str()); return 1; }
     std::ofstream out;
     if (out_path) { out.open(out_path); if (!out) { std::fprintf(stderr, "cannot write %s\n", out_path); return 1; } }
 

@@ -32,8 +32,9 @@ extern "C" {
 #endif
 
 #define RVIO_HIP_ABI_VERSION 2
-/* IMU samples one call accepts (0.96 s at 200 Hz: a few dropped images).  The robocentric propagation starts from a freshly
- * composed state (PreIntegrator.cc:63-70 after System.cc:325-365), so a longer gap cannot be split over two calls. */
+/* IMU samples the staging of the host-buffer entry points is allocated for (0.96 s at 200 Hz).  PreIntegrator::propagate iterates any
+ * list (PreIntegrator.cc:96-97), and so does every entry point here: a longer batch (dropped images) is accepted — the staging grows once,
+ * at the price of one host synchronisation; the _dev entry points take any m. */
 #define RVIO_HIP_MAX_IMU 192
 
 typedef enum rvio_status {

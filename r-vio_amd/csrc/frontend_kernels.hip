@@ -241,15 +241,20 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     const int tid = threadIdx.x, N = *n_pts_ptr;
     // one batch of global reads: RNG state, IMU samples (-> per-sample delta rotations), the points
     if (tid < 35) s_rng[tid] = rng[tid];
-    if (tid >= 64 && tid < 64 + m) {   // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal): per-sample dR
-        const int s = tid - 64;
+    // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal): per-sample dR
+    auto gyro_dR = [&](int s) {
         const m33 I = eye33();
         const d3 wm = mk3(imu[s].w[0], imu[s].w[1], imu[s].w[2]);
         const double dt = imu[s].dt, w1 = nrm3(wm), wdt = w1 * dt;
         const m33 wx = skew33(wm), wx2 = mul33(wx, wx);
-        m33 dR;
-        if (w1 < cfg.small_angle) dR = add33(sub33(I, scl33(dt, wx)), scl33(.5 * dt * dt, wx2));
-        else dR = add33(sub33(I, scl33(sin(wdt) / w1, wx)), scl33((1 - cos(wdt)) / (w1 * w1), wx2));
+        if (w1 < cfg.small_angle) return add33(sub33(I, scl33(dt, wx)), scl33(.5 * dt * dt, wx2));
+        return add33(sub33(I, scl33(sin(wdt) / w1, wx)), scl33((1 - cos(wdt)) / (w1 * w1), wx2));
+    };
+    const int m_lds = m < RVIO_MAX_IMU ? m : RVIO_MAX_IMU;   // one delta rotation per thread for the first RVIO_MAX_IMU samples; a longer batch
+                                                             // (dropped images) forms the remaining ones inside the product loop below
+    if (tid >= 64 && tid < 64 + m_lds) {
+        const int s = tid - 64;
+        const m33 dR = gyro_dR(s);
         for (int k = 0; k < 9; ++k) dRs[s][k] = dR.m[k];
     }
     for (int i = tid; i < N; i += 256) undistort_pt(cfg, tracked[2 * i], tracked[2 * i + 1], &un2[2 * i], &un2[2 * i + 1]);
@@ -282,7 +287,8 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     if (tid < 16) {
         const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
         m33 R = eye33();
-        for (int s = 0; s < m; ++s) R = mul33(ldm33(dRs[s]), R);
+        for (int s = 0; s < m_lds; ++s) R = mul33(ldm33(dRs[s]), R);
+        for (int s = m_lds; s < m; ++s) R = mul33(gyro_dR(s), R);
         R = mul33(mul33(Rci, R), Ric);
         // SetRansacModel, Ransac.cc:86-117
         const int ia = pairs[tid][0], ib = pairs[tid][1];

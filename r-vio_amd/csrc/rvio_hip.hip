@@ -61,6 +61,7 @@ struct rvio_hip {
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
+    int imu_cap = RVIO_MAX_IMU;   // samples the host-side staging (d_imu, hb_imu, pinned ring) holds; grows on demand (ensure_imu_capacity)
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
     DetDev det = {}, det_b = {};                  // device detector (T7), allocated on first use: two sets of scratch — in run-ahead mode the
@@ -314,6 +315,24 @@ static int alloc_frontend_slab(rvio_hip* h) {
     return RVIO_OK;
 }
 
+// The four streams of a handle each need a hardware queue of their own: the run-ahead pipeline is four concurrent chains, and two of them
+// on one queue serialise (measured: 4.5 k instead of 6.6 k frames/s).  hipStreamCreate deals streams onto a pool of GPU_MAX_HW_QUEUES (4)
+// shared queues by reference count, so whether a handle gets four distinct ones depends on every stream the process created before it
+// (torch's, another library's).  A stream created with a CU mask owns a private queue; the mask here enables every CU.
+static hipError_t make_stream(rvio_hip* h, hipStream_t* s) {
+    static const int mode = getenv("RVIO_STREAM_MODE") ? atoi(getenv("RVIO_STREAM_MODE")) : 1;
+    if (mode == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, h->device);
+    if (e != hipSuccess) return e;
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    std::vector<uint32_t> mask((size_t)std::max(words, 1), 0xffffffffu);
+    if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    e = hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+    return e;
+}
+
 static int create_impl(const rvio_config* cfg, int device, int batch, bool front_end, rvio_hip** out) {
     if (!cfg || !out) return RVIO_ERR_INVALID;
     *out = nullptr;
@@ -331,16 +350,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
     *out = h;   // returned even on allocation failure so last_error is readable
     HIPCHK(h, hipSetDevice(device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, make_stream(h, &h->stream));
     h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
-    if (h->one_stream) h->stream_t = h->stream;
-    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_t, hipStreamNonBlocking));
-    // the side stream is created here, right behind the other two: HIP deals its streams onto the hardware queues in creation order,
-    // so three streams created back to back land on three different queues
-    if (h->one_stream) h->stream_d = h->stream;
-    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_d, hipStreamNonBlocking));
-    if (h->one_stream) h->stream_c = h->stream;
-    else HIPCHK(h, hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));   // the fourth of HIP's four hardware queues
+    if (h->one_stream) h->stream_t = h->stream_d = h->stream_c = h->stream;
+    else {
+        HIPCHK(h, make_stream(h, &h->stream_t));
+        HIPCHK(h, make_stream(h, &h->stream_d));
+        HIPCHK(h, make_stream(h, &h->stream_c));
+    }
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, kEvFlags));
     for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->evC[b], kEvFlags));
@@ -612,6 +629,28 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 }
 
 // ------------------------------------------------------------------ P1
+// PreIntegrator::propagate iterates whatever list it is handed (PreIntegrator.cc:96-97) — a dropped image or a stalled camera driver makes
+// that list long.  The kernels take any m (propagate and RANSAC's gyro prior walk the samples in chunks); what is sized is the staging of
+// the HOST-buffer entry points: RVIO_HIP_MAX_IMU samples are allocated up front, a longer batch grows it once (the host waits for the
+// handle's streams, allocates, goes on) instead of being refused.
+static int ensure_imu_capacity(rvio_hip* h, int m) {
+    if (m <= h->imu_cap) return RVIO_OK;
+    int rc = rvio_hip_sync(h);
+    if (rc != RVIO_OK) return rc;
+    const int cap = std::max(2 * h->imu_cap, (m + 63) & ~63);
+    auto grow = [&](rvio_imu** p) -> int {
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, sizeof(rvio_imu) * (size_t)cap));
+        h->allocs.push_back(q);      // (the old block stays where it was — a slab member, or a block freed with the handle)
+        *p = (rvio_imu*)q;
+        return RVIO_OK;
+    };
+    if ((rc = grow(&h->d_imu)) != RVIO_OK) return rc;
+    for (int k = 0; k < 3; ++k) if (h->hb_imu[k] && (rc = grow(&h->hb_imu[k])) != RVIO_OK) return rc;
+    for (int k = 0; k < rvio_hip::kPin; ++k) if (h->pin[k]) { hipHostFree(h->pin[k]); h->pin[k] = nullptr; }   // rvio_hip_frame lays the ring out again
+    h->imu_cap = cap;
+    return RVIO_OK;
+}
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0) {   // imu_bs = 0: every instance integrates the same samples
     static const bool prop_b = getenv("RVIO_NO_PROP_B") == nullptr;   // A/B timing
     if (h->batch > 8 && prop_b)
@@ -624,8 +663,9 @@ static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_b
     return RVIO_OK;
 }
 int rvio_hip_propagate(rvio_hip* h, const rvio_imu* imu, int m) {
-    if (!h || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    if (!h || (!imu && m > 0) || m < 0) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rcg = ensure_imu_capacity(h, m); if (rcg != RVIO_OK) return rcg; }
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
     return propagate_dev(h, h->d_imu, m);
 }
@@ -1071,15 +1111,16 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     return rc;
 }
 int rvio_hip_track_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
-    if (!h || !d_img || m < 0 || m > RVIO_MAX_IMU || n_cand < 0) return RVIO_ERR_INVALID;
+    if (!h || !d_img || m < 0 || n_cand < 0) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     return track_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand);
 }
 
 int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    if (!h || !img || (!imu && m > 0) || m < 0 || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rcg = ensure_imu_capacity(h, m); if (rcg != RVIO_OK) return rcg; }
     const int nc = std::min(n_cand, h->dc.F);
     HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->dc.W, img, stride, h->dc.W, h->dc.H, hipMemcpyHostToDevice, h->stream));
     if (m > 0) HIPCHK(h, hipMemcpyAsync(h->d_imu, imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream));
@@ -1090,9 +1131,10 @@ int rvio_hip_track(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
 // direct-track mode: the caller supplies the KLT result
 int rvio_hip_track_points(rvio_hip* h, const float* tracked_xy, const unsigned char* status, int n_pts,
                           const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
+    if (!h || (!imu && m > 0) || m < 0 || n_cand < 0 || n_pts < 0 || n_pts > h->dc.F) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rcg = ensure_imu_capacity(h, m); if (rcg != RVIO_OK) return rcg; }
     const int nc = std::min(n_cand, h->dc.F);
     if (n_pts > 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_in_xy, tracked_xy, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, h->stream));
@@ -1167,7 +1209,7 @@ int rvio_hip_frame_plan(rvio_hip* h, int* do_update, int* do_augment) {
     return RVIO_OK;
 }
 int rvio_hip_propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m) {
-    if (!h || (!d_imu && m > 0) || m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    if (!h || (!d_imu && m > 0) || m < 0) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     return propagate_dev(h, d_imu, m);
 }
@@ -1193,7 +1235,7 @@ static int frame_tail_dev(rvio_hip* h, const rvio_imu* d_imu, int m, bool propag
 // of rvio_tracks with max_len = max_track_len), d_imu[B][imu_stride] (imu_stride = 0: one IMU batch shared by all instances).
 int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride, int m, const int32_t* d_n_feat, const unsigned char* d_types,
                               const int32_t* d_len, const float* d_meas) {
-    if (!h || (!d_imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || imu_stride < 0 || (imu_stride > 0 && imu_stride < m)) return RVIO_ERR_INVALID;
+    if (!h || (!d_imu && m > 0) || m < 0 || imu_stride < 0 || (imu_stride > 0 && imu_stride < m)) return RVIO_ERR_INVALID;
     if (!d_n_feat || !d_types || !d_len || !d_meas) return RVIO_ERR_INVALID;
     if (h->piped || h->in_frame) { h->err = "rvio_hip_frame_tracks_dev on a handle that runs the pipelined image path"; return RVIO_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1236,7 +1278,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
         else { h->book_dev = true; h->book_target = h->fin_target[b]; }
     } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
-    if (m < 0 || m > RVIO_MAX_IMU) return RVIO_ERR_INVALID;
+    if (m < 0) return RVIO_ERR_INVALID;
     static const bool dbg_host = getenv("RVIO_DBG_HOST") != nullptr;
     static double acc[5] = {0, 0, 0, 0, 0}; static long nacc = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1323,33 +1365,34 @@ int rvio_hip_frame_end(rvio_hip* h) {
 // The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap
 // the previous frame's filter work like the tracker kernels do.
 int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* imu, int m, const float* cand_xy, int n_cand) {
-    if (!h || !img || (!imu && m > 0) || m < 0 || m > RVIO_MAX_IMU || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
+    if (!h || !img || (!imu && m > 0) || m < 0 || n_cand < 0 || stride < h->dc.W) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rcg = ensure_imu_capacity(h, m); if (rcg != RVIO_OK) return rcg; }
     const int nc = cand_xy ? std::min(n_cand, h->dc.F) : 0;   // cand_xy == NULL: device detector
     if (!h->hb_img[0])
         for (int k = 0; k < 2; ++k) {
             DALLOC(h, h->hb_img[k], (size_t)h->dc.W * h->dc.H);
-            DALLOC(h, h->hb_imu[k], (size_t)RVIO_MAX_IMU);
-            if (k == 1) DALLOC(h, h->hb_imu[2], (size_t)RVIO_MAX_IMU);
+            DALLOC(h, h->hb_imu[k], (size_t)h->imu_cap);
+            if (k == 1) DALLOC(h, h->hb_imu[2], (size_t)h->imu_cap);
             DALLOC(h, h->hb_cand[k], (size_t)2 * h->dc.F);
             HIPCHK(h, hipStreamSynchronize(h->stream));   // DALLOC clears on the filter stream
         }
     const size_t npx = (size_t)h->dc.W * h->dc.H;
     if (!h->pin[0]) {
         h->pin_img = 0; h->pin_imu = (npx + 255) & ~(size_t)255;
-        const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
+        const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * (size_t)h->imu_cap + 255) & ~(size_t)255);
         h->pin_bytes = pin_cand + sizeof(float) * 2 * h->dc.F;
         for (int k = 0; k < rvio_hip::kPin; ++k) {
             HIPCHK(h, hipHostMalloc((void**)&h->pin[k], h->pin_bytes, hipHostMallocDefault));
-            HIPCHK(h, hipEventCreateWithFlags(&h->evPin[k], kEvFlags));
-            HIPCHK(h, hipEventCreateWithFlags(&h->evPin2[k], kEvFlags));
+            if (!h->evPin[k]) HIPCHK(h, hipEventCreateWithFlags(&h->evPin[k], kEvFlags));     // (the ring is laid out again after ensure_imu_capacity)
+            if (!h->evPin2[k]) HIPCHK(h, hipEventCreateWithFlags(&h->evPin2[k], kEvFlags));
         }
     }
     const int b = (int)(h->frame_no & 1);
     const int ps = (int)(h->frame_no % rvio_hip::kPin);
     uint8_t* pp = h->pin[ps];
-    const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * RVIO_MAX_IMU + 255) & ~(size_t)255);
+    const size_t pin_cand = h->pin_imu + ((sizeof(rvio_imu) * (size_t)h->imu_cap + 255) & ~(size_t)255);
     HIPCHK(h, hipEventSynchronize(h->evPin[ps]));   // the copies issued from this slot three frames ago are done (no-op before its first use)
     HIPCHK(h, hipEventSynchronize(h->evPin2[ps]));
     if (stride == h->dc.W) std::memcpy(pp, img, npx);   // (a continuous cv::Mat: one copy)

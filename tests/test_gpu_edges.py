@@ -158,3 +158,54 @@ def test_fisheye_camera(gpu_required):
             assert np.all(np.abs(un - want) <= np.spacing(np.abs(want)).astype(np.float32))
     h.close()
     assert recs[-1]["did_update"] and worst <= 1e-6, worst
+
+
+def test_imu_batches_longer_than_the_preallocated_staging(gpu_required, seqB):
+    """PreIntegrator::propagate iterates any list (PreIntegrator.cc:96-97): dropped images make it long.  Frames 5 and 8 of the sequence
+    are dropped, then a 1.5 s camera outage (300 samples > RVIO_HIP_MAX_IMU = 192): the IMU batch of the next frame is the union of the
+    gaps.  Through rvio_hip_frame (host buffers: the staging grows once), rvio_hip_propagate and the _dev entry points; RANSAC's gyro
+    prior (Ransac.cc:120-155) walks all of them too.  Tracker tables bit-exact, states within 1e-6 of the oracle."""
+    from rvio_amd import hip
+    import torch
+    cfg, seq, ks, imgs = seqB
+    w, a, n = seq.init_from_static(38)
+    x0, P0 = O.initialize(cfg, w, a, n)
+    # direct check of propagate alone: 500 samples in one call
+    imu_all = seq.imu_all()
+    long_imu = np.ascontiguousarray(imu_all[400:900])
+    h = hip.RvioHip(cfg)
+    h.set_state(x0, P0)
+    h.propagate(long_imu)
+    xa, Pa = h.get_state()
+    xb, Pb = O.propagate(cfg, x0, P0, long_imu)
+    assert S.state_delta(xa, xb) <= 1e-9 and np.max(np.abs(Pa - Pb)) <= 1e-9 * max(1.0, np.max(np.abs(Pb)))
+    d_imu = torch.from_numpy(long_imu.view(np.uint8)).cuda()
+    torch.cuda.synchronize()
+    h.set_state(x0, P0)
+    h.propagate_dev(d_imu.data_ptr(), len(long_imu))
+    xc, _ = h.get_state()
+    assert np.array_equal(xa, xc)
+    h.close()
+    # the whole frame with gaps
+    frames = [60, 61, 62, 63, 64, 66, 67, 69, 70, 71, 72, 73, 104, 105, 106]      # 65 and 68 dropped; 74..103 = a 1.5 s outage
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    s = O.System(cfg)
+    s.set_state(x0, P0)
+    t = s.tracker()
+    prev, longest = None, 0
+    for k in frames:
+        imu = seq.imu_between(k) if prev is None else np.concatenate([seq.imu_between(j) for j in range(prev + 1, k + 1)])
+        prev = k
+        longest = max(longest, len(imu))
+        img = seq.render(k)
+        s.frame(imu, None, img=img)
+        h.frame(img, imu)
+        h.sync()
+        _same_tracker(h, t, k)
+        xa, _ = h.get_state()
+        xb, _ = s.get_state()
+        assert S.state_delta(xa, xb) <= 1e-6, k
+        assert h.frame_info()["device_error"] == 0
+    h.close()
+    assert longest > 192

@@ -110,3 +110,38 @@ def test_replay_matches_the_oracle_host_loop(gpu_required, tmp_path, as_png):
     assert np.array_equal(got[:, 0], want[:, 0])             # same frames went through the filter
     q = got[:, 4:8] * np.sign(got[:, 7:8]) - want[:, 4:8] * np.sign(want[:, 7:8])
     assert np.abs(got[:, 1:4] - want[:, 1:4]).max() <= 1e-6 and np.abs(q).max() <= 1e-6
+
+
+def test_record_outputs_writes_the_references_two_files(gpu_required, tmp_path):
+    """INI.RecordOutputs: 1 (System.cc:81-88,369-380): stamped_pose_ests.dat and time_cost.dat in the record directory; the frame then runs
+    stage by stage (the two spans of time_cost.dat are host wall clock around Tracker::track and around propagate .. compose, as upstream),
+    and the poses are those of the pipelined path (same oracle bar)."""
+    cfg = abi.config_named("A", enable_equalizer=1)
+    seq = rv.synth.SynthSequence(cfg, duration=4.0)
+    frames = list(range(30, 30 + 30))
+    root = str(tmp_path)
+    write_asl(root, seq, frames, as_png=False)
+    yaml = tmp_path / "rvio_euroc.yaml"
+    yaml.write_text(EUROC_YAML.replace("INI.RecordOutputs: 0", "INI.RecordOutputs: 1") if "INI.RecordOutputs: 0" in EUROC_YAML else EUROC_YAML + "\nINI.RecordOutputs: 1\n")
+    rec = tmp_path / "rec"
+    rec.mkdir()
+    piped = tmp_path / "piped.dat"
+    r = subprocess.run([ensure_bin(), str(yaml), root, "--record-dir", str(rec)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    yaml0 = tmp_path / "rvio_euroc0.yaml"
+    yaml0.write_text(EUROC_YAML)
+    r0 = subprocess.run([ensure_bin(), str(yaml0), root, str(piped)], capture_output=True, text=True)
+    assert r0.returncode == 0, r0.stderr
+    got = np.loadtxt(str(rec / "stamped_pose_ests.dat"), ndmin=2)
+    tc = np.loadtxt(str(rec / "time_cost.dat"), ndmin=2)
+    want = oracle_replay(cfg, root, seq, frames)
+    assert got.shape == want.shape and len(got) >= 5
+    assert np.array_equal(got[:, 0], want[:, 0])
+    q = got[:, 4:8] * np.sign(got[:, 7:8]) - want[:, 4:8] * np.sign(want[:, 7:8])
+    assert np.abs(got[:, 1:4] - want[:, 1:4]).max() <= 1e-6 and np.abs(q).max() <= 1e-6
+    # time_cost.dat: nImageCountAfterInit, track ms, filter ms — one line per filtered frame, counting from 1
+    assert tc.shape == (len(got), 3) and np.array_equal(tc[:, 0], np.arange(1, len(got) + 1))
+    assert np.all(tc[:, 1] > 0) and np.all(tc[:, 2] > 0) and np.all(tc[:, 1:] < 50.0)
+    # the staged frame and the pipelined frame are the same arithmetic
+    pp = np.loadtxt(str(piped), ndmin=2)
+    assert pp.shape == got.shape and np.abs(pp - got).max() <= 1e-9
