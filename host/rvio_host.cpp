@@ -84,7 +84,7 @@ bool parse_settings(const std::string& text, Settings* out, std::string* err) {
         auto it = y.num.find(k);
         if (it != y.num.end()) return it->second;
         const std::string ks(k);
-        if (ks != "Camera.k3" && ks != "Camera.Fisheye" && ks != "Camera.nTimeOffset" && ks != "INI.RecordOutputs") out->missing.push_back(ks);
+        if (ks != "Camera.k3" && ks != "Camera.Fisheye" && ks != "Camera.nTimeOffset" && ks != "INI.RecordOutputs" && ks != "Camera.RGB") out->missing.push_back(ks);
         return dflt;
     };
     c.imu_rate = num("IMU.dps", c.imu_rate);
@@ -116,6 +116,7 @@ bool parse_settings(const std::string& text, Settings* out, std::string* err) {
     c.ini_enable_alignment = (int)num("INI.EnableAlignment", c.ini_enable_alignment);
     out->cam_time_offset = num("Camera.nTimeOffset", 0.0);
     out->record_outputs = (int)num("INI.RecordOutputs", 0.0);
+    out->is_rgb = (int)num("Camera.RGB", 0.0);
     return true;
 }
 
@@ -214,6 +215,7 @@ int System::MonoVIO(PoseLine* pose) {
     // (any number of samples: a gap of a few dropped images is integrated in one go as upstream does, PreIntegrator.cc:96-97; beyond
     // RVIO_HIP_MAX_IMU = 192 the library grows its staging once)
     if (image.width != s_.cfg.width || image.height != s_.cfg.height) { err_ = "image size does not match Camera.width/height"; return -1; }
+    to_gray(&image, s_.is_rgb != 0);                   // Tracker.cc:182-196
     // the timed body of MonoVIO (System.cc:253-367): track -> propagate -> update -> augment -> compose
     if (!rec_) {
         if (rvio_hip_frame(h_, image.px.data(), image.width, pi, m, nullptr, 0) != RVIO_OK) { err_ = rvio_hip_last_error(h_); return -1; }
@@ -259,12 +261,25 @@ std::string format_pose(const PoseLine& p) {
 }
 
 // ------------------------------------------------------------------ images
+void to_gray(ImageData* im, bool is_rgb) {
+    const int c = im->channels;
+    if (c != 3 && c != 4) return;
+    const size_t n = (size_t)im->width * im->height;
+    const int ir = is_rgb ? 0 : 2, ib = is_rgb ? 2 : 0;          // byte position of R and B inside a pixel
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* p = &im->px[i * c];
+        im->px[i] = (uint8_t)((p[ir] * 4899 + p[1] * 9617 + p[ib] * 1868 + (1 << 13)) >> 14);   // cv::cvtColor 8u: R2Y, G2Y, B2Y, yuv_shift = 14
+    }
+    im->px.resize(n);
+    im->channels = 1;
+}
+
 bool decode_png_gray8(const uint8_t* d, size_t n, ImageData* out, std::string* err) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (n < 8 || std::memcmp(d, sig, 8) != 0) { if (err) *err = "not a PNG"; return false; }
     auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
     size_t o = 8;
-    uint32_t w = 0, h = 0;
+    uint32_t w = 0, h = 0, bpp = 1;
     std::vector<uint8_t> z;
     bool have_hdr = false;
     while (o + 12 <= n) {
@@ -274,24 +289,26 @@ bool decode_png_gray8(const uint8_t* d, size_t n, ImageData* out, std::string* e
         const uint8_t* p = d + o + 8;
         if (!std::memcmp(type, "IHDR", 4)) {
             w = be32(o + 8); h = be32(o + 12);
-            if (p[8] != 8 || p[9] != 0 || p[12] != 0) { if (err) *err = "PNG: only 8-bit grayscale, non-interlaced images are supported"; return false; }
+            if (p[8] != 8 || (p[9] != 0 && p[9] != 2 && p[9] != 6) || p[12] != 0) { if (err) *err = "PNG: only 8-bit gray / RGB / RGBA, non-interlaced images are supported"; return false; }
+            bpp = p[9] == 0 ? 1 : (p[9] == 2 ? 3 : 4);
             have_hdr = true;
         } else if (!std::memcmp(type, "IDAT", 4)) z.insert(z.end(), p, p + len);
         else if (!std::memcmp(type, "IEND", 4)) break;
         o += 12 + len;
     }
     if (!have_hdr || w == 0 || h == 0) { if (err) *err = "PNG: no header"; return false; }
-    std::vector<uint8_t> raw((size_t)(w + 1) * h);
+    const size_t rowb = (size_t)w * bpp;
+    std::vector<uint8_t> raw((rowb + 1) * h);
     uLongf rl = (uLongf)raw.size();
     if (uncompress(raw.data(), &rl, z.data(), (uLong)z.size()) != Z_OK || rl != raw.size()) { if (err) *err = "PNG: inflate failed"; return false; }
-    out->width = (int)w; out->height = (int)h; out->px.assign((size_t)w * h, 0);
-    for (uint32_t y = 0; y < h; ++y) {                 // un-filter (bpp = 1)
-        const uint8_t ft = raw[(size_t)y * (w + 1)];
-        const uint8_t* s = &raw[(size_t)y * (w + 1) + 1];
-        uint8_t* r = &out->px[(size_t)y * w];
-        const uint8_t* up = y ? r - w : nullptr;
-        for (uint32_t x = 0; x < w; ++x) {
-            const int a = x ? r[x - 1] : 0, b = up ? up[x] : 0, c = (x && up) ? up[x - 1] : 0;
+    out->width = (int)w; out->height = (int)h; out->channels = (int)bpp; out->px.assign(rowb * h, 0);
+    for (uint32_t y = 0; y < h; ++y) {                 // un-filter
+        const uint8_t ft = raw[(size_t)y * (rowb + 1)];
+        const uint8_t* s = &raw[(size_t)y * (rowb + 1) + 1];
+        uint8_t* r = &out->px[(size_t)y * rowb];
+        const uint8_t* up = y ? r - rowb : nullptr;
+        for (size_t x = 0; x < rowb; ++x) {
+            const int a = x >= bpp ? r[x - bpp] : 0, b = up ? up[x] : 0, c = (x >= bpp && up) ? up[x - bpp] : 0;
             int pred = 0;
             switch (ft) {
                 case 0: pred = 0; break;
@@ -312,7 +329,8 @@ bool read_image(const std::string& path, ImageData* out, std::string* err) {
     std::ifstream f(path, std::ios::binary);
     if (!f) { if (err) *err = "cannot open " + path; return false; }
     std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    if (buf.size() >= 2 && buf[0] == 'P' && buf[1] == '5') {   // binary PGM: P5 <w> <h> <maxval> <single whitespace> data
+    if (buf.size() >= 2 && buf[0] == 'P' && (buf[1] == '5' || buf[1] == '6')) {   // binary PGM / PPM: P5|P6 <w> <h> <maxval> <single whitespace> data
+        const size_t ch = buf[1] == '6' ? 3 : 1;
         size_t o = 2;
         long v[3];
         for (int k = 0; k < 3; ++k) {
@@ -323,9 +341,9 @@ bool read_image(const std::string& path, ImageData* out, std::string* err) {
             v[k] = x;
         }
         ++o;
-        if (v[2] != 255 || o + (size_t)v[0] * v[1] > buf.size()) { if (err) *err = "PGM: only maxval 255 is supported (" + path + ")"; return false; }
-        out->width = (int)v[0]; out->height = (int)v[1];
-        out->px.assign(buf.begin() + o, buf.begin() + o + (size_t)v[0] * v[1]);
+        if (v[2] != 255 || o + (size_t)v[0] * v[1] * ch > buf.size()) { if (err) *err = "PGM/PPM: only maxval 255 is supported (" + path + ")"; return false; }
+        out->width = (int)v[0]; out->height = (int)v[1]; out->channels = (int)ch;
+        out->px.assign(buf.begin() + o, buf.begin() + o + (size_t)v[0] * v[1] * ch);
         return true;
     }
     std::string e;

@@ -26,16 +26,21 @@ struct ImuData {          // InputBuffer.h:35-51
     double w[3], a[3];
     double t, dt;
 };
-struct ImageData {        // InputBuffer.h:53-63 (cv::Mat mono8 -> packed bytes)
+struct ImageData {        // InputBuffer.h:53-63 (cv::Mat -> packed bytes, `channels` interleaved bytes per pixel: 1, 3 or 4)
     std::vector<uint8_t> px;
     int width = 0, height = 0;
+    int channels = 1;
     double t = 0;
 };
+// Tracker::track's "Convert to gray scale" (Tracker.cc:182-196): cvtColor CV_RGB2GRAY / CV_BGR2GRAY (3 channels) or the RGBA / BGRA forms
+// (4 channels, alpha ignored) on 8-bit data = OpenCV's fixed-point  (R 4899 + G 9617 + B 1868 + 8192) >> 14.  In place; 1 channel: no-op.
+void to_gray(ImageData* im, bool is_rgb);
 
 struct Settings {
     rvio_config cfg;              // everything the hot path needs
     double cam_time_offset = 0;   // Camera.nTimeOffset
     int record_outputs = 0;       // INI.RecordOutputs
+    int is_rgb = 0;               // Camera.RGB (Tracker.cc:64-65): channel order of a 3 / 4-channel image, 1 = RGB(A), 0 = BGR(A)
     std::vector<std::string> missing;   // keys the reference reads (cv::FileStorage would yield 0 for them) that the file does not hold:
                                         // they keep the EuRoC defaults here, and the caller is told (rvio_replay prints them)
 };
@@ -96,7 +101,7 @@ private:
     void* f_time_ = nullptr;
 };
 
-// 8-bit grayscale PNG (non-interlaced) or binary PGM (P5, maxval 255)
+// 8-bit PNG (non-interlaced; gray, RGB or RGBA: channels in file order = RGB) or binary PGM / PPM (P5 / P6, maxval 255)
 bool read_image(const std::string& path, ImageData* out, std::string* err);
 bool decode_png_gray8(const uint8_t* data, size_t n, ImageData* out, std::string* err);
 

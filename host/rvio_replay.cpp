@@ -28,11 +28,11 @@ static int check_settings(const char* path) {
                 "\"k1\": %.9g, \"k2\": %.9g, \"p1\": %.9g, \"p2\": %.9g, \"k3\": %.9g, \"sigma_px\": %.9g, \"sigma_py\": %.9g, \"fisheye\": %d, "
                 "\"n_features\": %d, \"max_track_len\": %d, \"min_track_len\": %d, \"min_dist\": %.9g, \"qual_lvl\": %.9g, \"block_x\": %.9g, "
                 "\"block_y\": %.9g, \"enable_equalizer\": %d, \"use_sampson\": %d, \"inlier_thr\": %.17g, \"ini_thr_angle\": %.17g, "
-                "\"ini_thr_displ\": %.17g, \"ini_enable_alignment\": %d, \"cam_time_offset\": %.17g, \"record_outputs\": %d, \"T_bc\": [",
+                "\"ini_thr_displ\": %.17g, \"ini_enable_alignment\": %d, \"cam_time_offset\": %.17g, \"record_outputs\": %d, \"is_rgb\": %d, \"T_bc\": [",
                 c.imu_rate, c.sigma_g, c.sigma_wg, c.sigma_a, c.sigma_wa, c.gravity, c.small_angle, c.width, c.height, c.fx, c.fy, c.cx, c.cy,
                 c.k1, c.k2, c.p1, c.p2, c.k3, c.sigma_px, c.sigma_py, c.fisheye, c.n_features, c.max_track_len, c.min_track_len, c.min_dist,
                 c.qual_lvl, c.block_x, c.block_y, c.enable_equalizer, c.use_sampson, c.inlier_thr, c.ini_thr_angle, c.ini_thr_displ,
-                c.ini_enable_alignment, s.cam_time_offset, s.record_outputs);
+                c.ini_enable_alignment, s.cam_time_offset, s.record_outputs, s.is_rgb);
     for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", c.T_bc[i]);
     std::printf("]}\n");
     return 0;
@@ -48,19 +48,21 @@ static int check_dataset(const char* root) {
     return 0;
 }
 
-static int check_image(const char* path) {
+static int check_image(const char* path, bool is_rgb) {
     ImageData im; std::string err;
     if (!read_image(path, &im, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    const int channels = im.channels;
+    to_gray(&im, is_rgb);
     unsigned long long sum = 0, wsum = 0;
     for (size_t i = 0; i < im.px.size(); ++i) { sum += im.px[i]; wsum += (unsigned long long)im.px[i] * (i % 251 + 1); }
-    std::printf("{\"width\": %d, \"height\": %d, \"sum\": %llu, \"wsum\": %llu}\n", im.width, im.height, sum, wsum);
+    std::printf("{\"width\": %d, \"height\": %d, \"channels\": %d, \"sum\": %llu, \"wsum\": %llu}\n", im.width, im.height, channels, sum, wsum);
     return 0;
 }
 
 int main(int argc, char** argv) {
     if (argc >= 3 && !std::strcmp(argv[1], "--check-settings")) return check_settings(argv[2]);
     if (argc >= 3 && !std::strcmp(argv[1], "--check-dataset")) return check_dataset(argv[2]);
-    if (argc >= 3 && !std::strcmp(argv[1], "--check-image")) return check_image(argv[2]);
+    if (argc >= 3 && !std::strcmp(argv[1], "--check-image")) return check_image(argv[2], !(argc >= 4 && !std::strcmp(argv[3], "--bgr")));
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s <settings.yaml> <asl_root> [<poses_out.dat>] [--device N] [--max-frames K] [--record-dir DIR] [--record]\n", argv[0]);
         return 2;

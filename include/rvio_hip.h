@@ -41,7 +41,7 @@ typedef enum rvio_status {
     RVIO_OK = 0,
     RVIO_ERR_INVALID = -1,     /* bad argument / size                                   */
     RVIO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error (see last_error)    */
-    RVIO_ERR_UNSUPPORTED = -3, /* e.g. a cornerSubPix window other than 7 with the device detector */
+    RVIO_ERR_UNSUPPORTED = -3, /* e.g. Tracker.nMinDist >= 32 with the device detector (cornerSubPix half-windows 1..15) */
     RVIO_ERR_STATE = -4        /* call out of sequence (e.g. update before set_state)    */
 } rvio_status;
 
@@ -117,7 +117,8 @@ typedef struct rvio_frame_info {
     int32_t n_tracked_out;     /* mnFeatsToTrack leaving track() (after refill) */
     int32_t ransac_winner;     /* nWinnerHypothesisIdx                          */
     int32_t reserved[5];       /* [0]: sticky device-side error flag: 1 = singular pivot in the solve, 2 = a track the window cannot hold was
-                                * dropped, 4 = a device-side stage counter (filter done -> book-keeping) timed out */
+                                * dropped, 4 = a device-side stage counter (filter done -> book-keeping) timed out,
+                                * 8 = a non-positive pivot in a feature's gate matrix S_f (indefinite covariance handed in): that feature was rejected */
     int32_t rank_truncated_at; /* Updater.cc:516-529: nRank when the leading-row scan cut informative rows off (the type-'1'
                                 * features' rows, dropped from this update), -1 otherwise */
 } rvio_frame_info;

@@ -150,12 +150,15 @@ void rect_subpix(const uint8_t* src, int w, int h, int stride, float cx, float c
     }
 }
 
-// cornerSubPix, cornersubpix.cpp.  Accumulation order of the five double sums (OpenCV adds the 225 terms in one row-major
-// chain; any fixed order differs from it by O(1e-16) relative): canonical = the terms on a zero-padded 16 x 16 grid, per
-// row a balanced binary tree over the columns, the rows in groups of four ((R0 + R1) + (R2 + R3)), the four groups the
-// same way.  Written for window half-sizes <= 7 (<= 15 rows / columns).
+// cornerSubPix, cornersubpix.cpp.  Accumulation order of the five double sums (OpenCV adds the (2 win + 1)^2 terms in one row-major
+// chain; any fixed order differs from it by O(1e-16) relative): canonical = the terms on a zero-padded G x G grid, G = 16 for window
+// half-sizes <= 7 (the stock 7: 15 rows / columns) and 32 for half-sizes <= 15; per row a balanced binary tree over the columns
+// ((j, j + G/2), then + G/4, ... + 1), the rows in groups of four ((R0 + R1) + (R2 + R3)), the G/4 groups by a balanced binary tree
+// (G = 16: (W0 + W1) + (W2 + W3)).
 void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps) {
     const int ww = 2 * win + 1, pw = ww + 2;
+    const int G = ww <= 16 ? 16 : 32;          // (half-sizes up to 15: Tracker.nMinDist < 32)
+    if (win < 1 || ww > 32) return;
     std::vector<float> mask((size_t)ww * ww);
     for (int i = 0; i < ww; ++i) {
         const float y = (float)(i - win) / (float)win;
@@ -177,8 +180,8 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
         double err = 0;
         do {
             rect_subpix(src, w, h, stride, cx, cy, pw, pw, patch.data());
-            // term[q][i][j] on a 16 x 16 grid (row / column 15 are zero padding)
-            static thread_local double term[5][16][16];
+            // term[q][i][j] on a G x G grid (rows / columns >= ww are zero padding)
+            static thread_local double term[5][32][32];
             std::memset(term, 0, sizeof term);
             for (int i = 0; i < ww; ++i) {
                 const float* sp = &patch[(size_t)(i + 1) * pw + 1];
@@ -194,23 +197,24 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
                     term[4][i][j] = gxy * px + gyy * py;
                 }
             }
-            // per row a balanced tree over the 16 columns: (j, j+8), then +4, +2, +1 -> R_i; groups of four rows
-            // W_w = (R_4w + R_4w+1) + (R_4w+2 + R_4w+3); total = (W_0 + W_1) + (W_2 + W_3)
+            // per row a balanced tree over the G columns: (j, j+G/2), then +G/4, ... +1 -> R_i; groups of four rows
+            // W_g = (R_4g + R_4g+1) + (R_4g+2 + R_4g+3); the G/4 groups by a balanced tree (G = 16: (W_0 + W_1) + (W_2 + W_3))
             double tot[5];
             for (int q = 0; q < 5; ++q) {
-                double R[16];
-                for (int i = 0; i < 16; ++i) {
+                double R[32];
+                for (int i = 0; i < G; ++i) {
                     double* v = term[q][i];
-                    for (int s = 8; s >= 1; s >>= 1) {
-                        double t[16];
-                        for (int j = 0; j < 16; ++j) t[j] = v[j] + v[(j + s) & 15];
-                        for (int j = 0; j < 16; ++j) v[j] = t[j];
+                    for (int s = G / 2; s >= 1; s >>= 1) {
+                        double t[32];
+                        for (int j = 0; j < G; ++j) t[j] = v[j] + v[(j + s) & (G - 1)];
+                        for (int j = 0; j < G; ++j) v[j] = t[j];
                     }
                     R[i] = v[0];
                 }
-                double Wg[4];
-                for (int g = 0; g < 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
+                double Wg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int g = 0; g < G / 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
                 tot[q] = (Wg[0] + Wg[1]) + (Wg[2] + Wg[3]);
+                if (G == 32) tot[q] = tot[q] + ((Wg[4] + Wg[5]) + (Wg[6] + Wg[7]));
             }
             const double a = tot[0], b = tot[1], c = tot[2], bb1 = tot[3], bb2 = tot[4];
             const double det = a * c - b * b;

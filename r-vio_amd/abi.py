@@ -53,7 +53,7 @@ class rvio_frame_info(C.Structure):
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         if hasattr(self, "reserved"):
-            d["device_error"] = int(self.reserved[0])   # sticky: 1 singular pivot, 2 track the window cannot hold, 4 a device-side stage counter timed out
+            d["device_error"] = int(self.reserved[0])   # sticky: 1 singular pivot, 2 track the window cannot hold, 4 a device-side stage counter timed out, 8 indefinite gate matrix
         return d
 
 

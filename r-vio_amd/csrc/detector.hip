@@ -36,7 +36,8 @@ struct DetDev {
     float* raw_xy;           // goodFeaturesToTrack output [F][2]
     float* xy;               // after cornerSubPix         [F][2]   (one of two buffers, by frame parity: see rvio_hip.hip)
     int* n_out;              // number of output corners (same parity)
-    const float* spmask;     // 15x15 Gaussian window of cornerSubPix (host-computed: expf is glibc's)
+    const float* spmask;     // (2 sp_win + 1)^2 Gaussian window of cornerSubPix (host-computed: expf is glibc's)
+    int sp_win;              // cornerSubPix half-window floor(nMinDist / 2) (FeatureDetector.cc:68): 7 for the stock 15 px
     int W, H, F;
     float min_dist;          // Tracker.nMinDist
     double quality;          // (double)(float)Tracker.nQualLvl
@@ -789,4 +790,86 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel1(const uint8_t* __restrict
     } while (++iter < 30 && err > eps);
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
     if (lane == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+}
+
+
+// cornerSubPix for any half-window 1 <= win <= 15 other than the stock 7 (FeatureDetector.cc:68: floor(nMinDist / 2)): the plain form.
+// One workgroup per corner; the (2 win + 1)^2 window terms go to a zero-padded G x G grid in LDS (G = 16 / 32) and are summed in the
+// canonical order of oracle/detector.cpp — per row a balanced tree over the columns, rows in groups of four, the groups by a balanced tree —
+// by 5 G threads (one per quantity and row), then one thread per quantity.  Correct for every window, tuned for none: the stock window
+// runs subpix_kernel / subpix_kernel1.
+#define SPG_T 256
+#define SPG_G 32
+__global__ __launch_bounds__(SPG_T) void subpix_generic_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    __shared__ double term[5][SPG_G][SPG_G + 1];
+    __shared__ double rowsum[5][SPG_G];
+    __shared__ double tot[5];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n = *d.n_out;
+    if (p >= n) return;
+    const int W = d.W, H = d.H, win = d.sp_win, ww = 2 * win + 1, pw = ww + 2, G = ww <= 16 ? 16 : 32;
+    const float tx = d.raw_xy[2 * p], ty = d.raw_xy[2 * p + 1];
+    auto pix = [&](int x, int y) -> float { return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)]; };
+    float cx = tx, cy = ty;
+    const double eps = 1e-2 * 1e-2;
+    int iter = 0;
+    double err = 0;
+    for (int e = tid; e < 5 * SPG_G * (SPG_G + 1); e += SPG_T) (&term[0][0][0])[e] = 0.0;      // padding stays zero
+    __syncthreads();
+    do {
+        const float ox = cx - (float)(pw - 1) * 0.5f, oy = cy - (float)(pw - 1) * 0.5f;   // getRectSubPix, samplers.cpp
+        const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+        float fa = ox - (float)ix;
+        const float fb = oy - (float)iy;
+        fa = fmaxf(fa, 0.0001f);
+        const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
+        auto samp = [&](int pi, int pj) -> float {
+            const int x = ix + pj, y = iy + pi;
+            return ((pix(x, y) * a11 + pix(x + 1, y) * a12) + pix(x, y + 1) * a21) + pix(x + 1, y + 1) * a22;
+        };
+        for (int e = tid; e < ww * ww; e += SPG_T) {
+            const int wi = e / ww, wj = e - wi * ww;
+            const double wm = (double)d.spmask[e], px = wj - win, py = wi - win;
+            const double tgx = samp(wi + 1, wj + 2) - samp(wi + 1, wj);
+            const double tgy = samp(wi + 2, wj + 1) - samp(wi, wj + 1);
+            const double gxx = tgx * tgx * wm, gxy = tgx * tgy * wm, gyy = tgy * tgy * wm;
+            term[0][wi][wj] = gxx; term[1][wi][wj] = gxy; term[2][wi][wj] = gyy;
+            term[3][wi][wj] = gxx * px + gxy * py;
+            term[4][wi][wj] = gxy * px + gyy * py;
+        }
+        __syncthreads();
+        if (tid < 5 * G) {      // the j = 0 leaf of the balanced column tree: level s combines (k, k + s) for k < s
+            const int q = tid / G, i = tid - q * G;
+            double v[SPG_G];
+#pragma unroll
+            for (int j = 0; j < SPG_G; ++j) v[j] = j < G ? term[q][i][j] : 0.0;
+            for (int sft = G / 2; sft >= 1; sft >>= 1)
+#pragma unroll
+                for (int k = 0; k < SPG_G / 2; ++k) if (k < sft) v[k] = v[k] + v[k + sft];
+            rowsum[q][i] = v[0];
+        }
+        __syncthreads();
+        if (tid < 5) {
+            const double* R = rowsum[tid];
+            double Wg[8];
+            for (int g = 0; g < G / 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
+            double t = (Wg[0] + Wg[1]) + (Wg[2] + Wg[3]);
+            if (G == 32) t = t + ((Wg[4] + Wg[5]) + (Wg[6] + Wg[7]));
+            tot[tid] = t;
+        }
+        __syncthreads();
+        const double a = tot[0], b = tot[1], c = tot[2], bb1 = tot[3], bb2 = tot[4];
+        const double det = a * c - b * b;
+        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+        const double scale = 1.0 / det;
+        const float nx = (float)(cx + c * scale * bb1 - b * scale * bb2);
+        const float ny = (float)(cy - b * scale * bb1 + a * scale * bb2);
+        const float ex = nx - cx, ey = ny - cy;
+        err = (double)(ex * ex + ey * ey);
+        cx = nx; cy = ny;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
+    } while (++iter < 30 && err > eps);
+    if (fabsf(cx - tx) > win || fabsf(cy - ty) > win) { cx = tx; cy = ty; }
+    if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }

@@ -470,6 +470,9 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
             if (tid == 0) {
                 const double w0 = S[rr * lds_s + k], w1 = S[rr * lds_s + k + 1] - w0 * ba;
                 gsum += w0 * (w0 * ra) + w1 * (w1 * rc);
+                // S_f = Hn Pcc Hn^T + s2 I is positive definite by construction; a non-positive pivot means the covariance handed in is not.
+                // The feature is rejected (gamma overflows the table) where the reference's pivoted QR would return some finite gamma: say so.
+                if (!(a > 0) || !(c2 > 0)) atomicOr(&zoffi(meta, bs, bi.z)->err, 8);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -489,6 +492,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         if (k < rr && tid == 0) {     // odd count: the last pivot only feeds gamma
             const double dk = S[k * lds_s + k], w = S[rr * lds_s + k];
             gsum += w * (w * fast_rcp(dk > 0 ? dk : 1e-300));
+            if (!(dk > 0)) atomicOr(&zoffi(meta, bs, bi.z)->err, 8);
         }
         if (tid == 0) misc[8] = fabs(gsum);
     }

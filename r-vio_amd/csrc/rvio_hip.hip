@@ -873,7 +873,8 @@ int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
 static int detector_check(rvio_hip* h) {
     const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist);
     if (cell1 < 1) { h->err = "Tracker.nMinDist < 1 is not supported by the device detector"; return RVIO_ERR_UNSUPPORTED; }
-    if ((int)std::floor(.5 * h->cfg.min_dist) != SP_WIN) { h->err = "device cornerSubPix is built for floor(nMinDist/2) == 7"; return RVIO_ERR_UNSUPPORTED; }
+    const int spw = (int)std::floor(.5 * h->cfg.min_dist);   // cornerSubPix half-window, FeatureDetector.cc:68
+    if (spw < 1 || spw > 15) { h->err = "device cornerSubPix takes half-windows 1..15 (2 <= Tracker.nMinDist < 32)"; return RVIO_ERR_UNSUPPORTED; }
     return RVIO_OK;
 }
 static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE detector in flight
@@ -899,8 +900,8 @@ static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a sla
     DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F); DALLOC(h, h->det_xy2[2], (size_t)2 * d.F);
     DALLOC(h, h->det_nout, 3);
     float* mask = nullptr;
-    DALLOC(h, mask, (size_t)SP_WW * SP_WW);
-    for (DetDev* q : {&h->det, &h->det_b}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; }
+    DALLOC(h, mask, (size_t)31 * 31);
+    for (DetDev* q : {&h->det, &h->det_b}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; q->sp_win = (int)std::floor(.5 * h->cfg.min_dist); }
     return RVIO_OK;
 }
 static int detector_init(rvio_hip* h) {
@@ -910,13 +911,15 @@ static int detector_init(rvio_hip* h) {
     if (!h->det_in_slab && (rc = detector_alloc(h)) != RVIO_OK) return rc;
     DetDev& q = h->det;
     // cornerSubPix window (cornersubpix.cpp): float expf on the host, so that device and oracle share glibc's values
-    float hm[SP_WW * SP_WW];
-    for (int i = 0; i < SP_WW; ++i) {
-        const float y = (float)(i - SP_WIN) / (float)SP_WIN;
+    const int spw = q.sp_win, spww = 2 * spw + 1;
+    std::vector<float> hm((size_t)spww * spww);
+    for (int i = 0; i < spww; ++i) {
+        const float y = (float)(i - spw) / (float)spw;
         const float vy = std::exp(-y * y);
-        for (int j = 0; j < SP_WW; ++j) { const float x = (float)(j - SP_WIN) / (float)SP_WIN; hm[i * SP_WW + j] = (float)(vy * std::exp(-x * x)); }
+        for (int j = 0; j < spww; ++j) { const float x = (float)(j - spw) / (float)spw; hm[(size_t)i * spww + j] = (float)(vy * std::exp(-x * x)); }
     }
-    HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm, sizeof hm, hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
+    HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm.data(), sizeof(float) * hm.size(), hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // (hm is a local)
     std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
     for (DetDev* qq : {&h->det, &h->det_b})
         HIPCHK(h, hipMemcpy2DAsync(qq->maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
@@ -962,7 +965,9 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
-    if (h->wide_px)
+    if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
+        hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, B), dim3(SPG_T), 0, ds, img, stride, q, src_bs, bs);
+    else if (h->wide_px)
         hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
     else
         hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
@@ -1561,7 +1566,8 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
             const DetDev q = [&] { DetDev v = h->det_set_last ? h->det_b : h->det; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
             const uint8_t* im = h->pyr[h->pyr_cur].img[0];   // level 0 of the current pyramid = the image the detector saw
-            if (h->wide_px) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            if (q.sp_win != SP_WIN) hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, 1), dim3(SPG_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            else if (h->wide_px) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
             else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
         } else return RVIO_ERR_INVALID;
     }

@@ -154,3 +154,50 @@ def test_whole_frame_with_device_detector(gpu_required):
     h.close()
     assert info["updated"] == 1 and info["device_error"] == 0
     assert S.state_delta(xa, xb) <= 1e-6
+
+
+@pytest.mark.parametrize("min_dist", [6.0, 10.0, 12.5, 20.0, 31.0])
+def test_detector_other_subpix_windows(gpu_required, min_dist):
+    """cornerSubPix's window is floor(nMinDist / 2) (FeatureDetector.cc:68): 3, 5, 6 (the 16 x 16 summation grid), 10 and 15 (32 x 32) beside
+    the stock 7 — goodFeaturesToTrack corners and refined corners bit-exact for s = 1 and s = 2, and a short free-running whole-frame run."""
+    from rvio_amd import hip
+    import scenarios as S
+    cfg = abi.config_named("B", enable_equalizer=1, min_dist=min_dist)
+    seq = rv.synth.SynthSequence(cfg, duration=4.0)
+    h = hip.RvioHip(cfg)
+    imu = np.zeros(2, abi.IMU_DTYPE)
+    imu["dt"] = 0.005
+    for s, k in ((1, 50), (2, 51)):
+        im = seq.render(k)
+        h.track(im, imu, None)
+        seen = O.clahe(im)
+        xy, raw = h.get_corners()
+        want_raw = O.gftt(seen, cfg.n_features, float(f32(cfg.qual_lvl)), float(f32(s) * f32(cfg.min_dist)))
+        assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw), (min_dist, s)
+        want = O.detect(cfg, seen, s)
+        assert len(xy) > 20 and np.array_equal(xy, want), (min_dist, s, float(np.abs(xy - want).max()))
+        assert np.any(xy != raw)                                   # the refinement did move corners
+    h.close()
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    lit = O.System(cfg)
+    lit.set_state(*O.initialize(cfg, w, a, n))
+    for k in range(39, 39 + 16):
+        img, imu = seq.render(k), seq.imu_between(k)
+        lit.frame(imu, None, img=img)
+        h.frame(img, imu, None)
+    h.sync()
+    assert np.array_equal(h.get_points()[0], lit.tracker().get_points()[0])
+    assert S.state_delta(h.get_state()[0], lit.get_state()[0]) <= 1e-6
+    h.close()
+
+
+def test_detector_refuses_what_it_cannot_do(gpu_required):
+    from rvio_amd import hip
+    cfg = abi.config_named("B", min_dist=40.0)
+    h = hip.RvioHip(cfg)
+    imu = np.zeros(2, abi.IMU_DTYPE)
+    with pytest.raises(hip.RvioHipError, match="half-windows"):
+        h.track(np.zeros((480, 752), np.uint8), imu, None)
+    h.close()

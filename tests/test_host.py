@@ -79,16 +79,20 @@ def ensure_bin():
 
 
 def write_png_gray(path, img, filters=(0, 1, 2, 3, 4)):
-    """8-bit grayscale PNG with the row filters cycling through `filters` (exercises every un-filter branch)"""
-    h, w = img.shape
+    """8-bit PNG (gray [h,w], RGB [h,w,3] or RGBA [h,w,4]) with the row filters cycling through `filters` (exercises every un-filter branch)"""
+    h, w = img.shape[:2]
+    bpp = 1 if img.ndim == 2 else img.shape[2]
+    ctype = {1: 0, 3: 2, 4: 6}[bpp]
+    img = img.reshape(h, w * bpp)
+    w = w * bpp
     raw = bytearray()
     prev = np.zeros(w, np.int32)
     for y in range(h):
         ft = filters[y % len(filters)]
         cur = img[y].astype(np.int32)
-        a = np.concatenate(([0], cur[:-1]))
+        a = np.concatenate((np.zeros(bpp, np.int32), cur[:-bpp]))
         b = prev
-        c = np.concatenate(([0], prev[:-1]))
+        c = np.concatenate((np.zeros(bpp, np.int32), prev[:-bpp]))
         if ft == 0:
             pred = np.zeros(w, np.int32)
         elif ft == 1:
@@ -110,7 +114,7 @@ def write_png_gray(path, img, filters=(0, 1, 2, 3, 4)):
     z = zlib.compress(bytes(raw), 6)
     half = len(z) // 2                       # two IDAT chunks
     with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w // bpp, h, 8, ctype, 0, 0, 0)) +
                 chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b""))
 
 
@@ -173,7 +177,7 @@ def test_png_and_pgm_decoders(tmp_path, shape):
     yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
     img = ((xx * 3 + yy * 5) % 256 ^ rng.integers(0, 32, shape)).astype(np.uint8)
     idx = np.arange(img.size) % 251 + 1
-    want = {"width": shape[1], "height": shape[0], "sum": int(img.sum(dtype=np.int64)), "wsum": int((img.ravel().astype(np.int64) * idx).sum())}
+    want = {"width": shape[1], "height": shape[0], "channels": 1, "sum": int(img.sum(dtype=np.int64)), "wsum": int((img.ravel().astype(np.int64) * idx).sum())}
     write_png_gray(str(tmp_path / "a.png"), img)
     write_pgm(str(tmp_path / "a.pgm"), img)
     for name in ("a.png", "a.pgm"):
@@ -203,3 +207,34 @@ def test_settings_reader_reports_missing_keys(tmp_path):
     cfg = json.loads(r.stdout)
     assert cfg["block_x"] == 150.5 and np.float32(cfg["qual_lvl"]) == np.float32(0.01)
     assert "Tracker.nQualLvl is missing" in r.stderr and "nBlockSize" not in r.stderr
+
+
+def test_colour_images_are_converted_like_cvtColor(tmp_path):
+    """Tracker.cc:182-196: 3- and 4-channel input goes through cvtColor (RGB2GRAY / BGR2GRAY by Camera.RGB) before anything else.  The host
+    applies OpenCV's 8-bit fixed-point form (R 4899 + G 9617 + B 1868 + 8192) >> 14 — checked against its float definition
+    0.299 R + 0.587 G + 0.114 B (never more than one grey level away, equal on > 95 % of random pixels) and bit-exact against the integers."""
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+    idx = np.arange(h * w) % 251 + 1
+
+    def gray(img, is_rgb):
+        r, g, b = (img[..., 0], img[..., 1], img[..., 2]) if is_rgb else (img[..., 2], img[..., 1], img[..., 0])
+        return ((r.astype(np.int64) * 4899 + g.astype(np.int64) * 9617 + b.astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    fl = np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2])
+    d = np.abs(gray(rgb, True).astype(np.int64) - fl)
+    assert d.max() <= 1 and (d == 0).mean() > 0.95
+    write_png_gray(str(tmp_path / "c.png"), rgb)
+    write_png_gray(str(tmp_path / "d.png"), rgba)
+    with open(tmp_path / "e.ppm", "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+    for name, img, ch in (("c.png", rgb, 3), ("d.png", rgba, 4), ("e.ppm", rgb, 3)):
+        for flag, is_rgb in (([], True), (["--bgr"], False)):
+            g = gray(img, is_rgb)
+            want = {"width": w, "height": h, "channels": ch, "sum": int(g.sum(dtype=np.int64)), "wsum": int((g.ravel().astype(np.int64) * idx).sum())}
+            assert json.loads(subprocess.check_output([ensure_bin(), "--check-image", str(tmp_path / name)] + flag)) == want, (name, flag)
+    # the settings key
+    p = tmp_path / "s.yaml"
+    p.write_text(EUROC_YAML + "\nCamera.RGB: 1\n")
+    assert json.loads(subprocess.check_output([ensure_bin(), "--check-settings", str(p)]))["is_rgb"] == 1
