@@ -216,9 +216,12 @@ def main():
     def frame(i):
         if not sharded:
             h.frame_dev(*fs.args(i))
+        elif comm is not None:
+            # ONE C-ABI call per frame: pipelined like N=1, the ncclAllGather enqueued by the library on the handle's filter stream
+            h.frame_sharded_dev(*fs.args(i), rank, world, comm.comm)
         else:
-            # pipelined like N=1; the all-gather is enqueued on the handle's filter stream (no host synchronisation per frame)
-            h.frame_sharded_piped(*fs.args(i), rank, world, gathered, dist, DeviceArray, torch, stream, force_collective=args.force_sharded, comm=comm)
+            # fall-back without a direct RCCL communicator: the same frame split open, the collective through torch.distributed
+            h.frame_sharded_piped(*fs.args(i), rank, world, gathered, dist, DeviceArray, torch, stream, force_collective=args.force_sharded, comm=None)
 
     for i in range(1 + W):
         frame(i)
@@ -262,7 +265,7 @@ def main():
                                % (args.config, cfg.width, cfg.height, cfg.n_features, cfg.max_track_len - 1, "on (CLAHE 3.0, 5x5)" if cfg.enable_equalizer else "off",
                                   "a caller-side list" if args.host_corners else "the device detector (GFTT + cornerSubPix)"),
                    "parallelism": ("1 process/GPU; feature-sharded updater + 1 all-gather/frame (%s)"
-                                   % ("ncclAllGather on the filter stream" if comm is not None else "torch.distributed")) if sharded else "single GPU"},
+                                   % ("rvio_hip_frame_sharded_dev: one C-ABI call per frame, ncclAllGather on the filter stream" if comm is not None else "torch.distributed")) if sharded else "single GPU"},
         "gpu_ms_per_step_events": gpu_ms / K, "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         "last_frame": {k: info[k] for k in ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated", "device_error")},
     }

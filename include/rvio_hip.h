@@ -282,6 +282,15 @@ int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int 
  * order and run the EKF update; bit-identical on every rank. */
 int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world);
 
+/* The whole sharded frame behind ONE call (what a multi-GPU host loop issues per image): rvio_hip_frame_begin_dev, rvio_hip_frame_plan,
+ * rvio_hip_update_local, ncclAllGather of the blocks ON THE HANDLE'S FILTER STREAM, rvio_hip_update_global, rvio_hip_augment_compose,
+ * rvio_hip_frame_end — no host synchronisation, the collective ordered by plain stream order.  `comm` is the caller's ncclComm_t (RCCL);
+ * NULL is allowed with world == 1 only (no collective).  `allgather` = NULL: RCCL's ncclAllGather is resolved from the RCCL the process has
+ * loaded (the library has no link-time dependency on it); or the entry point itself,
+ *   int (*)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream). */
+int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m,
+                               const float* d_cand_xy, int n_cand, int rank, int world, void* comm, void* allgather);
+
 /* --- diagnostics for parity tests ------------------------------------------ */
 /* per-feature results of the last update: accept flag, Mahalanobis distance,
  * nDOF, inverse-depth estimate (phi,psi,rho). arrays sized n_feat. */

@@ -3,6 +3,7 @@
 // builds the whole library (frontend_kernels.hip switches FP contraction off for itself).
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,8 @@ struct rvio_hip {
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
+    double* gathered = nullptr;   // rvio_hip_frame_sharded_dev: world x [S2 | S1] as the all-gather delivers them (allocated on first use)
+    int gathered_world = 0;
     int imu_cap = RVIO_MAX_IMU;   // samples the host-side staging (d_imu, hb_imu, pinned ring) holds; grows on demand (ensure_imu_capacity)
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
@@ -1365,6 +1368,60 @@ int rvio_hip_frame_end(rvio_hip* h) {
     h->frame_no++;
     h->in_frame = false;
     return RVIO_OK;
+}
+// RCCL's ncclAllGather, resolved at run time from the RCCL instance the process has ALREADY loaded (the communicator the caller hands over
+// belongs to it: torch ships its own librccl.so) and only then from the system's.  No link-time dependency: a single-GPU user never loads RCCL.
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_allgather_fn resolve_allgather(std::string* why) {
+    static nccl_allgather_fn fn = nullptr;
+    if (fn) return fn;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib) {   // torch's copy is loaded by path, not by soname lookup: look for a loaded object whose name ends in librccl.so*
+        fn = (nccl_allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (fn) return fn;
+    }
+    if (!lib) for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (lib) fn = (nccl_allgather_fn)dlsym(lib, "ncclAllGather");
+    if (!fn && why) *why = "ncclAllGather not found (no librccl.so loaded or loadable)";
+    return fn;
+}
+// One pipelined frame with the feature-sharded updater behind ONE call: the front end and propagate replicated, U1-U5 + the
+// share reduction on the features f % world == rank, ONE ncclAllGather of the [S2 | S1] blocks enqueued on the filter stream between the two
+// kernels it separates (plain stream order: no helper stream, no event, no host synchronisation), the replicated global stage, augmentation /
+// composition.  comm: the caller's ncclComm_t; NULL only with world == 1 (the collective is skipped).  allgather: NULL = resolve RCCL's
+// ncclAllGather from the loaded process image; a caller may hand in the entry point itself (same signature).
+int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand,
+                               int rank, int world, void* comm, void* allgather) {
+    if (!h || !d_img || world < 1 || rank < 0 || rank >= world || (!comm && world > 1)) return RVIO_ERR_INVALID;
+    FRONT_END_ONLY(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nblk = 2 * (size_t)h->dc.ldh * h->dc.ldh;
+    nccl_allgather_fn ag = (nccl_allgather_fn)allgather;
+    if (comm && !ag && !(ag = resolve_allgather(&h->err))) return RVIO_ERR_UNSUPPORTED;
+    if (comm && h->gathered_world < world) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, sizeof(double) * nblk * (size_t)world));
+        h->allocs.push_back(q);
+        h->gathered = (double*)q; h->gathered_world = world;
+    }
+    int rc = frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false, /*begin_only=*/true);
+    if (rc != RVIO_OK) return rc;
+    h->img_count++;
+    if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
+        rc = update_local_dev(h, rank, world, false);
+        const double* blocks = h->block;
+        if (rc == RVIO_OK && comm) {
+            const int nrc = ag(h->block, h->gathered, nblk, /*ncclFloat64*/ 8, comm, h->stream);
+            if (nrc != 0) { h->err = "ncclAllGather failed (ncclResult_t " + std::to_string(nrc) + ")"; rc = RVIO_ERR_NO_DEVICE; }
+            blocks = h->gathered;
+        }
+        if (rc == RVIO_OK) rc = update_global_dev(h, blocks, world, false);
+    }
+    if (rc == RVIO_OK) rc = augment_compose_dev(h, h->img_count > 1);      // System.cc:280
+    const int rce = rvio_hip_frame_end(h);
+    return rc != RVIO_OK ? rc : rce;
 }
 // The same body fed from HOST buffers — what System::MonoVIO holds at System.cc:253 (a cv::Mat and the IMU list).
 // The three H2D copies go to the tracker stream into staging buffers double-buffered by frame parity, so they overlap

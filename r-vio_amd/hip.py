@@ -23,7 +23,7 @@ SYMBOLS = [
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
     "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
-    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at",
+    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at", "rvio_hip_frame_sharded_dev",
 ]
 
 _LIB = None
@@ -275,6 +275,12 @@ class RvioHip:
 
     def frame_end(self):
         self._ck(self.L.rvio_hip_frame_end(self.h), "frame_end")
+
+    def frame_sharded_dev(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand, rank, world, comm=None, allgather=None):
+        """one pipelined frame with the feature-sharded updater behind ONE C-ABI call; comm: ncclComm_t (int / c_void_p), None with world 1"""
+        cp = comm.value if isinstance(comm, C.c_void_p) else comm
+        self._ck(self.L.rvio_hip_frame_sharded_dev(self.h, C.c_void_p(d_img_ptr), int(stride), C.c_void_p(d_imu_ptr), int(m), C.c_void_p(d_cand_ptr), int(n_cand),
+                                                   int(rank), int(world), C.c_void_p(cp), C.c_void_p(allgather)), "frame_sharded_dev")
 
     def frame_sharded_piped(self, d_img_ptr, stride, d_imu_ptr, m, d_cand_ptr, n_cand, rank, world, gathered, dist, DeviceArray, torch, stream,
                             force_collective=False, comm=None):

@@ -45,3 +45,15 @@ def test_short_and_odd_step_counts_do_not_kill_the_line(gpu_required, steps, war
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out = json.loads(lines[-1])
     assert out["steps"] == steps and "error" not in out["pose_latency_unpipelined"], out["pose_latency_unpipelined"]
+
+
+def test_forced_sharded_line_equals_the_single_gpu_updater(gpu_required):
+    """bench.py --force-sharded: the sharded frame (rvio_hip_frame_sharded_dev: update_local -> the REAL ncclAllGather on the filter stream ->
+    update_global, one C-ABI call per frame) at world 1 against the same frames through the unsharded updater: block sums in rank order, so
+    the two agree to rounding — asserted, not just printed (it was null in round 2)."""
+    r, lines = _run(["--gpus", "1", "--steps", "60", "--warmup", "5", "--force-sharded", "--no-cpu", "--batch", "", "--batch-streams", "", "--no-streams"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads(lines[-1])
+    assert "ncclAllGather" in out["config"]["parallelism"], out["config"]["parallelism"]
+    assert out["last_frame"]["updated"] == 1 and out["last_frame"]["device_error"] == 0
+    assert out["max_state_delta_sharded_vs_single_gpu"] is not None and out["max_state_delta_sharded_vs_single_gpu"] <= 1e-9, out["max_state_delta_sharded_vs_single_gpu"]
