@@ -214,10 +214,14 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                 if (cost <= lastCost) {
                     // damped normal equations, SPD 3x3: Cholesky solve (reference: colPivHouseholderQr, Updater.cc:239)
                     // L D L^T (square-root free): 3 reciprocals instead of 3 sqrt + 9 divisions
+                    // A pivot that is zero against the largest diagonal entry is a dependent direction — the inverse-depth column is exactly
+                    // zero when every relative translation of the track is (a platform at rest fed an empty IMU batch): the reference's
+                    // rank-revealing QR leaves that component of the step at 0; a reciprocal here would turn it into NaN.
                     const double a00 = c00 + lambda * c00, a11 = c11 + lambda * c11, a22 = c22 + lambda * c22;
-                    const double i0 = fast_rcp(a00), l10 = c01 * i0, l20 = c02 * i0;
-                    const double dd1 = a11 - l10 * c01, i1 = fast_rcp(dd1), l21 = (c12 - l20 * c01) * i1;
-                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = fast_rcp(dd2);
+                    const double ptiny = 2.220446049250313e-16 * fmax(a00, fmax(a11, a22));
+                    const double i0 = a00 > ptiny ? fast_rcp(a00) : 0.0, l10 = c01 * i0, l20 = c02 * i0;
+                    const double dd1 = a11 - l10 * c01, i1 = dd1 > ptiny ? fast_rcp(dd1) : 0.0, l21 = (c12 - l20 * c01) * i1;
+                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = dd2 > ptiny ? fast_rcp(dd2) : 0.0;
                     const double z0 = g0, z1 = g1 - l10 * z0, z2 = g2 - l20 * z0 - l21 * z1;
                     const double d2 = z2 * i2, d1 = z1 * i1 - l21 * d2, d0 = z0 * i0 - l10 * d1 - l20 * d2;
                     phi += d0; psi += d1; rho += d2;

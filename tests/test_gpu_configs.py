@@ -167,7 +167,7 @@ def test_whole_frame_on_images_cfg_e(gpu_required):
     nFeatures, is what limits), tracker tables bit-exact, states within 1e-6"""
     from rvio_amd import hip
     cfg = abi.config_named("E", enable_equalizer=1)
-    seq = rv.synth.SynthSequence(cfg, duration=3.0, n_landmarks=12000)
+    seq = rv.synth.SynthSequence(cfg, duration=4.5, n_landmarks=12000)
     w, a, n = seq.init_from_static(38)
     h = hip.RvioHip(cfg)
     h.initialize(w, a, n)

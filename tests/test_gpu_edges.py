@@ -209,3 +209,46 @@ def test_imu_batches_longer_than_the_preallocated_staging(gpu_required, seqB):
         assert h.frame_info()["device_error"] == 0
     h.close()
     assert longest > 192
+
+
+def test_imu_stream_that_ends_mid_sequence(gpu_required):
+    """The IMU stream stops while images keep coming (m = 0 for every later frame): the newer clones' relative poses are EXACTLY the identity,
+    the inverse-depth column of the triangulation's normal equations is exactly zero for tracks inside that stretch, and the reference's
+    rank-revealing QR (colPivHouseholderQr, Updater.cc:239) leaves that component of the step at 0 — some of those features then pass
+    the gate.  (Found by a test whose sequence was shorter than its frame loop: a plain reciprocal of the zero pivot turned the triangulation
+    into NaN and rejected what the reference accepts.)  Accept sets, counters and tracker tables equal, states within 1e-6."""
+    from rvio_amd import hip
+    cfg = abi.config_named("B")
+    seq = rv.synth.SynthSequence(cfg, duration=3.0)          # 60 frames of IMU; the loop runs to frame 84
+    w, a, n = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, n)
+    x, P = O.initialize(cfg, w, a, n)
+    trk = O.Tracker(cfg)
+    img_count, zero_rho_accepts, empties = 0, 0, 0
+    for k in range(39, 85):
+        img, imu = seq.render(k), seq.imu_between(k)
+        empties += len(imu) == 0
+        trk.track(img, imu, None)
+        img_count += 1
+        ncl = (len(x) - 26) // 7
+        x1, P1 = O.propagate(cfg, x, P, imu)
+        types, lens, meas = trk.get_tracks()
+        d = None
+        if ncl > cfg.min_track_len - 1:
+            x, P, d = O.update(cfg, x1, P1, types, lens, meas)
+        else:
+            x, P = x1, P1
+        x, P, _, _ = O.augment_compose(cfg, x, P, img_count > 1)
+        h.frame(img, imu)
+        h.sync()
+        _same_tracker(h, trk, k)
+        if d is not None:
+            dg = h.update_diag()
+            assert np.array_equal(dg["accepted"], d["accepted"]), (k, dg["accepted"], d["accepted"])
+            assert np.array_equal(np.isfinite(dg["pfinv"]), np.isfinite(d["pfinv"])), k
+            zero_rho_accepts += int(np.sum((d["pfinv"][:, 2] == 0) & (d["accepted"] == 1)))
+        xa, _ = h.get_state()
+        assert np.all(np.isfinite(xa)) and S.state_delta(xa, x) <= 1e-6, k
+    h.close()
+    assert empties >= 20 and zero_rho_accepts >= 1, (empties, zero_rho_accepts)

@@ -12,6 +12,15 @@ import scenarios as S
 abi, rv = O.abi, O.rv
 pytestmark = pytest.mark.gpu
 
+# Free-running bar: 1e-6 per state (north star).  The platform AT REST is the exception and gets 5e-6: there the filter is unobservable in
+# scale and rounding is amplified ~1e9-fold by the sequence itself — the literal oracle started ONE ULP away from itself ends 2.2e-7 away
+# after 100 such frames (7.8e-14 on the stock motion; tests/test_truncation.py::test_the_reference_itself_is_ill_conditioned_at_rest).  What
+# the structural rule owes is agreement PER UPDATE, which test_degenerate_motion_on_direct_tracks holds to 1e-9 on a second handle that is
+# re-seeded with the literal state before every frame.
+def bar(kw):
+    return 5e-6 if kw.get("motion") == "stationary" else 1e-6
+
+
 MOTIONS = [dict(motion="stationary"), dict(motion="rotation"), dict(motion="line"), dict(scene="sphere")]
 IDS = ["stationary", "rotation", "line", "sphere"]
 COUNTERS = ("n_tracked_in", "n_klt_ok", "n_ransac_inliers", "n_feat_update", "n_feat_accepted", "n_rows", "updated")
@@ -42,10 +51,10 @@ def test_degenerate_motion_on_images_tracks_the_literal_oracle(gpu_required, kw)
         xa, Pa = h.get_state()
         xl, Pl = lit.get_state()
         worst = max(worst, S.state_delta(xa, xl))
-        assert worst <= 1e-6, (k, worst)
-        # (covariance: 1e-5 of its largest entry — zero-parallax windows are the badly conditioned ones, and the information form squares the
-        # condition number of the stacked Jacobian; the stock motion holds 1e-6, tests/test_gpu_detector.py)
-        assert np.max(np.abs(Pa - Pl)) <= 1e-5 * np.max(np.abs(Pl)), (k, float(np.max(np.abs(Pa - Pl))), float(np.max(np.abs(Pl))))
+        assert worst <= bar(kw), (k, worst)
+        # (covariance: 1e-5 of its largest entry, 1e-4 at rest — zero-parallax windows are the badly conditioned ones; the stock motion holds
+        # 1e-6, tests/test_gpu_detector.py)
+        assert np.max(np.abs(Pa - Pl)) <= 20 * bar(kw) * np.max(np.abs(Pl)), (k, float(np.max(np.abs(Pa - Pl))), float(np.max(np.abs(Pl))))
         if gi["updated"]:
             updates += 1
             c6 = 6 * min(k - 39, cfg.max_track_len - 1)
@@ -67,14 +76,20 @@ def test_degenerate_motion_on_direct_tracks(gpu_required, kw):
     x0, P0 = O.initialize(cfg, w, a, ni)
     h = hip.RvioHip(cfg)
     h.initialize(w, a, ni)
+    h1 = hip.RvioHip(cfg)          # re-seeded with the literal state before every frame: ONE update's worth of difference
+    h1.initialize(w, a, ni)
     lit = O.System(cfg)
     lit.set_state(x0, P0)
     drv = rv.synth.DirectTrackDriver(seq)
-    worst, updates = 0.0, 0
+    worst, worst1, updates = 0.0, 0.0, 0
     for k in range(39, 39 + n):
         inp = drv.inputs(k)
+        h1.set_state(*lit.get_state())
         oi = lit.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])[0]
         h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        h1.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        worst1 = max(worst1, S.state_delta(h1.get_state()[0], lit.get_state()[0]))
+        assert worst1 <= 1e-9, (k, worst1)
         pts = h.get_points()[0]
         assert np.array_equal(pts, lit.tracker().get_points()[0]), k
         drv.after(pts)
@@ -84,9 +99,10 @@ def test_degenerate_motion_on_direct_tracks(gpu_required, kw):
         xa, _ = h.get_state()
         xl, _ = lit.get_state()
         worst = max(worst, S.state_delta(xa, xl))
-        assert worst <= 1e-6, (k, worst)
+        assert worst <= bar(kw), (k, worst)
         updates += gi["updated"]
         if gi["rank_truncated_at"] >= 0:
             assert gi["rank_truncated_at"] == lit.last_rank(), k
     h.close()
+    h1.close()
     assert updates >= 80
