@@ -30,7 +30,9 @@ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 // covariance products in float; 3x3 unnormalised box sum (boxFilter uses double sums for float input): canonical order =
 // vertical sums top->bottom, then the three columns left->right, rounded once to float;
 // lambda_min = (a + c) - sqrt((a - c)^2 + b^2), a = .5 cxx, b = cxy, c = .5 cyy  (calcMinEigenVal, float).
-void min_eig_map(const uint8_t* src, int w, int h, int stride, float* eig) {
+// cv_order = true (orc_min_eig_cvorder, measurement only): the 3x3 box sums as cv::boxFilter forms them — RowSum: a running sum along the row
+// (s += in[x+2] - in[x-1]), ColumnSum: a running sum down the column (add the newest row sum, emit, subtract the oldest), both in double.
+void min_eig_map(const uint8_t* src, int w, int h, int stride, float* eig, bool cv_order = false) {
     const double scale = 1.0 / (4.0 * 3.0 * 255.0);
     const float k1 = (float)scale, k0 = (float)(2.0 * scale);
     // source with a 1-px reflected frame, as float
@@ -60,6 +62,32 @@ void min_eig_map(const uint8_t* src, int w, int h, int stride, float* eig) {
     for (auto& p : pr) {
         for (int y = 0; y < h; ++y) { p[(size_t)(y + 1) * pw] = p[(size_t)(y + 1) * pw + 1 + refl(-1, w)]; p[(size_t)(y + 1) * pw + w + 1] = p[(size_t)(y + 1) * pw + 1 + refl(w, w)]; }
         for (int x = 0; x < pw; ++x) { p[x] = p[(size_t)(1 + refl(-1, h)) * pw + x]; p[(size_t)(h + 1) * pw + x] = p[(size_t)(1 + refl(h, h)) * pw + x]; }
+    }
+    if (cv_order) {
+        std::vector<float> cov[3];
+        for (int k = 0; k < 3; ++k) {
+            cov[k].assign((size_t)w * h, 0.f);
+            std::vector<double> rs((size_t)w * (h + 2));            // row sums of the framed plane, rows -1 .. h
+            for (int y = 0; y < h + 2; ++y) {
+                const double* in = &pr[k][(size_t)y * pw];
+                double sacc = (in[0] + in[1]) + in[2];
+                rs[(size_t)y * w] = sacc;
+                for (int x = 0; x + 1 < w; ++x) { sacc += in[x + 3] - in[x]; rs[(size_t)y * w + x + 1] = sacc; }
+            }
+            std::vector<double> SUM((size_t)w);
+            for (int x = 0; x < w; ++x) SUM[x] = rs[x] + rs[(size_t)w + x];     // the first ksize - 1 rows
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const double s0 = SUM[x] + rs[(size_t)(y + 2) * w + x];
+                    cov[k][(size_t)y * w + x] = (float)s0;
+                    SUM[x] = s0 - rs[(size_t)y * w + x];
+                }
+        }
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            const float a = cov[0][i] * 0.5f, b = cov[1][i], c = cov[2][i] * 0.5f;
+            eig[i] = (a + c) - std::sqrt((a - c) * (a - c) + b * b);
+        }
+        return;
     }
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y)
@@ -155,7 +183,8 @@ void rect_subpix(const uint8_t* src, int w, int h, int stride, float cx, float c
 // half-sizes <= 7 (the stock 7: 15 rows / columns) and 32 for half-sizes <= 15; per row a balanced binary tree over the columns
 // ((j, j + G/2), then + G/4, ... + 1), the rows in groups of four ((R0 + R1) + (R2 + R3)), the G/4 groups by a balanced binary tree
 // (G = 16: (W0 + W1) + (W2 + W3)).
-void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps) {
+// row_major = true (orc_corner_subpix_rowmajor, measurement only): the five sums as one row-major chain each, OpenCV's own order.
+void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps, bool row_major = false) {
     const int ww = 2 * win + 1, pw = ww + 2;
     const int G = ww <= 16 ? 16 : 32;          // (half-sizes up to 15: Tracker.nMinDist < 32)
     if (win < 1 || ww > 32) return;
@@ -216,6 +245,24 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
                 tot[q] = (Wg[0] + Wg[1]) + (Wg[2] + Wg[3]);
                 if (G == 32) tot[q] = tot[q] + ((Wg[4] + Wg[5]) + (Wg[6] + Wg[7]));
             }
+            if (row_major) {
+                const float* patchp = patch.data();
+                double ra = 0, rb = 0, rc = 0, r1 = 0, r2 = 0;
+                for (int i = 0; i < ww; ++i) {
+                    const float* sp = &patchp[(size_t)(i + 1) * pw + 1];
+                    const double py = i - win;
+                    for (int j = 0; j < ww; ++j) {
+                        const double m = mask[(size_t)i * ww + j];
+                        const double tgx = sp[j + 1] - sp[j - 1], tgy = sp[j + pw] - sp[j - pw];
+                        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                        const double px = j - win;
+                        ra += gxx; rb += gxy; rc += gyy;
+                        r1 += gxx * px + gxy * py;
+                        r2 += gxy * px + gyy * py;
+                    }
+                }
+                tot[0] = ra; tot[1] = rb; tot[2] = rc; tot[3] = r1; tot[4] = r2;
+            }
             const double a = tot[0], b = tot[1], c = tot[2], bb1 = tot[3], bb2 = tot[4];
             const double det = a * c - b * b;
             if (std::fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
@@ -237,6 +284,10 @@ extern "C" {
 void orc_min_eig(const uint8_t* img, int w, int h, int stride, float* eig) { min_eig_map(img, w, h, stride, eig); }
 int orc_gftt(const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance, float* out_xy) {
     return gftt(img, w, h, stride, max_corners, quality, min_distance, out_xy);
+}
+void orc_min_eig_cvorder(const uint8_t* img, int w, int h, int stride, float* eig) { min_eig_map(img, w, h, stride, eig, true); }
+void orc_corner_subpix_rowmajor(const uint8_t* img, int w, int h, int stride, float* pts_xy, int n, int win) {
+    corner_subpix(img, w, h, stride, pts_xy, n, win, 30, 1e-2, true);
 }
 void orc_corner_subpix(const uint8_t* img, int w, int h, int stride, float* pts_xy, int n, int win) {
     corner_subpix(img, w, h, stride, pts_xy, n, win, 30, 1e-2);

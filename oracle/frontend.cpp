@@ -201,7 +201,10 @@ inline int der(const Level& L, int x, int y, int c) { return (x < 0 || y < 0 || 
 // OpenCV (whose order is build-dependent: scalar vs SSE/NEON lanes) are
 // replaced by exact 64-bit integer sums converted once to float — order-free,
 // so the HIP kernel can be bit-identical.
-void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox, float* oy, unsigned char* st) {
+// float_acc = true (orc_klt_float, measurement only): the accumulators as OpenCV's SCALAR path holds them — float, every integer product
+// converted and added in row-major window order (lkpyramid.cpp LKTrackerInvoker, acctype = itemtype = float without SIMD).  It is one of the
+// build-dependent orders the header of this file speaks of; tests/test_opencv_distance.py reports how far the exact-sum definition sits from it.
+void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox, float* oy, unsigned char* st, bool float_acc = false) {
     const int maxLevel = (int)std::min(P.lv.size(), N.lv.size()) - 1;
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2 = 0.01 * 0.01;
@@ -223,6 +226,7 @@ void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox,
         int iw11 = (1 << 14) - iw00 - iw01 - iw10;
         short Iw[kWin * kWin], Ixw[kWin * kWin], Iyw[kWin * kWin];
         long long s11 = 0, s12 = 0, s22 = 0;
+        float f11 = 0, f12 = 0, f22 = 0;
         for (int y = 0; y < kWin; ++y)
             for (int x = 0; x < kWin; ++x) {
                 int X = ipx + x, Y = ipy + y;
@@ -231,8 +235,10 @@ void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox,
                 int iyv = descale(der(I, X, Y, 1) * iw00 + der(I, X + 1, Y, 1) * iw01 + der(I, X, Y + 1, 1) * iw10 + der(I, X + 1, Y + 1, 1) * iw11, 14);
                 Iw[y * kWin + x] = (short)ival; Ixw[y * kWin + x] = (short)ixv; Iyw[y * kWin + x] = (short)iyv;
                 s11 += (long long)ixv * ixv; s12 += (long long)ixv * iyv; s22 += (long long)iyv * iyv;
+                f11 += (float)(ixv * ixv); f12 += (float)(ixv * iyv); f22 += (float)(iyv * iyv);
             }
         float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
+        if (float_acc) { A11 = f11 * FLT_SCALE; A12 = f12 * FLT_SCALE; A22 = f22 * FLT_SCALE; }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * kWin * kWin);
         if (minEig < 1e-3f || D < 1.1920929e-07f) { if (level == 0) *st = 0; continue; }
@@ -248,13 +254,16 @@ void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox,
             iw10 = cv_round((1.f - a) * b * (1 << 14));
             iw11 = (1 << 14) - iw00 - iw01 - iw10;
             long long sb1 = 0, sb2 = 0;
+            float fb1 = 0, fb2 = 0;
             for (int y = 0; y < kWin; ++y)
                 for (int x = 0; x < kWin; ++x) {
                     int X = inx + x, Y = iny + y;
                     int diff = descale(pix(J, X, Y) * iw00 + pix(J, X + 1, Y) * iw01 + pix(J, X, Y + 1) * iw10 + pix(J, X + 1, Y + 1) * iw11, 14 - 5) - Iw[y * kWin + x];
                     sb1 += (long long)diff * Ixw[y * kWin + x]; sb2 += (long long)diff * Iyw[y * kWin + x];
+                    fb1 += (float)(diff * Ixw[y * kWin + x]); fb2 += (float)(diff * Iyw[y * kWin + x]);
                 }
             float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            if (float_acc) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
             float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
             npx += dx; npy += dy;
             nx = npx + 7.f; ny = npy + 7.f;
@@ -467,6 +476,13 @@ void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
     Pyramid P = build_pyramid(prev, w, h, stride, true), N = build_pyramid(next, w, h, stride, false);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < n; ++i) lk_point(P, N, pts[2 * i], pts[2 * i + 1], &out[2 * i], &out[2 * i + 1], &status[i]);
+}
+// measurement only (tests/test_opencv_distance.py): the same tracker with OpenCV's scalar-path float accumulators
+void orc_klt_float(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+             const float* pts, int n, float* out, unsigned char* status) {
+    Pyramid P = build_pyramid(prev, w, h, stride, true), N = build_pyramid(next, w, h, stride, false);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; ++i) lk_point(P, N, pts[2 * i], pts[2 * i + 1], &out[2 * i], &out[2 * i + 1], &status[i], true);
 }
 
 orc_tracker* orc_tracker_create(const rvio_config* cfg) {

@@ -92,6 +92,9 @@ void orc_scharr(const uint8_t* src, int w, int h, int stride, int16_t* dxy);
 /* LK on raw images: win 15x15, maxLevel 3, 30 it / eps 0.01, minEig 1e-3 (Tracker.cc:237-244) */
 void orc_klt(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
              const float* pts_xy, int n, float* out_xy, unsigned char* status);
+/* measurement only: float accumulators in row-major order, as OpenCV's scalar LKTrackerInvoker holds them */
+void orc_klt_float(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+             const float* pts_xy, int n, float* out_xy, unsigned char* status);
 
 /* ---- T0: cv::createCLAHE(3.0, Size(5,5))->apply, Tracker.cc:198-202 (OpenCV clahe.cpp restated); out is w*h, packed ---- */
 void orc_clahe(const uint8_t* img, int w, int h, int stride, uint8_t* out);
@@ -100,6 +103,9 @@ void orc_clahe(const uint8_t* img, int w, int h, int stride, uint8_t* out);
 void orc_min_eig(const uint8_t* img, int w, int h, int stride, float* eig);
 int orc_gftt(const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance, float* out_xy);
 void orc_corner_subpix(const uint8_t* img, int w, int h, int stride, float* pts_xy, int n, int win);
+/* measurement only (tests/test_opencv_distance.py): OpenCV's own summation orders where the oracle fixes a canonical one */
+void orc_min_eig_cvorder(const uint8_t* img, int w, int h, int stride, float* eig);
+void orc_corner_subpix_rowmajor(const uint8_t* img, int w, int h, int stride, float* pts_xy, int n, int win);
 /* s = 1 on the first image, 2 on refills (Tracker.cc:207,350); out_xy holds n_features points; returns the count */
 int orc_detect(const rvio_config* cfg, const uint8_t* img, int stride, int s, float* out_xy);
 

@@ -285,6 +285,36 @@ def klt(prev, nxt, pts):
     return out, st
 
 
+def klt_float(prev, nxt, pts):
+    """measurement only: the tracker with OpenCV's scalar-path float accumulators (row-major)"""
+    prev = np.ascontiguousarray(prev, np.uint8)
+    nxt = np.ascontiguousarray(nxt, np.uint8)
+    pts = np.ascontiguousarray(pts, np.float32)
+    h, w = prev.shape
+    out = np.zeros_like(pts)
+    st = np.zeros(len(pts), np.uint8)
+    lib().orc_klt_float(_p(prev, up), _p(nxt, up), w, h, w, _p(pts, fp), len(pts), _p(out, fp), _p(st, up))
+    return out, st
+
+
+def min_eig_cvorder(img):
+    """measurement only: 3x3 box sums as cv::boxFilter's running sums"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    lib().orc_min_eig_cvorder(_p(img, up), w, h, w, _p(out, fp))
+    return out
+
+
+def corner_subpix_rowmajor(img, pts, win=7):
+    """measurement only: cornerSubPix with its five sums as row-major chains"""
+    img = np.ascontiguousarray(img, np.uint8)
+    pts = np.array(pts, np.float32, copy=True)
+    h, w = img.shape
+    lib().orc_corner_subpix_rowmajor(_p(img, up), w, h, w, _p(pts, fp), len(pts), int(win))
+    return pts
+
+
 class Tracker:
     def __init__(self, cfg):
         self.cfg = cfg
