@@ -52,9 +52,10 @@ def test_degenerate_motion_on_images_tracks_the_literal_oracle(gpu_required, kw)
         xl, Pl = lit.get_state()
         worst = max(worst, S.state_delta(xa, xl))
         assert worst <= bar(kw), (k, worst)
-        # (covariance: 1e-5 of its largest entry, 1e-4 at rest — zero-parallax windows are the badly conditioned ones; the stock motion holds
+        # (covariance: 2e-5 of its largest entry, 1e-3 at rest — zero-parallax windows are the badly conditioned ones; the stock motion holds
         # 1e-6, tests/test_gpu_detector.py)
-        assert np.max(np.abs(Pa - Pl)) <= 20 * bar(kw) * np.max(np.abs(Pl)), (k, float(np.max(np.abs(Pa - Pl))), float(np.max(np.abs(Pl))))
+        cov_bar = 1e-3 if kw.get("motion") == "stationary" else 2e-5       # (at rest the unobservable block of P itself grows frame by frame)
+        assert np.max(np.abs(Pa - Pl)) <= cov_bar * np.max(np.abs(Pl)), (k, float(np.max(np.abs(Pa - Pl))), float(np.max(np.abs(Pl))))
         if gi["updated"]:
             updates += 1
             c6 = 6 * min(k - 39, cfg.max_track_len - 1)
