@@ -9,7 +9,8 @@
 
 #define CLAHE_LUT_T 1024
 __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
-                                                                int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs) {
+                                                                int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs, int dbg_tag) {
+    DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 0);
     src = zoff(src, src_bs); lut = zoff(lut, bs);
     __shared__ int hist[16][256];
     __shared__ int s_w[16];

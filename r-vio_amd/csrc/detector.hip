@@ -56,7 +56,8 @@ __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k
 #define DET_TW 64
 #define DET_TH 8
 #define DET_T (DET_TW * DET_TH)
-__global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+__global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
+    DBG_I(blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, dbg_tag, 1);
     src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     __shared__ float sdx[DET_TH + 2][DET_TW + 2], sdy[DET_TH + 2][DET_TW + 2];
     __shared__ int s_max[DET_TH];
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
 #define SP_RS (SP_PW + 1 + 2 * SP_MARG)
 #define SP_T 256
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
-__global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+__global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
+    DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 2);
     src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     __shared__ unsigned char reg[SP_RS * SP_RS];
     __shared__ double s_part[2][4][5];        // by iteration parity: one barrier per iteration
@@ -677,6 +679,7 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
 #endif
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
     if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+    DBG_I(p == n - 1 && blockIdx.z == 0, dbg_tag, 3);
 }
 
 // Throughput form (batched launches): ONE wave per corner, four corners per workgroup, no workgroup barrier inside the iteration.

@@ -518,7 +518,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         const int nts = t1 - t0 + 1, nq = nts + ((tr > t1) ? 1 : 0);
         for (int tile = gw; tile < nts * nq; tile += nw) {
             const int pt = t0 + tile / nq, qi = tile % nq, qt = (qi < nts) ? t0 + qi : tr;
-            if (HOIST > 4 && qt < pt) continue;   // (batch handles store both triangles: their reduction then has no scattered mirror stores)
+            if (qt < pt) continue;   // the tiles on and above the diagonal only: the reduction mirrors the sum once
             const int p0 = pt * 16, q0 = qt * 16;
             const bool pok = p0 + gi < c6, qok = q0 + gi <= c6;
             d4 acc = {0, 0, 0, 0};
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         if (direct) {
             const double v = a2 + a1;
             S2[e] = v;
-            if (wide && qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
+            if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
         } else { S2[e] = a2; S1[e] = a1; }
     };
     if (wide) {
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         // batch handles: one thread per element, every share in list order (few accepted features per instance, many instances)
         for (int e = bi.x * 256 + tid; e < total; e += gridDim.x * 256) {
             const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
-            if (q > c6) continue;                           // (the shares of a batch handle hold both triangles: every element is summed where it lies)
+            if (q > c6 || qt < pt) continue;                // padding / lower tiles: the mirror image of the upper ones (store)
             double a2 = 0, a1 = 0;
             accumulate(e, pt, qt, 0, ng, a2, a1);
             store(e, q, pq, pt, qt, a2, a1);
@@ -771,6 +771,116 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         return;
     }
     if (last_block_done(cnt, gridDim.x)) trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
+}
+
+// Batch handles, windows whose [A|b] fits in LDS (6n (6n+1) doubles <= 64 KB: cfg A, B): ONE workgroup per instance keeps the sum in LDS and
+// walks the accepted features in ascending order, touching exactly the tiles feat_build_kernel stored (on and above the diagonal, inside
+// the feature's column range, plus the residual column's tile) — the element-per-thread form above reads every share over the whole
+// block, ~0.7 GB per launch at B = 2048 for 29 KB of result per instance.  Thread (r, c) owns element (16 pt + r, 16 qt + c) of EVERY tile,
+// so the additions to one element happen in feature order in one thread: deterministic without a barrier between features.  The sum
+// leaves LDS once, lower triangle mirrored.  A truncation candidate (rare) takes two passes (S2, then S1) and trunc_finish.
+__host__ __device__ inline size_t gram_batch_lds_doubles(int max_len, int ldh) {
+    const size_t a = (size_t)(ldh - 1) * ldh, t = trunc_lds_doubles(max_len);
+    return a > t ? a : t;
+}
+__global__ __launch_bounds__(256) void gram_reduce_batch_kernel(DevCfg cfg, int n, const double* __restrict__ partial, const int* __restrict__ nrows,
+                                                                const unsigned char* __restrict__ types, const int* __restrict__ lens, double* __restrict__ block,
+                                                                size_t bs, BatchIn bin) {
+    extern __shared__ __align__(16) double gb_dyn[];
+    const int z = blockIdx.z;
+    partial = zoffi(partial, bs, z); nrows = zoffi(nrows, bs, z); block = zoffi(block, bs, z);
+    types = zoffi(types, bin.types, z); lens = zoffi(lens, bin.len, z);
+    const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu, total = c6 * ldh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < Fu; f0 += 256) {      // ascending list of the accepted features (as in gram_reduce_kernel)
+        const int f = f0 + tid;
+        const bool flag = f < Fu && nrows[f] > 0;
+        const unsigned long long mask = __ballot(flag);
+        if (lane == 0) s_wtot[wave] = __popcll(mask);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w];
+        if (flag) {
+            const int L = lens[f];
+            const bool t2 = types[f] == '2';
+            const int Lu = t2 ? (L + 1) / 2 : L, lo = t2 ? 0 : 6 * (n - (Lu - 1)), hi = lo + 6 * (Lu - 1);
+            s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = f | (t2 ? (1 << 30) : 0) | ((lo >> 4) << 16) | (((hi - 1) >> 4) << 20);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        __syncthreads();
+    }
+    const int ng = s_base;
+    if (tid < 64) {
+        int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
+        for (int f = tid; f < Fu; f += 64) {
+            const int r = nrows[f];
+            if (r > 0) {
+                good++; rows += r;
+                const int L = lens[f];
+                if (types[f] == '2') { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
+                else smin = min(smin, 6 * (n - (L - 1)));
+            }
+        }
+        good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
+        for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
+        if (tid == 0) { s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin; }
+    }
+    __syncthreads();
+    const bool cand = s_cnt[0] > 2 && s_cnt[1] > c6 && s_cnt[3] >= 0 && s_cnt[3] < c6 && s_cnt[4] < TR_NONE && s_cnt[4] > s_cnt[3] && s_cnt[2] >= s_cnt[3] + 1;
+    const size_t gs = (size_t)ldh * ldh;
+    double* S2 = block; double* S1 = block + gs;
+    double* acc = gb_dyn;                                  // [c6][ldh]
+    const int r = tid >> 4, c = tid & 15, trq = c6 >> 4;
+    // pass 0: every feature (direct) or the type-'2' features (candidate); pass 1 (candidate only): the type-'1' features
+    for (int pass = 0; pass < (cand ? 2 : 1); ++pass) {
+        for (int e = tid; e < total; e += 256) acc[e] = 0.0;
+        __syncthreads();
+        for (int t = 0; t < ng; ++t) {
+            const int fl = s_list[t];
+            if (cand && (((fl >> 30) & 1) != (pass == 0))) continue;
+            const double* sh = partial + (size_t)(fl & 0xffff) * gs;
+            const int t0 = (fl >> 16) & 15, t1 = (fl >> 20) & 15, nts = t1 - t0 + 1, nq = nts + ((trq > t1) ? 1 : 0);
+            // the feature's stored tiles, up to 8 loads in flight per thread
+            for (int tb = 0; tb < nts * nq; tb += 8) {
+                double v[8]; int eo[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int tile = tb + u;
+                    const int pt = t0 + tile / nq, qi = tile % nq, qt = (qi < nts) ? t0 + qi : trq;
+                    const int pp = 16 * pt + r, qq = 16 * qt + c;
+                    const bool on = tile < nts * nq && qt >= pt && pp < c6 && qq <= c6;
+                    eo[u] = on ? pp * ldh + qq : -1;
+                    v[u] = on ? sh[(size_t)pp * ldh + qq] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (eo[u] >= 0) acc[eo[u]] += v[u];
+            }
+        }
+        __syncthreads();
+        double* dst = pass == 0 ? S2 : S1;
+        if (!cand) {
+            // [A|b] = the sum, lower tiles mirrored (A is symmetric; column c6 = b has no mirror image)
+            for (int e = tid; e < total; e += 256) {
+                const int q = e % ldh, pq = e / ldh;
+                if (q > c6) continue;
+                dst[e] = (q < c6 && (q >> 4) < (pq >> 4)) ? acc[q * ldh + pq] : acc[e];
+            }
+        } else {
+            for (int e = tid; e < total; e += 256) { const int q = e % ldh; if (q <= c6 && (q >> 4) >= ((e / ldh) >> 4)) dst[e] = acc[e]; }
+        }
+        __syncthreads();
+    }
+    if (!cand) {
+        if (tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; }
+        return;
+    }
+    __threadfence();
+    __syncthreads();
+    trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], gb_dyn);
 }
 
 // Gathered shards (rank-major, `block_stride` doubles apart) -> Ab = [A|b] + {n_good, n_rows, truncation column}: both parts are summed

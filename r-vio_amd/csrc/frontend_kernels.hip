@@ -427,23 +427,43 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
     }
     if (tid == 0) { t.mid[0] = 0; t.mid[1] = nIn; t.mid[2] = nMeas; *t.n_feat = nMeas; t.info->n_feat_update = nMeas; }
 }
+// hand (single instance, run-ahead mode): the counter the gate in front of this frame's filter polls — the Updater's input is complete
 __global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev t, size_t bs,
-                                                         const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
+                                                         const unsigned long long* done, unsigned long long done_target, FilterMeta* meta,
+                                                         unsigned long long* hand) {
     bookkeep_a_body(cfg, t, bs, done, done_target, meta);
+    if (hand) stage_signal(hand);
 }
+// The filter of a frame starts behind the hand-over half of that frame's book-keeping.  As a stream-level event that wait cost the filter
+// stream ~19 us of its serial chain per frame in the pipelined run (an AQL barrier packet between augcomp and the per-feature launch, with
+// four queues busy); this one-workgroup kernel polls the device-side counter instead (~5 us, launch gaps included).  One workgroup only:
+// a poll inside the ~100 LDS-heavy workgroups of the per-feature launch is a priority inversion.
+__global__ __launch_bounds__(64) void stage_gate_kernel(const unsigned long long* ctr, unsigned long long target, FilterMeta* meta, int dbg_tag) {
+    DBG_I(true, dbg_tag, 4);
+    stage_wait(ctr, target, meta);
+    DBG_I(true, dbg_tag, 5);
+}
+// ... and the other direction of the same idea: one workgroup behind cornerSubPix says "the corners of this frame are final"
+__global__ __launch_bounds__(64) void stage_signal_kernel(unsigned long long* ctr) { stage_signal(ctr); }
 // RANSAC and the hand-over half of book-keeping in ONE launch (both are one-workgroup stages of the side stream's serial chain, nothing
 // separates them since the hand-over does not wait for the detector): one launch boundary less before the filter may start
 __global__ __launch_bounds__(256) void ransac_book_a_kernel(DevCfg cfg, TrackerDev t, const rvio_imu* imu, int m, int* rng, size_t bs, size_t imu_bs,
-                                                            const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
+                                                            const unsigned long long* done, unsigned long long done_target, FilterMeta* meta,
+                                                            unsigned long long* hand) {
     extern __shared__ __align__(16) unsigned char dsh_ra[];
     ransac_body(cfg, t.n_pts, t.tracked, t.un1, t.un2, t.status, imu, m, rng, t.info, bs, imu_bs, dsh_ra);
     __threadfence_block();
     __syncthreads();
     bookkeep_a_body(cfg, t, bs, done, done_target, meta);
+    if (hand) stage_signal(hand);
 }
 
-__global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs) {
+// corners / corners_target (single instance, run-ahead mode): the counter stage_signal_kernel bumps behind this frame's cornerSubPix
+__global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
+                                                         const unsigned long long* corners, unsigned long long corners_target, FilterMeta* meta) {
     extern __shared__ __align__(16) unsigned char dsh[];
+    if (corners && !stage_wait(corners, corners_target, meta)) return;   // (timed out: error bit 4 is set)
+    DBG_S(blockIdx.z == 0, 6);
     tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, ML = cfg.max_len;

@@ -81,6 +81,12 @@ __device__ long long g_ring[64 * 8];
 __device__ int g_ring_frame;
 __device__ long long g_ring2[64 * 8];   // the same for the side stream's chain (pyramid, KLT, RANSAC, book-keeping)
 __device__ int g_ring2_frame;
+__device__ long long g_ring3[64 * 8];   // the image chain of frame `tag` (CLAHE ... cornerSubPix; the chains of consecutive frames overlap on two streams)
+#ifdef RVIO_DBG_CLOCKS
+#define DBG_I(cond, tag, id) do { if (threadIdx.x == 0 && (cond)) g_ring3[((tag) & 63) * 8 + (id)] = wall_clock64(); } while (0)
+#else
+#define DBG_I(cond, tag, id) do { } while (0)
+#endif
 #ifdef RVIO_DBG_CLOCKS
 #define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)
 #define DBG_R(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring_frame = g_ring_frame + 1; g_ring[(g_ring_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
@@ -231,7 +237,11 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
 }
 
 // ---------------------------------------------------------------- device-side completion counter (augcomp_kernel2 -> bookkeep_kernel)
-struct StageSync { unsigned long long aug; };   // device memory, zero at creation: bumped by every workgroup of the last kernel of a frame's filter chain
+// device memory, zero at creation.  aug: bumped by every workgroup of the last kernel of a frame's filter chain (-> book-keeping of frame k+2);
+// handover: bumped once by the hand-over half of book-keeping (-> the gate in front of the filter of the same frame);
+// corners: bumped once behind cornerSubPix (-> the refill half of book-keeping).  One-workgroup consumers poll them; a stream-level event in
+// their place costs the WAITING stream ~10-20 us of its serial chain in the pipelined run (measured in situ, profiles/r03_chain_clocks.txt).
+struct StageSync { unsigned long long aug, handover, corners; };
 // every thread of the workgroup calls these
 __device__ __forceinline__ void stage_signal(unsigned long long* c) {
     __threadfence();                         // each wave: its stores written back and performed at agent scope

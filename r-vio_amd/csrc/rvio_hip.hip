@@ -51,7 +51,7 @@ struct rvio_hip {
     double *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
            *Pt1 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
     int *nrows = nullptr, *acc = nullptr, *ndof = nullptr, *gram_cnt = nullptr;
-    size_t trunc_lds = 0;
+    size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
     int feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
@@ -67,13 +67,17 @@ struct rvio_hip {
     int imu_cap = RVIO_MAX_IMU;   // samples the host-side staging (d_imu, hb_imu, pinned ring) holds; grows on demand (ensure_imu_capacity)
     float* d_cand = nullptr;
     uint8_t* d_img = nullptr;
-    DetDev det = {}, det_b = {};                  // device detector (T7), allocated on first use: two sets of scratch — in run-ahead mode the
+    static const int kIC = 3;                     // image chains in flight in run-ahead mode (streams, detector scratch sets, CLAHE LUT sets)
+    DetDev dets[kIC] = {};                        // device detector (T7), allocated on first use: kIC sets of scratch — in run-ahead mode the
                                                   // detectors of consecutive frames run on two streams, by frame parity
     int det_set_last = 0;                         // the set the last call used (rvio_hip_get_corners)
     bool det_ready = false, use_det = false;
     hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
     hipStream_t stream_c = nullptr;               // CLAHE stream of the run-ahead mode (frame k+1 is equalised while frame k is still being detected)
-    hipEvent_t evC[2] = {nullptr, nullptr};       // equalised image of the frame ready, by frame parity
+    hipEvent_t evC[kIC] = {nullptr, nullptr, nullptr};   // equalised image + pyramid of the frame ready, by image chain
+    hipStream_t stream_e = nullptr;               // third image-chain stream (the chain is ~200 us long in situ: two in flight made it a co-bottleneck of the 130 us period)
+    int n_ic = 2;                                 // image chains in flight (<= kIC)
+    int ic = 0;                                   // image chain (stream / detector scratch / LUT set) of the call in progress: frame_no % kIC in run-ahead mode, else the parity
     hipStream_t side = nullptr;                   // stream of pyramid / KLT / RANSAC of the call in progress (stream_d beside the detector, else ts)
     hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
@@ -93,7 +97,7 @@ struct rvio_hip {
     uint8_t* pin[kPin] = {nullptr, nullptr, nullptr};
     hipEvent_t evPin[kPin] = {nullptr, nullptr, nullptr}, evPin2[kPin] = {nullptr, nullptr, nullptr};
     size_t pin_img = 0, pin_imu = 0, pin_bytes = 0;
-    uint8_t *d_eq = nullptr, *d_lut2[2] = {nullptr, nullptr};   // CLAHE output image and tile LUTs (enable_equalizer), the LUTs by frame parity
+    uint8_t *d_eq = nullptr, *d_lut2[kIC] = {nullptr, nullptr, nullptr};   // CLAHE output image and tile LUTs (enable_equalizer), the LUTs by image chain
     // Buffers the front end of frame k+1 would otherwise overwrite while book-keeping of frame k still reads them (run-ahead of the
     // image chain on the pipelined path, see track_dev_impl): equalised image, detector corner list and its count, by frame parity
     uint8_t* d_eq2[4] = {nullptr, nullptr, nullptr, nullptr};   // four, in rotation: the equalised image IS level 0 of its pyramid, which the KLT of the NEXT frame still reads
@@ -104,6 +108,9 @@ struct rvio_hip {
     int par = 0;                                  // parity of the call in progress / of the last call (getters)
     hipStream_t tail = nullptr;                   // stream that ran book-keeping in the call in progress (the hand-over event is recorded there)
     bool runahead = false;                        // call in progress: pipelined whole-frame path with the device detector
+    bool dev_sync = false;                        // ... of ONE instance: hand-over -> filter and corners -> refill go through device-side counters (StageSync)
+    bool gate_pending = false;                    // the filter of the frame in flight starts behind stage_gate_kernel (target: gate_target)
+    unsigned long long gate_target = 0;
     int cl_tx = 0, cl_ty = 0, cl_tw = 0, cl_th = 0, cl_clip = 0;
     float cl_scale = 0.f;
     float* d_in_xy = nullptr;
@@ -183,6 +190,7 @@ static int dalloc(rvio_hip* h, T** p, size_t n) {
 #define SYNC_FRONT(h)                                                                     \
     do {                                                                                  \
         if ((h)->stream_c) HIPCHK(h, hipStreamSynchronize((h)->stream_c));                \
+        if ((h)->stream_e) HIPCHK(h, hipStreamSynchronize((h)->stream_e));                \
         if ((h)->stream_d) HIPCHK(h, hipStreamSynchronize((h)->stream_d));                \
         HIPCHK(h, hipStreamSynchronize((h)->stream_t));                                   \
     } while (0)
@@ -292,7 +300,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
         DALLOC(h, h->d_eq2[0], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[1], (size_t)d.W * d.H); DALLOC(h, h->d_eq2[2], (size_t)d.W * d.H);
         DALLOC(h, h->d_eq2[3], (size_t)d.W * d.H);
         h->d_eq = h->d_eq2[0];
-        DALLOC(h, h->d_lut2[0], (size_t)h->cl_tx * h->cl_ty * 256); DALLOC(h, h->d_lut2[1], (size_t)h->cl_tx * h->cl_ty * 256);
+        for (int k = 0; k < std::max(2, h->n_ic); ++k) DALLOC(h, h->d_lut2[k], (size_t)h->cl_tx * h->cl_ty * 256);
     }
     DALLOC(h, h->d_in_xy, (size_t)2 * d.F); DALLOC(h, h->d_in_st, d.F);
     DALLOC(h, h->rng, 40); DALLOC(h, h->cand_scratch, (size_t)2 * d.F + 8);
@@ -322,7 +330,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
 // on one queue serialise (measured: 4.5 k instead of 6.6 k frames/s).  hipStreamCreate deals streams onto a pool of GPU_MAX_HW_QUEUES (4)
 // shared queues by reference count, so whether a handle gets four distinct ones depends on every stream the process created before it
 // (torch's, another library's).  A stream created with a CU mask owns a private queue; the mask here enables every CU.
-static hipError_t make_stream(rvio_hip* h, hipStream_t* s) {
+static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = false) {
     static const int mode = getenv("RVIO_STREAM_MODE") ? atoi(getenv("RVIO_STREAM_MODE")) : 1;
     if (mode == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     hipDeviceProp_t prop;
@@ -331,6 +339,9 @@ static hipError_t make_stream(rvio_hip* h, hipStream_t* s) {
     const int words = (prop.multiProcessorCount + 31) / 32;
     std::vector<uint32_t> mask((size_t)std::max(words, 1), 0xffffffffu);
     if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    // experiment: the front-end streams leave every `fe_skip`-th CU to the filter stream (RVIO_FE_SKIP=4: three quarters of the chip)
+    static const int fe_skip = getenv("RVIO_FE_SKIP") ? atoi(getenv("RVIO_FE_SKIP")) : 0;
+    if (front_end && fe_skip > 1) for (int c = 0; c < prop.multiProcessorCount; ++c) if (c % fe_skip == 0) mask[c / 32] &= ~(1u << (c % 32));
     e = hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
     if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
     return e;
@@ -355,15 +366,20 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, make_stream(h, &h->stream));
     h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
-    if (h->one_stream) h->stream_t = h->stream_d = h->stream_c = h->stream;
+    if (h->one_stream) h->stream_t = h->stream_d = h->stream_c = h->stream_e = h->stream;
     else {
-        HIPCHK(h, make_stream(h, &h->stream_t));
-        HIPCHK(h, make_stream(h, &h->stream_d));
-        HIPCHK(h, make_stream(h, &h->stream_c));
+        HIPCHK(h, make_stream(h, &h->stream_t, true));
+        HIPCHK(h, make_stream(h, &h->stream_d, true));
+        HIPCHK(h, make_stream(h, &h->stream_c, true));
+        // Image chains in flight.  Two (default): with the filter, tracker and side streams that makes FOUR busy queues.  A third chain on a
+        // fifth queue was measured (RVIO_IC=3): the frame period goes from 131 to 180-250 us whatever CUs the front end is kept off — beyond
+        // four busy queues the command processor time-slices them.
+        if (const char* e = getenv("RVIO_IC")) h->n_ic = std::max(1, std::min((int)rvio_hip::kIC, atoi(e)));
+        if (h->n_ic > 2) HIPCHK(h, make_stream(h, &h->stream_e, true));
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, kEvFlags));
-    for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->evC[b], kEvFlags));
+    for (int b = 0; b < rvio_hip::kIC; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->evC[b], kEvFlags));
     h->ts = h->stream;
     for (int b = 0; b < 2; ++b) {
         HIPCHK(h, hipEventCreateWithFlags(&h->evT[b], kEvFlags));
@@ -438,6 +454,10 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
+    if (batch > 1 && gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double) <= 64 * 1024) {
+        h->gram_batch_lds = gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double);
+        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
+    }
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
@@ -496,6 +516,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream_c) hipStreamSynchronize(h->stream_c);
+    if (h->stream_e) hipStreamSynchronize(h->stream_e);
     if (h->stream_d) hipStreamSynchronize(h->stream_d);
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -506,7 +527,8 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
     if (h->stream_c && !h->one_stream) hipStreamDestroy(h->stream_c);
-    for (int b = 0; b < 2; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
+    if (h->stream_e && !h->one_stream) hipStreamDestroy(h->stream_e);
+    for (int b = 0; b < rvio_hip::kIC; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
     for (int b = 0; b < 4; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evH[b]) hipEventDestroy(h->evH[b]); }
     for (int b = 0; b < 2; ++b) { if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
     if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
@@ -518,6 +540,7 @@ void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
 int rvio_hip_sync(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
     if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+    if (h->stream_e) HIPCHK(h, hipStreamSynchronize(h->stream_e));
     if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d));
     HIPCHK(h, hipStreamSynchronize(h->stream_t));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -716,6 +739,10 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
     // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
     const int gram_chunk = (B == 1) ? 64 : 256;
+    static const bool no_gram_batch = getenv("RVIO_NO_GRAM_BATCH") != nullptr;   // A/B timing
+    if (B > 1 && world == 1 && combine && h->gram_batch_lds && !no_gram_batch)   // batch handle, [A|b] fits in LDS: one workgroup per instance, stored tiles only
+        hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, B), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, bs, h->bin);
+    else
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + gram_chunk - 1) / gram_chunk)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
                        h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, (B == 1) ? 1 : 0, bs, h->bin);
     HIPCHK(h, hipGetLastError());
@@ -856,7 +883,10 @@ int rvio_hip_get_update_diag(rvio_hip* h, int32_t* n_feat, int32_t* accepted, do
 static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const DevCfg& d = h->dc;
     const int c = h->cur, o = c ^ 1;
-    const int cg = 1 + std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256));
+    // one stream: width (one entry per thread, ~29 workgroups); a batch: every workgroup builds Vk first (a serial section of one thread),
+    // so few fat workgroups per instance (the chip is full anyway)
+    static const int aug_wgs = getenv("RVIO_AUG_WGS") ? atoi(getenv("RVIO_AUG_WGS")) : 4;   // A/B timing
+    const int cg = 1 + (h->batch > 1 ? std::max(1, aug_wgs) : std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256)));
     unsigned long long* done = nullptr;
     if (h->batch == 1) { done = &h->stage_sync->aug; h->stage_tgt.aug += (unsigned long long)cg; }
     hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
@@ -897,14 +927,14 @@ static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE 
 }
 static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a slab)
     const DevCfg& d = h->dc;
-    int rc = detector_alloc_set(h, h->det);
-    if (rc != RVIO_OK) return rc;
-    if ((rc = detector_alloc_set(h, h->det_b)) != RVIO_OK) return rc;
+    int rc = RVIO_OK;
+    for (int k = 0; k < h->n_ic; ++k) if ((rc = detector_alloc_set(h, h->dets[k])) != RVIO_OK) return rc;
+    for (int k = h->n_ic; k < rvio_hip::kIC; ++k) h->dets[k] = h->dets[0];
     DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F); DALLOC(h, h->det_xy2[2], (size_t)2 * d.F);
     DALLOC(h, h->det_nout, 3);
     float* mask = nullptr;
     DALLOC(h, mask, (size_t)31 * 31);
-    for (DetDev* q : {&h->det, &h->det_b}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; q->sp_win = (int)std::floor(.5 * h->cfg.min_dist); }
+    for (DetDev* q : {&h->dets[0], &h->dets[1], &h->dets[2]}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; q->sp_win = (int)std::floor(.5 * h->cfg.min_dist); }
     return RVIO_OK;
 }
 static int detector_init(rvio_hip* h) {
@@ -912,7 +942,7 @@ static int detector_init(rvio_hip* h) {
     int rc = detector_check(h);
     if (rc != RVIO_OK) return rc;
     if (!h->det_in_slab && (rc = detector_alloc(h)) != RVIO_OK) return rc;
-    DetDev& q = h->det;
+    DetDev& q = h->dets[0];
     // cornerSubPix window (cornersubpix.cpp): float expf on the host, so that device and oracle share glibc's values
     const int spw = q.sp_win, spww = 2 * spw + 1;
     std::vector<float> hm((size_t)spww * spww);
@@ -924,7 +954,7 @@ static int detector_init(rvio_hip* h) {
     HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm.data(), sizeof(float) * hm.size(), hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
     HIPCHK(h, hipStreamSynchronize(h->stream));   // (hm is a local)
     std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
-    for (DetDev* qq : {&h->det, &h->det_b})
+    for (DetDev* qq : {&h->dets[0], &h->dets[1], &h->dets[2]})
         HIPCHK(h, hipMemcpy2DAsync(qq->maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
                                    hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -941,26 +971,27 @@ static int detector_init(rvio_hip* h) {
 //    except mbIsTheFirstImage (the detector's distance factor), hence one wait on book-keeping(k-1) in front of nms(k).  What
 //    book-keeping(k) still reads while frame k+1 is being detected is double-buffered by frame parity (equalised image, corner list).
 static DetDev det_view(const rvio_hip* h) {
-    DetDev q = (h->runahead && h->par) ? h->det_b : h->det;
+    DetDev q = h->dets[h->runahead ? h->ic : 0];
     q.xy = h->det_xy2[h->dslot]; q.n_out = h->det_nout + h->dslot;
     return q;
 }
 // the stream CLAHE and the detector of the call in progress run on: in run-ahead mode the image chains of consecutive frames
 // alternate between two streams (each with its own detector scratch and CLAHE LUTs), so that two of them are in flight — the chain is
 // ~150 us long, the longest of the frame, and with one stream it WAS the frame period
-static hipStream_t image_stream(const rvio_hip* h) { return h->runahead ? (h->par ? h->stream_c : h->stream_t) : h->ts; }
+static hipStream_t image_stream_of(const rvio_hip* h, int ic) { return ic == 0 ? h->stream_t : (ic == 1 ? h->stream_c : h->stream_e); }
+static hipStream_t image_stream(const rvio_hip* h) { return h->runahead ? image_stream_of(h, h->ic) : h->ts; }
 static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs, hipEvent_t first_flag_ready) {
     const DevCfg& d = h->dc;
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
     const DetDev q = det_view(h);
     const hipStream_t ds = image_stream(h);
-    h->det_set_last = (h->runahead && h->par) ? 1 : 0;
+    h->det_set_last = h->runahead ? h->ic : 0;
     const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
     if (h->wide_px)
         hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
     if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
     if (h->wide_px && d.W % 4 == 0)
         hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
@@ -973,7 +1004,7 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     else if (h->wide_px)
         hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
     else
-        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
+        hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -1008,9 +1039,9 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         h->eq_slot = (h->eq_slot + 1) % 4;
         uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
-        uint8_t* lut = h->d_lut2[h->par];
+        uint8_t* lut = h->d_lut2[h->runahead ? h->ic : h->par];
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
-                           h->cl_clip, h->cl_scale, lut, src_bs, bs);
+                           h->cl_clip, h->cl_scale, lut, src_bs, bs, (int)h->frame_no);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)
             hipLaunchKernelGGL(clahe_interp_kernel4, dim3((d.W / 4 + 63) / 64, (d.H + 15) / 16, B), dim3(256), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_ty,
                                1.0f / (float)h->cl_tw, 1.0f / (float)h->cl_th, lut, eq, src_bs, bs);
@@ -1023,8 +1054,8 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             // the longest serial chain of the front end — 19 us less of it; the image chain has the slack
             launch_pyramid(cs);
             pyramid_done = true;
-            HIPCHK(h, hipEventRecord(h->evC[h->par], cs));
-            HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->par], 0));
+            HIPCHK(h, hipEventRecord(h->evC[h->ic], cs));
+            HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->ic], 0));
             forked = true;
         }
     }
@@ -1047,7 +1078,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         const hipEvent_t flag = (h->runahead && h->frame_no >= 1 && !h->first_cleared) ? h->evT[(h->frame_no - 1) & 3] : nullptr;
         const int rc = detect_dev(h, d_img, stride, src_bs, flag);
         if (rc != RVIO_OK) return rc;
-        if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));   // corners of frame k ready (book-keeping on the side stream waits for it)
+        // corners of frame k ready (the refill half of book-keeping on the side stream waits for it): a one-workgroup signal behind
+        // cornerSubPix that book-keeping polls, or a stream-level event
+        if (h->dev_sync) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, image_stream(h), &h->stage_sync->corners); h->stage_tgt.corners++; }
+        else if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));
     }
     if (!pyramid_done) launch_pyramid(h->side);
     HIPCHK(h, hipGetLastError());
@@ -1067,6 +1101,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     h->tail = h->ts;
     h->handover_evt = false;
     const unsigned long long* done = nullptr; unsigned long long done_target = 0;
+    const unsigned long long* corners = nullptr; unsigned long long corners_target = 0;
     if (h->use_det) {   // the detector's corner list replaces the caller's
         const float* xy = h->det_xy2[h->dslot];
         const int* nout = h->det_nout + h->dslot;
@@ -1076,23 +1111,31 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             if (h->book_dev && !(kDbgSkip & 4)) { done = &h->stage_sync->aug; done_target = h->book_target; }
             h->book_dev = false;
             h->tail = h->side;
+            unsigned long long* hand = nullptr;
+            if (h->dev_sync) { hand = &h->stage_sync->handover; h->stage_tgt.handover++; }
             if (fused)
                 hipLaunchKernelGGL(ransac_book_a_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
-                                   done, done_target, h->meta);
+                                   done, done_target, h->meta, hand);
             else
-            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta);
-            HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));   // the Updater's input is complete: the filter of this frame waits for THIS
-            h->handover_evt = true;
-            HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
+            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, hand);
+            // the Updater's input is complete: the filter of this frame waits for THIS — the gate kernel on the filter stream polls the
+            // counter the launch above bumps, and the refill half below polls the detector's; or two stream-level events
+            if (h->dev_sync) { h->gate_pending = true; h->gate_target = h->stage_tgt.handover; corners = &h->stage_sync->corners; corners_target = h->stage_tgt.corners; }
+            else {
+                HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));
+                h->handover_evt = true;
+                HIPCHK(h, hipStreamWaitEvent(h->side, h->evD1, 0));
+            }
         } else {             // join the side stream (long finished when the detector is)
             HIPCHK(h, hipEventRecord(h->evD1, h->side));
             HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
-            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta);
+            hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, (unsigned long long*)nullptr);
         }
-        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs);
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs, corners, corners_target, h->meta);
     } else {
-        hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1), dim3(256), 0, h->ts, h->dc, h->t, (size_t)0, (const unsigned long long*)nullptr, 0ull, h->meta);
-        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0);
+        hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1), dim3(256), 0, h->ts, h->dc, h->t, (size_t)0, (const unsigned long long*)nullptr, 0ull, h->meta, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0,
+                           (const unsigned long long*)nullptr, 0ull, h->meta);
     }
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -1108,7 +1151,11 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->par = piped_call ? (int)(h->frame_no & 1) : 0;
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;   // A/B timing only
     h->runahead = piped_call && h->use_det && !no_runahead;
+    static const bool no_devsync = getenv("RVIO_NO_DEVFLAG") != nullptr || getenv("RVIO_NO_DEVSYNC") != nullptr;   // A/B timing: stream-level events instead
+    h->dev_sync = h->runahead && h->batch == 1 && !no_devsync;
+    h->gate_pending = false;
     h->dslot = h->runahead ? (int)(h->frame_no % 3) : h->par;
+    h->ic = h->runahead ? (int)(h->frame_no % h->n_ic) : h->par;
     const int nb = (h->pyr_cur + 1) % 4;   // pyramid of the new image; pyr_cur holds mLastImage's (slot nb was last read by KLT(k-3))
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
@@ -1310,7 +1357,10 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const double t2 = dbg_host ? now() : 0;
     HIPCHK(h, hipEventRecord(h->evT[h->frame_no & 3], h->tail));      // behind book-keeping, on the stream that ran it
     // the filter needs the hand-over, not the refill: in run-ahead mode it waits for the first half of book-keeping only
-    if (!(kDbgSkip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
+    if (h->gate_pending) {
+        if (!(kDbgSkip & 16)) hipLaunchKernelGGL(stage_gate_kernel, dim3(1), dim3(64), 0, h->stream, &h->stage_sync->handover, h->gate_target, h->meta, (int)h->frame_no);
+        h->gate_pending = false;
+    } else if (!(kDbgSkip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
     if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
@@ -1478,7 +1528,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         // The image goes to the stream of this frame's image chain (image_stream: tracker stream / fourth stream by parity).  hb_img[b]
         // was last read by frame k-2: its CLAHE / detector (same stream, earlier) and — without the equaliser — its pyramid on the side
         // stream, which book-keeping(k-2) followed.
-        hipStream_t is = b ? h->stream_c : h->stream_t;
+        hipStream_t is = image_stream_of(h, (int)(h->frame_no % h->n_ic));
         if (h->frame_no >= 2) HIPCHK(h, hipStreamWaitEvent(is, h->evT[(h->frame_no - 2) & 3], 0));
         HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
         HIPCHK(h, hipEventRecord(h->evPin2[ps], is));
@@ -1544,7 +1594,7 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->dslot, sizeof cnt, hipMemcpyDeviceToHost));
     if (n) *n = cnt;
     if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->dslot], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
-    const DetDev& ds_ = h->det_set_last ? h->det_b : h->det;
+    const DetDev& ds_ = h->dets[h->det_set_last];
     if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
     if (eig) HIPCHK(h, hipMemcpy(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
     return RVIO_OK;
@@ -1614,6 +1664,9 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta);
+        } else if (which == 3 && h->batch > 1 && h->gram_batch_lds) {
+            hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, h->batch), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block,
+                               h->slab_bytes, h->bin);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
             hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + (h->batch == 1 ? 63 : 255)) / (h->batch == 1 ? 64 : 256))), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
                                h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);
@@ -1621,11 +1674,11 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             launch_ug_final(h, n, h->block, h->P[h->cur ^ 1], which == 4, which == 5);   // (outputs: scratch / the spare covariance buffer, overwritten by the next stage anyway)
         } else if (which == 6) {   // cornerSubPix on the corners of the last detector call (reads raw_xy, rewrites xy with the same values)
             if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
-            const DetDev q = [&] { DetDev v = h->det_set_last ? h->det_b : h->det; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
+            const DetDev q = [&] { DetDev v = h->dets[h->det_set_last]; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
             const uint8_t* im = h->pyr[h->pyr_cur].img[0];   // level 0 of the current pyramid = the image the detector saw
             if (q.sp_win != SP_WIN) hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, 1), dim3(SPG_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
             else if (h->wide_px) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
-            else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes, 0);
         } else return RVIO_ERR_INVALID;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -1650,6 +1703,13 @@ int rvio_hip_debug_ring2(rvio_hip* h, long long* out512, int* frame) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring2), sizeof(long long) * 512));
     HIPCHK(h, hipMemcpyFromSymbol(frame, HIP_SYMBOL(g_ring2_frame), sizeof(int)));
+    return RVIO_OK;
+}
+int rvio_hip_debug_ring3(rvio_hip* h, long long* out512) {
+    if (!h || !out512) return RVIO_ERR_INVALID;
+    int rc = rvio_hip_sync(h);
+    if (rc != RVIO_OK) return rc;
+    HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring3), sizeof(long long) * 512));
     return RVIO_OK;
 }
 int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {

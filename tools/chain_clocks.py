@@ -58,4 +58,35 @@ print("bookkeep end -> next klt: %.1f us" % np.mean(rows2[1:, 0] - rows2[:-1, 5]
 # how far the side chain runs ahead of the filter: book-keeping(k) end -> feat_prop(k) start (frame numbers: side = fr2, filter = last)
 off = fr2.value - last
 print("side chain frames ahead of the filter at the end:", off)
+# ---- absolute timeline of the three chains by FRAME (image chain tag = frame number; the side ring advances once per frame at KLT, the
+# filter ring once per update at feat_prop): who waits for whom
+out3 = (C.c_longlong * 512)()
+h.L.rvio_hip_debug_ring3(h.h, out3)
+t3 = np.array(list(out3), dtype=np.int64).reshape(64, 8) / 100.0
+side_of = lambda f: t2[(fr2.value - (n_frames - 1 - f)) & 63] / 100.0     # KLT of frame f was the (f+1)-th KLT launch
+filt_of = lambda f: t[(last - (n_frames - 1 - f)) & 63] / 100.0
+rows = []
+for f in range(n_frames - 40, n_frames - 2):
+    im, sd, fl = t3[f & 63], side_of(f), filt_of(f)
+    rows.append([im[3] - im[0],            # image chain: CLAHE start -> last cornerSubPix workgroup done
+                 sd[6] - im[3],            # corners ready -> refill half of book-keeping starts (negative: book-keeping waited for the detector)
+                 sd[6] - sd[4],            # hand-over half (after its wait) -> refill half starts
+                 sd[0] - side_of(f - 1)[5],  # book-keeping(f-1) end -> KLT(f) start
+                 fl[0] - sd[4],            # hand-over half of book-keeping(f) after its wait -> feat_prop(f) start
+                 sd[4] - sd[3],            # the hand-over half's wait for filter(f-2)
+                 im[0] - side_of(f - 3)[5]])   # book-keeping(f-3) end -> CLAHE(f) start
+rows = np.array(rows)
+for name, col in zip(["image chain CLAHE start -> cornerSubPix end", "cornerSubPix(f) end -> bookkeep_b(f) start (<0: waited for the detector)",
+                      "bookkeep_a(f) after wait -> bookkeep_b(f) start", "bookkeep_b(f-1) end -> KLT(f) start", "bookkeep_a(f) after wait -> feat_prop(f) start",
+                      "bookkeep_a(f): wait for filter(f-2)", "bookkeep_b(f-3) end -> CLAHE(f) start"], rows.T):
+    print("%-78s mean %7.1f  min %7.1f  max %7.1f us" % (name, col.mean(), col.min(), col.max()))
+g = []
+for f in range(n_frames - 40, n_frames - 2):
+    im, fl, flp = t3[f & 63], filt_of(f), filt_of(f - 1)
+    if im[4] > 0:
+        g.append([im[4] - flp[6], im[5] - im[4], fl[0] - im[5]])
+if g:
+    g = np.array(g)
+    print("filter stream: augcomp(f-1) block 0 end -> gate(f) start %.1f us, gate start -> end %.1f us, gate end -> feat_prop(f) start %.1f us (means)" % tuple(g.mean(0)))
+    print("gate duration per frame (us):", " ".join("%.0f" % v for v in g[:, 1]))
 h.close()
