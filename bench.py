@@ -467,9 +467,9 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
            "p50_ekf_update_ms": float(np.median(lat["update"])) if lat["update"] else None,
            "x_at_cpu_frames": x_at, "x_final": h.get_state()[0]}
     # ---- roofline (live, HIP events on the handle's stream; the rocprofv3 summary in profiles/ must agree).
-    # Candidates = the four longest kernels of the frame in profiles/*_kernel_stats.md, each timed by rvio_hip_debug_time_kernel in the very
-    # form the handle launches, on the operands the last frame left in HBM; the DOMINANT one (largest live average) is `roofline`, the
-    # others go to `roofline_other`.
+    # Candidates = the longest kernels of the section-8(a) hot path (KLT chain -> HBM, filter -> FP64: SURVEY.md 8d), each timed by
+    # rvio_hip_debug_time_kernel in the very form the handle launches, on the operands the last frame left in HBM; the DOMINANT one
+    # (largest live average) is `roofline`, the others and the detector's longest kernel (cornerSubPix, section 8(f)) go to `roofline_other`.
     n = cfg.max_track_len - 1
     c6 = 6 * n
     F = cfg.n_features
@@ -481,6 +481,12 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     # solve: T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T (c6 = 6n columns, register tableau).  Algorithmic
     # FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8)
     fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
+    # per-feature stage (U1-U5): the gate term of W_filter for the tracks the last frame handed over, sum_f 2 rho (6n)^2 + 2 rho^2 (6n) + 4/3 rho^3
+    ty_l, ln_l, _ = h.get_tracks()
+    fl_feat = 0.0
+    for L, t in zip(ln_l, ty_l):
+        rho = max(2 * ((int(L) + 1) // 2 if t == ord("2") else int(L)) - 3, 0)
+        fl_feat += 2.0 * rho * c6 ** 2 + 2.0 * rho ** 2 * c6 + (4.0 / 3.0) * rho ** 3
     it_l = 10
     by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10: template + it_l bilinear windows per level
     by_subpix = F * (4.0 * 17 * 17) * 5                          # cornerSubPix: a 17x17 float window re-sampled per iteration, ~5 iterations per corner
@@ -492,21 +498,21 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
          "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_klt * 1e6,
          "note": "timed matching the current image back onto the previous one from the current feature positions (the forward match's displacements, "
                  "reversed): the frame's own inputs are gone once book-keeping has moved the features"},
-        {"bound": "mfma", "kernel": "feat_build_kernel (U1-U5, FP64 MFMA gate)", "match": "feat_", "achieved": None, "peak": PEAK_F64, "unit": "TFLOP/s",
-         "avg_us": t_feat * 1e6},
-        {"bound": "hbm", "kernel": "subpix_kernel (cornerSubPix, 4 waves per corner)", "match": "subpix_kernel", "achieved": by_subpix / t_subpix / 1e9, "peak": 8000.0,
-         "unit": "GB/s", "avg_us": t_subpix * 1e6},
+        {"bound": "mfma", "kernel": "feat_build_kernel (U1-U5, FP64 MFMA gate; %d features handed over by the last frame)" % len(ln_l), "match": "feat_",
+         "achieved": (fl_feat / t_feat / 1e12) if fl_feat > 0 else None, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_feat * 1e6},
     ]
-    for c in cands:
+    detector = {"bound": "hbm", "kernel": "subpix_kernel (cornerSubPix, 4 waves per corner; detector = section 8(f))", "match": "subpix_kernel",
+                "achieved": by_subpix / t_subpix / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_subpix * 1e6}
+    for c in cands + [detector]:
         c["frac"] = None if c["achieved"] is None else c["achieved"] / c["peak"]
         # HBM-side bytes per launch: PMC counters cannot be read live, so this is the committed rocprofv3 --pmc result OF THIS CONFIGURATION
         # (profiles/r03_pmc_traffic_cfg<name>.json: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
         c["traffic"], c["traffic_unit"] = pmc_traffic(name, c.pop("match"))
     cands.sort(key=lambda c: -c["avg_us"])
-    res["roofline"] = dict(cands[0], dominant_by="largest live average among the frame's four longest kernels (rvio_hip_debug_time_kernel)",
+    res["roofline"] = dict(cands[0], dominant_by="largest live average among the hot path's longest kernels (rvio_hip_debug_time_kernel)",
                            context="a single 752x480 stream offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1% of either roof by construction; "
                                    "update_at_load.roofline prices the whole update at full load, batched_filter / batched_streams the same kernels with the chip full")
-    res["roofline_other"] = cands[1:]
+    res["roofline_other"] = cands[1:] + [detector]
     h.close()
     return res
 

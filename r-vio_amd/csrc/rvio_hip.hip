@@ -478,7 +478,10 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (getenv("RVIO_SOLVE6") || getenv("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
-            if (batch > 1 && h->solve5_variant && !getenv("RVIO_SOLVE7")) h->solve7_variant = 0;
+            // (round 3, measured and NOT adopted: solve7 with T through the L2 scratch instead of LDS — 11 KB of LDS, eight workgroups per CU, no gemm_T
+            // launch — as the batch form at 6n <= 64, RVIO_BATCH_SOLVE7: 2.62 ms per batched frame at B = 2048 against 2.29 with solve6 behind gemm_T)
+            if (batch > 1 && h->solve5_variant && !getenv("RVIO_SOLVE7") && !(h->solve7_variant == 1 && getenv("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
+            if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
             if (h->solve7_variant == 1)
             {
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
@@ -771,6 +774,7 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     }
     case 3: hipLaunchKernelGGL((solve7_kernel<2, 16, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     case 4: hipLaunchKernelGGL((solve7_kernel<3, 16, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+    case 5: hipLaunchKernelGGL((solve7_kernel<1, 16, 4, false, 8>), gb, dim3(256), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     default: break;
     }
     if (h->solve5_variant == 1)

@@ -34,20 +34,23 @@ __device__ __forceinline__ void s7_for(F&& f) {
 
 #define S7_RING 32     // slots of the publication ring: >= NW + 2 (a wave lags the publisher by less than NW + 1 steps)
 
-template <int RPL, int CPW, int NW>
+// STAGE (6n <= 64 only): T's operands through LDS (one stream: latency); false: T through the scratch buffer in L2 like the longer windows —
+// 11 KB of LDS instead of 112 KB, eight workgroups per CU: the throughput form batch handles use (with RING = 8 publication slots).
+template <int RPL, int CPW, int NW, bool STAGE_ = (RPL == 1), int RING = S7_RING>
 __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
                                                          const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ Tscr,
                                                          double* __restrict__ Wout, double* __restrict__ x_out, size_t bs) {
     meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Tscr = zoff(Tscr, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
     static_assert(RPL >= 1 && RPL <= 3, "rows per lane");
     static_assert(CPW % 2 == 0, "a wave owns pairs of columns");
-    static_assert(S7_RING >= NW + 2 && (S7_RING & (S7_RING - 1)) == 0, "ring depth");
+    static_assert(RING >= NW + 2 && (RING & (RING - 1)) == 0, "ring depth");
+    static_assert(!STAGE_ || RPL == 1, "staging needs 6n <= 64");
     constexpr int NT = 64 * NW, NR = 64 * RPL;
-    constexpr bool STAGE = (RPL == 1);                  // 6n <= 64: T through LDS
+    constexpr bool STAGE = STAGE_;                      // 6n <= 64: T through LDS
     constexpr int LS = 65;                              // LDS row stride of the staged 64 x 64 operands
     extern __shared__ __align__(16) double s7_dyn[];    // STAGE: As | Ps | Ts (3 x 64 x LS) | Pt (24 x 64); As is reused for the dx partial sums
-    __shared__ double s_f[S7_RING][2][NR];
-    __shared__ int s_p[S7_RING][2], s_flag[S7_RING];
+    __shared__ double s_f[RING][2][NR];
+    __shared__ int s_p[RING][2], s_flag[RING];
     __shared__ int s_prow[6 * RVIO_MAX_LEN], s_invp[NR];
     __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
     __shared__ double s_y[6 * RVIO_MAX_LEN];
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         return;
     }
     DBG_T(56);
-    if (tid < S7_RING) s_flag[tid] = 0;
+    if (tid < RING) s_flag[tid] = 0;
     const double s2 = cfg.sigma_im * cfg.sigma_im;
     double mcol[CPW][RPL], mbv[RPL];                    // the tableau: register column cc of this wave, this lane's RPL rows; the right-hand side
     // ---- T = s2 I + A Pcc on the matrix cores: A = Ab (row-major, ld = ldh), B = Pcc = P[24:,24:] (column-major, ld = dmax)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         if (lane == (pa & 63)) used |= 1u << (pa >> 6);
         elim_v(mcol[C0 + 1], fa, pa);
         search(std::integral_constant<int, C0 + 1>{}, fb, pb, ipb, sb);
-        const int slot = sp & (S7_RING - 1);
+        const int slot = sp & (RING - 1);
 #pragma unroll
         for (int r = 0; r < RPL; ++r) { s_f[slot][0][lane + 64 * r] = fa[r]; s_f[slot][1][lane + 64 * r] = fb[r]; }
         if (lane == 0) {
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
             if (sp >= npair) { done = true; break; }
             if (sp == 15) DBG_T(50);
             if (sp == 16) DBG_T(52);
-            const int slot = sp & (S7_RING - 1);
+            const int slot = sp & (RING - 1);
             // flag, pivot rows and multipliers are read together; the data is valid if the flag (written last by the publisher) matches
             int pa, pb;
             double fa[RPL], fb[RPL];
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
     DBG_T(61);
     // dx = K r = Pc y   (Updater.cc:544): NT / d threads per row, each a contiguous share of the columns; partial sums added in a fixed order
     {
-        double* part = STAGE ? s7_dyn : &s_f[0][0][0];         // (As is idle now; the ring is idle too: NR * S7_RING >= 4096 doubles)
+        double* part = STAGE ? s7_dyn : &s_f[0][0][0];         // (As is idle now; the ring is idle too: 2 NR RING >= 1024 doubles >= np d)
         const int np = max(1, min(4, NT / d)), share = (c6 + np - 1) / np;
         const int pt = tid / d, i = tid - pt * d;
         if (pt < np) {

@@ -29,7 +29,8 @@ def test_the_drivers_bench_command_prints_its_line(gpu_required):
         assert leg in out and "error" not in out[leg], (leg, out.get(leg))
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["achieved"] > 0 and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert "traffic" in rf and rf["avg_us"] >= max(o["avg_us"] for o in out["roofline_other"])     # the dominant kernel is the slowest one timed
+    hot = [o for o in out["roofline_other"] if "section 8(f)" not in o["kernel"]]
+    assert "traffic" in rf and rf["avg_us"] >= max(o["avg_us"] for o in hot)     # the dominant kernel is the slowest hot-path kernel timed
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("port", "reference") and cb["sample"]
     par = out["parity"]

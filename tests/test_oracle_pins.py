@@ -207,6 +207,37 @@ def test_fisheye_undistort_inverts_the_equidistant_model():
     assert np.array_equal(O.undistort(cfg, np.float32([[cfg.cx, cfg.cy]])), np.zeros((1, 2), np.float32))   # theta_d <= 1e-8: scale 1
 
 
+def test_fisheye_wide_field_points_follow_the_opencv_3_3_form():
+    """The restated cv::fisheye::undistortPoints is the OpenCV 3.3 form (the version the reference's README names): ten fixed-point
+    iterations, NO clamp of theta_d.  Later versions differ for wide-field points — 3.4.x clamps theta_d to [-pi/2, pi/2], 4.x iterates with
+    Newton steps and flags points that do not converge — so a reference built against a newer OpenCV returns something else there.  Pinned
+    here: an independent numpy write-up of the 3.3 loop agrees to the last float for rays up to 88 degrees off axis and for theta_d beyond
+    pi/2, and the 3.4 clamp would change exactly the points with theta_d > pi/2 (stated, not adopted)."""
+    cfg = abi.config_named("B", fisheye=1, k1=-0.0137, k2=0.0207, p1=-0.0128, p2=0.0025)
+    k = [float(cfg.k1), float(cfg.k2), float(cfg.p1), float(cfg.p2)]
+    rng = np.random.default_rng(11)
+    thd = np.concatenate([rng.uniform(0.05, 1.53, 60), rng.uniform(np.pi / 2, 2.2, 20)])      # distorted angles, 20 of them beyond pi/2
+    ang = rng.uniform(0, 2 * np.pi, len(thd))
+    xd = np.stack([thd * np.cos(ang), thd * np.sin(ang)], 1)
+    px = np.stack([float(cfg.fx) * xd[:, 0] + float(cfg.cx), float(cfg.fy) * xd[:, 1] + float(cfg.cy)], 1).astype(np.float32)
+    un = O.undistort(cfg, px)
+    want, clamped = np.zeros_like(un), np.zeros_like(un)
+    for i, (u, v) in enumerate(px):
+        pw = np.array([(float(u) - float(cfg.cx)) / float(cfg.fx), (float(v) - float(cfg.cy)) / float(cfg.fy)])
+        for out, clamp in ((want, False), (clamped, True)):
+            td = float(np.linalg.norm(pw))
+            if clamp:
+                td = min(max(-np.pi / 2, td), np.pi / 2)
+            th = td
+            for _ in range(10):
+                t2 = th * th
+                th = td / (1 + k[0] * t2 + k[1] * t2 ** 2 + k[2] * t2 ** 3 + k[3] * t2 ** 4)
+            out[i] = (pw * (np.tan(th) / np.linalg.norm(pw))).astype(np.float32)
+    assert np.array_equal(un, want)
+    wide = thd > np.pi / 2
+    assert np.all(np.any(clamped[wide] != want[wide], axis=1)) and np.array_equal(clamped[~wide], want[~wide])
+
+
 def test_pyr_down_and_scharr_against_numpy():
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
