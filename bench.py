@@ -254,6 +254,7 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
     info = h.frame_info()
     x_gpu, P_gpu = h.get_state()
+    h.close()      # (the first live handle of a process owns private hardware queues: every secondary leg below measures a handle of its own)
 
     out = {
         "metric": "camera frames/sec (KLT+RANSAC track, IMU propagate, MSCKF update, augment/compose), 200 feat / 10-clone window",
@@ -383,7 +384,6 @@ def main():
             except Exception as e:   # noqa: BLE001
                 out.setdefault("cpu_baseline", {"error": repr(e)[:300]})
                 out.setdefault("parity", {"error": repr(e)[:300]})
-    h.close()
     if sharded:
         if comm is not None:
             comm.close()

@@ -13,6 +13,8 @@
 //                     runs the rounds on those lists with the candidate states in LDS, then ranks
 //   subpix_kernel     one workgroup of 4 waves per corner: the neighbourhood cached in LDS, 17x17 bilinear patch, one
 //                     window term per thread, double sums in the oracle's canonical tree order, 2x2 solve, <= 30 iterations
+//   subpix_kernel1    the throughput form (one wave per corner: batch handles); subpix_generic_kernel: any half-window 1..15 other than the stock 7
+//   (mineig_kernel4, nms_kernel4: several pixels per thread, batch handles)
 #pragma once
 
 #define DET_NBCAP 64          // stronger-neighbour list capacity per candidate (global memory)

@@ -2,7 +2,7 @@
 // R-VIO hot path.
 //
 //   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455 (U1..U5) + the feature's share of the information block
-//   gram_reduce_kernel / block_sum_kernel
+//   gram_reduce_kernel / block_sum_kernel / gram_reduce_batch_kernel (batch handles: one workgroup per instance, the sum in LDS, stored tiles only)
 //                        measurement compression (Updater.cc:469-536) in information form [A|b] = Hw^T [Hw | r], with the
 //                        reference's rank truncation (Updater.cc:516-529) in its structural form   
 //   gemm_T_kernel        FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc

@@ -7,6 +7,7 @@
 //   ransac_kernel     UndistortAndNormalize + Ransac::FindInliers    (Tracker.cc:252-264, Ransac.cc:180-247); ransac_book_a_kernel = the same
 //                     + bookkeep_a_kernel's body in one launch (run-ahead path)
 //   bookkeep_a_kernel, bookkeep_b_kernel   track book-keeping: the Updater's hand-over / FindNewer + refill (Tracker.cc:271-393, FeatureDetector.cc:78-150)
+//   stage_gate_kernel, stage_signal_kernel one-workgroup poll / bump of a device-side counter (StageSync): hand-over -> filter, corners -> refill
 #include "rvio_dev.h"
 #include "frontend_dev.h"
 #include "../../include/rvio_hip.h"

@@ -2,6 +2,7 @@
 // Single translation unit: the two kernel files are included so that one hipcc call
 // builds the whole library (frontend_kernels.hip switches FP contraction off for itself).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <dlfcn.h>
 #include <cmath>
@@ -108,6 +109,7 @@ struct rvio_hip {
     int par = 0;                                  // parity of the call in progress / of the last call (getters)
     hipStream_t tail = nullptr;                   // stream that ran book-keeping in the call in progress (the hand-over event is recorded there)
     bool runahead = false;                        // call in progress: pipelined whole-frame path with the device detector
+    bool private_queues = false;                  // this handle's streams own hardware queues (make_stream)
     bool dev_sync = false;                        // ... of ONE instance: hand-over -> filter and corners -> refill go through device-side counters (StageSync)
     bool gate_pending = false;                    // the filter of the frame in flight starts behind stage_gate_kernel (target: gate_target)
     unsigned long long gate_target = 0;
@@ -330,9 +332,13 @@ static int alloc_frontend_slab(rvio_hip* h) {
 // on one queue serialise (measured: 4.5 k instead of 6.6 k frames/s).  hipStreamCreate deals streams onto a pool of GPU_MAX_HW_QUEUES (4)
 // shared queues by reference count, so whether a handle gets four distinct ones depends on every stream the process created before it
 // (torch's, another library's).  A stream created with a CU mask owns a private queue; the mask here enables every CU.
+// ... for ONE handle: beyond four busy queues the command processor time-slices (eight handles with four private queues each ran at a quarter
+// of the rate of eight handles on the shared pool), so only the first live handle of a process takes private queues; the others share the pool
+// as before (many streams per GPU are what batch handles are for).
+static std::atomic<int> g_private_queue_handles{0};
 static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = false) {
     static const int mode = getenv("RVIO_STREAM_MODE") ? atoi(getenv("RVIO_STREAM_MODE")) : 1;
-    if (mode == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (mode == 0 || !h->private_queues) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, h->device);
     if (e != hipSuccess) return e;
@@ -345,6 +351,11 @@ static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = fals
     e = hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
     if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
     return e;
+}
+
+static bool profiler_serialises() {
+    const char* e = getenv("ROCPROF_COUNTER_COLLECTION");
+    return e && *e && std::strcmp(e, "0") != 0 && std::strcmp(e, "False") != 0 && std::strcmp(e, "false") != 0;
 }
 
 static int create_impl(const rvio_config* cfg, int device, int batch, bool front_end, rvio_hip** out) {
@@ -364,6 +375,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
     *out = h;   // returned even on allocation failure so last_error is readable
     HIPCHK(h, hipSetDevice(device));
+    h->private_queues = g_private_queue_handles.fetch_add(1) == 0;
+    if (!h->private_queues) g_private_queue_handles.fetch_sub(1);
     HIPCHK(h, make_stream(h, &h->stream));
     h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
     if (h->one_stream) h->stream_t = h->stream_d = h->stream_c = h->stream_e = h->stream;
@@ -523,6 +536,7 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_d) hipStreamSynchronize(h->stream_d);
     if (h->stream_t) hipStreamSynchronize(h->stream_t);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->private_queues) g_private_queue_handles.fetch_sub(1);
     for (void* p : h->allocs) hipFree(p);
     for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); if (h->evPin2[k]) hipEventDestroy(h->evPin2[k]); }
     if (h->first_mirror) hipHostFree(h->first_mirror);
@@ -743,7 +757,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
     const int gram_chunk = (B == 1) ? 64 : 256;
     static const bool no_gram_batch = getenv("RVIO_NO_GRAM_BATCH") != nullptr;   // A/B timing
-    if (B > 1 && world == 1 && combine && h->gram_batch_lds && !no_gram_batch)   // batch handle, [A|b] fits in LDS: one workgroup per instance, stored tiles only
+    if (B >= 128 && world == 1 && combine && h->gram_batch_lds && !no_gram_batch)   // batch handle, [A|b] fits in LDS: one workgroup per instance, stored tiles only
         hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, B), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, bs, h->bin);
     else
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + gram_chunk - 1) / gram_chunk)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
@@ -890,7 +904,7 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     // one stream: width (one entry per thread, ~29 workgroups); a batch: every workgroup builds Vk first (a serial section of one thread),
     // so few fat workgroups per instance (the chip is full anyway)
     static const int aug_wgs = getenv("RVIO_AUG_WGS") ? atoi(getenv("RVIO_AUG_WGS")) : 4;   // A/B timing
-    const int cg = 1 + (h->batch > 1 ? std::max(1, aug_wgs) : std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256)));
+    const int cg = 1 + (h->batch >= 128 ? std::max(1, aug_wgs) : std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256)));
     unsigned long long* done = nullptr;
     if (h->batch == 1) { done = &h->stage_sync->aug; h->stage_tgt.aug += (unsigned long long)cg; }
     hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
@@ -1155,7 +1169,10 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     h->par = piped_call ? (int)(h->frame_no & 1) : 0;
     static const bool no_runahead = getenv("RVIO_NO_RUNAHEAD") != nullptr;   // A/B timing only
     h->runahead = piped_call && h->use_det && !no_runahead;
-    static const bool no_devsync = getenv("RVIO_NO_DEVFLAG") != nullptr || getenv("RVIO_NO_DEVSYNC") != nullptr;   // A/B timing: stream-level events instead
+    // A/B timing: stream-level events instead.  Also when a counter-collecting profiler is attached (rocprofv3 --pmc exports
+    // ROCPROF_COUNTER_COLLECTION): it serialises kernels across queues, and a kernel that polls a counter another queue's kernel bumps would sit
+    // there until its 30 s time-out.
+    static const bool no_devsync = getenv("RVIO_NO_DEVFLAG") != nullptr || getenv("RVIO_NO_DEVSYNC") != nullptr || profiler_serialises();
     h->dev_sync = h->runahead && h->batch == 1 && !no_devsync;
     h->gate_pending = false;
     h->dslot = h->runahead ? (int)(h->frame_no % 3) : h->par;
@@ -1373,7 +1390,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const double t4 = dbg_host ? now() : 0;
     // the filter of this frame is finished when ... single instance in run-ahead mode: its last kernel has bumped the device-side counter
     // (book-keeping of frame k+2 polls it); otherwise an event behind it
-    static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr;
+    static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr || profiler_serialises();
     if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->stage_tgt.aug; }
     else { if (!(kDbgSkip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
     if (dbg_host) {
@@ -1668,7 +1685,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta);
-        } else if (which == 3 && h->batch > 1 && h->gram_batch_lds) {
+        } else if (which == 3 && h->batch >= 128 && h->gram_batch_lds) {
             hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, h->batch), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block,
                                h->slab_bytes, h->bin);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
