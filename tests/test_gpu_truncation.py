@@ -121,3 +121,36 @@ def test_degenerate_motion_on_direct_tracks(gpu_required, kw):
     h.close()
     h1.close()
     assert updates >= 80
+
+
+@pytest.mark.parametrize("name,scale", [("B", 0.1), ("A", 0.1), ("A", 0.03), ("C", 0.1)])
+def test_information_form_under_small_image_noise_and_long_windows(gpu_required, name, scale):
+    """The device forms A = Hw^T Hw (condition number squared) and inverts T = s2 I + A Pcc.  Stressed where that hurts most: the image
+    noise sigma_im 10x / 30x smaller than EuRoC's (s2 100x / 1000x smaller against the same A), on the 14- and 20-clone windows, direct
+    tracks with 10 % drops — free-running against the LITERAL oracle (QR compression, S = H P H^T + R in measurement space), 70 frames."""
+    from rvio_amd import hip
+    cfg = abi.config_named(name, enable_equalizer=0, sigma_px=0.002180293 * scale, sigma_py=0.002186767 * scale)
+    n = 70
+    seq = rv.synth.SynthSequence(cfg, duration=(38 + n + 4) / 20.0, seed=6, drop_prob=0.1)
+    w, a, ni = seq.init_from_static(38)
+    h = hip.RvioHip(cfg)
+    h.initialize(w, a, ni)
+    lit = O.System(cfg)
+    lit.set_state(*O.initialize(cfg, w, a, ni))
+    drv = rv.synth.DirectTrackDriver(seq)
+    worst, accepted = 0.0, 0
+    for k in range(39, 39 + n):
+        inp = drv.inputs(k)
+        oi = lit.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])[0]
+        h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        pts = h.get_points()[0]
+        drv.after(pts)
+        gi = h.frame_info()
+        for key in ("n_feat_update", "n_feat_accepted", "n_rows", "updated"):
+            assert gi[key] == oi[key], (k, key, gi[key], oi[key])
+        assert gi["device_error"] == 0, (k, gi["device_error"])
+        worst = max(worst, S.state_delta(h.get_state()[0], lit.get_state()[0]))
+        assert worst <= 1e-6, (k, worst)
+        accepted += gi["n_feat_accepted"]
+    h.close()
+    assert accepted > 500
