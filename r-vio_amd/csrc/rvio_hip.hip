@@ -36,10 +36,16 @@ struct rvio_hip {
     hipStream_t ts = nullptr;         // stream the tracker kernels of the call in progress go to
     hipEvent_t evT[4] = {nullptr, nullptr, nullptr, nullptr};   // book-keeping(k) done: a ring by frame number (the image chain of frame k waits for frame k-3's)
     hipEvent_t evH[4] = {nullptr, nullptr, nullptr, nullptr};   // hand-over of frame k written (bookkeep_a_kernel): what the filter of frame k waits for
-    hipEvent_t evF[2] = {nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
+    // Tracker -> Updater hand-over tables in rotation: book-keeping(k) rewrites table k % kHand once filter(k - kHand) has read it.  Two
+    // tables (rounds 1-2) let the side chain run at most two frames ahead of the filter; four were built to absorb the frames in which the
+    // side chain is late (one in ten: the gate in front of the filter then waits ~100 us).  Measured: they do not — the side chain's own
+    // period equals the filter's (134 against 136 us in situ), so it never builds the lead; what is late in those frames is the IMAGE
+    // chain (greedy_kernel: 29-200 us, data dependent), which the refill half of book-keeping waits for.  Kept: it costs 30 KB per instance.
+    static const int kHand = 4;
+    hipEvent_t evF[kHand] = {nullptr, nullptr, nullptr, nullptr}, evIn[2] = {nullptr, nullptr};
     long frame_no = 0;
     bool piped = false, in_frame = false;
-    struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[2];
+    struct TrackOut { int* n_feat; unsigned char* types; int* len; float* meas; } tout[kHand];
     std::string err;
     // filter state (double-buffered)
     FilterMeta* meta = nullptr;
@@ -82,12 +88,12 @@ struct rvio_hip {
     hipStream_t side = nullptr;                   // stream of pyramid / KLT / RANSAC of the call in progress (stream_d beside the detector, else ts)
     hipEvent_t evD0 = nullptr, evD1 = nullptr;
     uint8_t* hb_img[2] = {nullptr, nullptr};      // staging of rvio_hip_frame (host buffers), by frame parity
-    rvio_imu* hb_imu[3] = {nullptr, nullptr, nullptr};   // (run-ahead mode rotates three slots: see rvio_hip_frame)
+    rvio_imu* hb_imu[kHand + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // (run-ahead mode rotates kHand + 1 slots: see rvio_hip_frame)
     hipEvent_t book_wait = nullptr;   // run-ahead: the event book-keeping of the frame in flight has to wait for (filter k-2)
     // how "the filter of the frame with parity b has finished" is known: 0 = evF[b] was recorded behind it, 1 = the device-side counter
     // stage_sync->aug reaches fin_target[b] (single instance, run-ahead mode: no marker packet on the filter stream)
-    int fin_mode[2] = {0, 0};
-    unsigned long long fin_target[2] = {0, 0}, book_target = 0;
+    int fin_mode[kHand] = {0, 0, 0, 0};
+    unsigned long long fin_target[kHand] = {0, 0, 0, 0}, book_target = 0;
     bool book_dev = false;
     bool handover_evt = false;        // frame in flight: evH was recorded behind the hand-over half of book-keeping
     bool last_ra = false;             // the previous rvio_hip_frame call ran in run-ahead mode
@@ -313,8 +319,10 @@ static int alloc_frontend_slab(rvio_hip* h) {
     DALLOC(h, t.tmp_feats, (size_t)2 * d.F); DALLOC(h, t.tmp_un, (size_t)2 * d.F); DALLOC(h, t.tmp_slot, d.F);
     DALLOC(h, t.cand_acc, d.F); DALLOC(h, t.mid, 4);
     DALLOC(h, t.cell_pts, (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2);
-    DALLOC(h, h->tout[1].n_feat, 1); DALLOC(h, h->tout[1].types, d.Fu); DALLOC(h, h->tout[1].len, d.Fu);
-    DALLOC(h, h->tout[1].meas, (size_t)2 * d.Fu * d.max_len);
+    for (int k = 1; k < rvio_hip::kHand; ++k) {
+        DALLOC(h, h->tout[k].n_feat, 1); DALLOC(h, h->tout[k].types, d.Fu); DALLOC(h, h->tout[k].len, d.Fu);
+        DALLOC(h, h->tout[k].meas, (size_t)2 * d.Fu * d.max_len);
+    }
     for (int b = 0; b < 4; ++b) {
         int w = d.W, hg = d.H;
         for (int l = 0; l < 4; ++l) {
@@ -400,6 +408,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipEventCreateWithFlags(&h->evH[b], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evH[b + 2], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evF[b], kEvFlags));
+        HIPCHK(h, hipEventCreateWithFlags(&h->evF[b + 2], kEvFlags));
         HIPCHK(h, hipEventCreateWithFlags(&h->evIn[b], kEvFlags));
     }
     const size_t ldh = d.ldh;
@@ -547,7 +556,8 @@ void rvio_hip_destroy(rvio_hip* h) {
     if (h->stream_e && !h->one_stream) hipStreamDestroy(h->stream_e);
     for (int b = 0; b < rvio_hip::kIC; ++b) if (h->evC[b]) hipEventDestroy(h->evC[b]);
     for (int b = 0; b < 4; ++b) { if (h->evT[b]) hipEventDestroy(h->evT[b]); if (h->evH[b]) hipEventDestroy(h->evH[b]); }
-    for (int b = 0; b < 2; ++b) { if (h->evF[b]) hipEventDestroy(h->evF[b]); if (h->evIn[b]) hipEventDestroy(h->evIn[b]); }
+    for (int b = 0; b < rvio_hip::kHand; ++b) if (h->evF[b]) hipEventDestroy(h->evF[b]);
+    for (int b = 0; b < 2; ++b) if (h->evIn[b]) hipEventDestroy(h->evIn[b]);
     if (h->stream_t && !h->one_stream) hipStreamDestroy(h->stream_t);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -661,7 +671,7 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
             const size_t o = (size_t)i * h->slab_bytes;
             HIPCHK(h, hipMemsetAsync((char*)h->t.n_pts + o, 0, sizeof(int), h->stream));
             HIPCHK(h, hipMemsetAsync((char*)h->t.hist_len + o, 0, sizeof(int) * h->dc.F, h->stream));
-            for (int b = 0; b < 2; ++b) HIPCHK(h, hipMemsetAsync((char*)h->tout[b].n_feat + o, 0, sizeof(int), h->stream));
+            for (int b = 0; b < rvio_hip::kHand; ++b) HIPCHK(h, hipMemsetAsync((char*)h->tout[b].n_feat + o, 0, sizeof(int), h->stream));
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->frame_no = 0; h->piped = false; h->in_frame = false; h->fuse_m = -1;
@@ -689,7 +699,7 @@ static int ensure_imu_capacity(rvio_hip* h, int m) {
         return RVIO_OK;
     };
     if ((rc = grow(&h->d_imu)) != RVIO_OK) return rc;
-    for (int k = 0; k < 3; ++k) if (h->hb_imu[k] && (rc = grow(&h->hb_imu[k])) != RVIO_OK) return rc;
+    for (int k = 0; k <= rvio_hip::kHand; ++k) if (h->hb_imu[k] && (rc = grow(&h->hb_imu[k])) != RVIO_OK) return rc;
     for (int k = 0; k < rvio_hip::kPin; ++k) if (h->pin[k]) { hipHostFree(h->pin[k]); h->pin[k] = nullptr; }   // rvio_hip_frame lays the ring out again
     h->imu_cap = cap;
     return RVIO_OK;
@@ -1339,19 +1349,20 @@ int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride
 static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand, bool staged,
                           bool begin_only = false) {
     if (h->in_frame) { h->err = "rvio_hip_frame_begin_dev without rvio_hip_frame_end"; return RVIO_ERR_INVALID; }
-    const int b = (int)(h->frame_no & 1);
-    h->t.n_feat = h->tout[b].n_feat; h->t.types = h->tout[b].types; h->t.len = h->tout[b].len; h->t.meas = h->tout[b].meas;
+    const int b = (int)(h->frame_no & 1);                   // parity: the staging of rvio_hip_frame
+    const int hb = (int)(h->frame_no % rvio_hip::kHand);    // hand-over table of this frame
+    h->t.n_feat = h->tout[hb].n_feat; h->t.types = h->tout[hb].types; h->t.len = h->tout[hb].len; h->t.meas = h->tout[hb].meas;
     static const bool no_ra = getenv("RVIO_NO_RUNAHEAD") != nullptr;
     const bool ra = !d_cand && !h->one_stream && !no_ra;   // run-ahead mode (track_dev_impl): book-keeping runs on the side stream
-    if (h->frame_no >= 2) {   // the filter of frame k-2 has consumed this hand-over buffer: only the stream that runs book-keeping has to know.
+    if (h->frame_no >= rvio_hip::kHand) {   // the filter of frame k - kHand has consumed this hand-over buffer: only the stream that runs book-keeping has to know.
         // (In run-ahead mode the image chains — CLAHE, detector — never touch the hand-over: making them wait here tied image(k) to
         // filter(k-2) and with it the frame period to image chain + filter chain over two frames.)
         // Run-ahead: of the side stream's chain (pyramid, KLT, RANSAC, book-keeping) only book-keeping writes the hand-over, so the wait
         // goes right in front of it (post_klt_dev) — at the head of the frame it tied KLT(k) to filter(k-2) and made
         // [side chain + filter chain] the period of two frames.
-        if (!ra) { int rcw = wait_filter_done(h, b, h->stream_t); if (rcw == RVIO_OK) rcw = wait_filter_done(h, b, h->stream_d); if (rcw != RVIO_OK) return rcw; }
-        else if (h->fin_mode[b] == 0) h->book_wait = h->evF[b];
-        else { h->book_dev = true; h->book_target = h->fin_target[b]; }
+        if (!ra) { int rcw = wait_filter_done(h, hb, h->stream_t); if (rcw == RVIO_OK) rcw = wait_filter_done(h, hb, h->stream_d); if (rcw != RVIO_OK) return rcw; }
+        else if (h->fin_mode[hb] == 0) h->book_wait = h->evF[hb];
+        else { h->book_dev = true; h->book_target = h->fin_target[hb]; }
     } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
     if (m < 0) return RVIO_ERR_INVALID;
@@ -1391,8 +1402,8 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     // the filter of this frame is finished when ... single instance in run-ahead mode: its last kernel has bumped the device-side counter
     // (book-keeping of frame k+2 polls it); otherwise an event behind it
     static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr || profiler_serialises();
-    if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[b] = 1; h->fin_target[b] = h->stage_tgt.aug; }
-    else { if (!(kDbgSkip & 8)) HIPCHK(h, hipEventRecord(h->evF[b], h->stream)); h->fin_mode[b] = 0; }
+    if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[hb] = 1; h->fin_target[hb] = h->stage_tgt.aug; }
+    else { if (!(kDbgSkip & 8)) HIPCHK(h, hipEventRecord(h->evF[hb], h->stream)); h->fin_mode[hb] = 0; }
     if (dbg_host) {
         const double t5 = now();
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
@@ -1434,8 +1445,8 @@ int rvio_hip_frame_begin_dev(rvio_hip* h, const uint8_t* d_img, int stride, cons
 int rvio_hip_frame_end(rvio_hip* h) {
     if (!h || !h->in_frame) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipEventRecord(h->evF[h->frame_no & 1], h->stream));
-    h->fin_mode[h->frame_no & 1] = 0;
+    HIPCHK(h, hipEventRecord(h->evF[h->frame_no % rvio_hip::kHand], h->stream));
+    h->fin_mode[h->frame_no % rvio_hip::kHand] = 0;
     h->frame_no++;
     h->in_frame = false;
     return RVIO_OK;
@@ -1507,7 +1518,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         for (int k = 0; k < 2; ++k) {
             DALLOC(h, h->hb_img[k], (size_t)h->dc.W * h->dc.H);
             DALLOC(h, h->hb_imu[k], (size_t)h->imu_cap);
-            if (k == 1) DALLOC(h, h->hb_imu[2], (size_t)h->imu_cap);
+            if (k == 1) for (int q = 2; q <= rvio_hip::kHand; ++q) DALLOC(h, h->hb_imu[q], (size_t)h->imu_cap);
             DALLOC(h, h->hb_cand[k], (size_t)2 * h->dc.F);
             HIPCHK(h, hipStreamSynchronize(h->stream));   // DALLOC clears on the filter stream
         }
@@ -1538,10 +1549,10 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
     if (ra) {
         // run-ahead mode.  The IMU batch goes to the SIDE stream (RANSAC runs there; propagate on the filter stream waits for evIn): it
         // has to wait for the filter of frame k-2 (the last reader of hb_imu[b]), and that wait must not sit in front of an image chain.
-        // Three IMU slots in rotation: slot k % 3 was last read by filter(k-3) / RANSAC(k-3), and this copy follows book-keeping(k-1) on the
-        // side stream, which waited for filter(k-3) — no wait of its own (one here would again put filter(k-2) in front of KLT(k)).
-        imu_slot = (int)(h->frame_no % 3);
-        if (!h->last_ra && h->frame_no >= 1) { int rcw = wait_filter_done(h, 0, h->stream_d); if (rcw == RVIO_OK && h->frame_no >= 2) rcw = wait_filter_done(h, 1, h->stream_d); if (rcw != RVIO_OK) return rcw; }
+        // kHand + 1 IMU slots in rotation: slot k % (kHand + 1) was last read by filter(k - kHand - 1) / RANSAC(k - kHand - 1), and this copy follows
+        // book-keeping(k-1) on the side stream, which waited for filter(k - 1 - kHand) — no wait of its own (one here would again put a filter in front of KLT(k)).
+        imu_slot = (int)(h->frame_no % (rvio_hip::kHand + 1));
+        if (!h->last_ra) for (int i = 0; i < rvio_hip::kHand && i < h->frame_no; ++i) { const int rcw = wait_filter_done(h, i, h->stream_d); if (rcw != RVIO_OK) return rcw; }
         if (h->frame_no < 2 && !h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
         if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[imu_slot], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_d));
         HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_d));
@@ -1554,7 +1565,7 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         HIPCHK(h, hipMemcpyAsync(h->hb_img[b], pp, npx, hipMemcpyHostToDevice, is));
         HIPCHK(h, hipEventRecord(h->evPin2[ps], is));
     } else {
-        if (h->frame_no >= 2) { const int rcw = wait_filter_done(h, b, h->stream_t); if (rcw != RVIO_OK) return rcw; }   // filter(k-2) has consumed hb_imu[b]
+        if (h->frame_no >= 2) { const int rcw = wait_filter_done(h, (int)((h->frame_no - 2) % rvio_hip::kHand), h->stream_t); if (rcw != RVIO_OK) return rcw; }   // filter(k-2) has consumed hb_imu[b]
         else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));
         if (m > 0) HIPCHK(h, hipMemcpyAsync(h->hb_imu[b], pp + h->pin_imu, sizeof(rvio_imu) * m, hipMemcpyHostToDevice, h->stream_t));
         HIPCHK(h, hipEventRecord(h->evIn[b], h->stream_t));                                  // propagate (filter stream) only needs the IMU batch
