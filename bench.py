@@ -8,7 +8,10 @@ resident in HBM before the timed region.  N=1 workload = BASELINE.json configs[1
 features, 10-clone window).  N>1: the feature-sharded updater — every rank runs the
 replicated front end + propagate, builds the Jacobians / nullspace / gate / compression of its
 feature shard, and the per-rank information blocks [A|b] are exchanged with ONE all-gather (RCCL)
-per frame; the same frames are processed by the whole group => "scaling": "strong".
+per frame, enqueued by the library on the handle's filter stream (rvio_hip_frame_sharded_dev: one
+C-ABI call per frame); the same frames are processed by the whole group => "scaling": "strong".
+Every frame index goes through FrameSet.args, which refuses anything outside the resident sequence;
+secondary legs fail soft ({"error": ...}) — tests/test_gpu_bench.py runs the driver's own command.
 
 Prints ONE JSON line on rank 0.
 """

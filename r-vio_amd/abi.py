@@ -7,7 +7,7 @@ import ctypes as C
 import math
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class rvio_config(C.Structure):

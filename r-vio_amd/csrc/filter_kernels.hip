@@ -2,6 +2,7 @@
 // R-VIO hot path.
 //
 //   feat_build_kernel    Updater::update per-feature loop  Updater.cc:109-455 (U1..U5) + the feature's share of the information block
+//   geom4_kernel         U1 + U2 of a batch handle, four features per wave (one per 16-lane DPP row), ahead of feat_build_kernel<4>
 //   gram_reduce_kernel / block_sum_kernel / gram_reduce_batch_kernel (batch handles: one workgroup per instance, the sum in LDS, stored tiles only)
 //                        measurement compression (Updater.cc:469-536) in information form [A|b] = Hw^T [Hw | r], with the
 //                        reference's rank truncation (Updater.cc:516-529) in its structural form   
@@ -52,12 +53,14 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                                                 const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                 int shard_rank, int shard_world,
                                                 double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta, const int f) {
+                                                double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta, const int f,
+                                                const double* gpose = nullptr, const int* gvalid = nullptr) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
     ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
     if (tm_global) tm_global = zoffi(tm_global, bs, bi.z);
+    if (gpose) { gpose = zoffi(gpose, bs, bi.z); gvalid = zoffi(gvalid, bs, bi.z); }
     n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, bi.z); types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z); meas = zoffi(meas, bin.meas, bi.z);
     const int tid = threadIdx.x, T = blockDim.x;   // f: the feature slot of this pass
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
@@ -92,9 +95,12 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     float mxv = 0, myv = 0;
     const int lane = tid & 63;
     if (lane < ML) { mxv = mz[2 * lane]; myv = mz[2 * lane + 1]; }
-    for (int e = tid; e < 7 * n; e += T) xcl[e] = x[26 + e];
-    const bool wave0 = tid < 64;
     const int nPh = L - 1;
+    // batch handles: U1 + U2 were computed by geom4_kernel, four features per wave (the relative-pose chain and the triangulation are
+    // single-wave phases with <= 11 of 64 lanes at work; here they are a third of the kernel's instructions) — fetch the poses and the triple
+    if (gpose) { const double* gp = gpose + (size_t)f * (ML - 1) * 24; for (int e = tid; e < nPh * 24; e += T) pose[e] = gp[e]; }
+    else for (int e = tid; e < 7 * n; e += T) xcl[e] = x[26 + e];
+    const bool wave0 = tid < 64;
     const double sig = cfg.sigma_im, sig2 = sig * sig;
     const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
     const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
@@ -106,7 +112,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     // R_I(i) = R(q_i) R_I(i-1), t_I(i) = R(q_i) (t_I(i-1) - p_i) as a short serial product of 3x3 matrices, then the
     // camera-frame poses in parallel again.  The reference carries the chain as normalised quaternions and passes
     // R_c through RotToQuat/QuatToRot; both are the same rotations up to O(1e-16).
-    if (wave0) {
+    if (wave0 && !gpose) {
         const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
         if (lane < nPh) {
             const m33 Rl = q2r(ldq(rel + 7 * lane));
@@ -150,6 +156,9 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     double phi = 0, psi = 0, rho = 0;
     bool valid = true;
     const float fx0 = __shfl(mxv, 0, 64), fy0 = __shfl(myv, 0, 64);
+    if (gpose) {
+        if (tid == 0) { misc[0] = pfinv_out[3 * f]; misc[1] = pfinv_out[3 * f + 1]; misc[2] = pfinv_out[3 * f + 2]; misc[3] = gvalid[f] ? 1.0 : 0.0; }
+    } else
     if (wave0) {
         phi = atan2((double)fy0, sqrt((double)fx0 * (double)fx0 + 1));
         psi = atan2((double)fx0, 1.0);
@@ -546,9 +555,174 @@ __global__ __launch_bounds__(HOIST > 4 ? 256 : 1024) void feat_build_kernel(DevC
                                   const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                   int shard_rank, int shard_world,
                                   double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
-                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta) {
+                                  double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta,
+                                  const double* gpose, const int* gvalid) {
     feat_build_body<HOIST>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
-                           tm_global, bs, bin, meta, (int)blockIdx.x);
+                           tm_global, bs, bin, meta, (int)blockIdx.x, gpose, gvalid);
+}
+
+// =============================================================== U1 + U2, four features per wave (batch handles, max_len <= 16)
+// The relative-pose chain and the inverse-depth triangulation of feat_build_kernel are single-wave phases with one lane per observation:
+// at most 16 of 64 lanes work, and at B = 2048 the kernel is instruction-issue bound.  Here a wave carries FOUR features, one per 16-lane
+// DPP row (lane l of row g <-> observation l of feature 4 blockIdx.x + g): the same expressions in the same order per feature — the
+// row reductions are the DPP row rotations of row16_sum, the broadcasts come from the row's own lanes 0 / 1 —, so the results are those
+// of feat_build_kernel bit for bit; the rows iterate until the last one has converged (a converged row is frozen).  Output: the camera /
+// IMU poses of the chain (gpose[f][(L-1) x 24]), the triple (pfinv[f]) and the validity flag, which feat_build_kernel<4> then reads.
+__device__ __forceinline__ double row_bcast(double v, int src) { return __shfl(v, (int)((threadIdx.x & 48) + src), 64); }
+__device__ __forceinline__ double row16_sum_b(double v) {
+    v += dpp_f64<0x128>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x121>(v);
+    return row_bcast(v, 0);
+}
+#define GEOM4_ML 16
+__global__ __launch_bounds__(64) void geom4_kernel(DevCfg cfg, int n, const double* __restrict__ x, const int* __restrict__ n_feat_ptr,
+                                                   const unsigned char* __restrict__ types, const int* __restrict__ lens, const float* __restrict__ meas,
+                                                   double* __restrict__ gpose, double* __restrict__ pfinv_out, int* __restrict__ gvalid, size_t bs, BatchIn bin) {
+    const int z = blockIdx.z;
+    x = zoffi(x, bs, z); gpose = zoffi(gpose, bs, z); pfinv_out = zoffi(pfinv_out, bs, z); gvalid = zoffi(gvalid, bs, z);
+    n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, z); types = zoffi(types, bin.types, z); lens = zoffi(lens, bin.len, z); meas = zoffi(meas, bin.meas, z);
+    __shared__ double xcl[7 * (GEOM4_ML - 1)];
+    __shared__ double poses[4][(GEOM4_ML - 1) * 24];
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, ML = cfg.max_len;
+    const int n_feat = *n_feat_ptr;
+    if (4 * (int)blockIdx.x >= n_feat) return;                       // four empty slots
+    const int f = 4 * blockIdx.x + g;
+    unsigned char type = '1'; int L = 2;
+    bool active = f < n_feat;
+    if (active) { type = types[f]; L = lens[f]; }
+    if (L < 2 || L > ML || L - 1 > n || (type != '1' && type != '2')) { active = false; L = 2; }   // (feat_build_kernel drops such a track and says so)
+    const int nPh = L - 1;
+    float mxv = 0, myv = 0;
+    if (active && l < L) { const float* mz = meas + (size_t)f * ML * 2; mxv = mz[2 * l]; myv = mz[2 * l + 1]; }
+    for (int e = lane; e < 7 * n; e += 64) xcl[e] = x[26 + e];
+    const double sig = cfg.sigma_im, sig2 = sig * sig;
+    const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
+    const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
+    __syncthreads();
+    double* pose = poses[g];
+    // ---- U1 (feat_build_kernel, same expressions)
+    const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
+    if (active && l < nPh) {
+        const m33 Rl = q2r(ldq(rel + 7 * l));
+        double* o = pose + l * 24 + 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = Rl.m[k];
+    }
+    __syncthreads();
+    {
+        m33 RI = ldm33(pose + 12);
+        d3 tI = scl3(-1.0, mv33(RI, ld3(rel + 4)));
+        for (int i = 0; i < ML - 1; ++i) {
+            if (__builtin_amdgcn_readfirstlane(__any(active && i < nPh)) == 0) break;
+            if (active && i < nPh) {
+                if (i > 0) {
+                    const m33 Ri = ldm33(pose + i * 24 + 12);
+                    tI = mv33(Ri, sub3(tI, ld3(rel + 7 * i + 4)));
+                    RI = mul33(Ri, RI);
+                }
+                if (l == 0) {
+                    double* o = pose + i * 24;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) o[k] = RI.m[k];
+                    st3(o + 9, tI);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active && l < nPh) {
+        double* o = pose + l * 24;
+        const m33 RIl = ldm33(o);
+        const d3 tIl = ld3(o + 9);
+        const m33 RciRI = mul33(Rci, RIl);
+        const m33 Rc = mul33(RciRI, Ric);
+        const d3 tC = add3(add3(mv33(RciRI, tic), mv33(Rci, tIl)), tci);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[12 + k] = Rc.m[k];
+        st3(o + 21, tC);
+    }
+    __syncthreads();
+    // ---- U2 (feat_build_kernel, same expressions; lane l of the row <-> observation l)
+    const float fx0 = __shfl(mxv, lane & 48, 64), fy0 = __shfl(myv, lane & 48, 64);
+    double phi = atan2((double)fy0, sqrt((double)fx0 * (double)fx0 + 1));
+    double psi = atan2((double)fx0, 1.0);
+    double rho = 0;
+    bool valid = true;
+    if (fabs(phi) > .5 * 3.14 || fabs(psi) > .5 * 3.14) valid = false;
+    {
+        const bool act = active && l < L;
+        const float mx = mxv, my = myv;
+        m33 Rc = eye33(); d3 tc = mk3(0, 0, 0);
+        if (act && l > 0) { Rc = ldm33(pose + (l - 1) * 24 + 12); tc = ld3(pose + (l - 1) * 24 + 21); }
+        const double ri = 1. / sig2;
+        double lambda = 0.01, lastCost = INFINITY;
+        bool done = !(active && valid);
+        for (int it = 0; it < 10; ++it) {
+            if (__builtin_amdgcn_readfirstlane(__any(!done)) == 0) break;
+            double sv, cv;
+            sincos((l & 1) ? psi : phi, &sv, &cv);
+            const double sph = row_bcast(sv, 0), cph = row_bcast(cv, 0), sps = row_bcast(sv, 1), cps = row_bcast(cv, 1);
+            const d3 ep = mk3(cph * sps, sph, cph * cps);
+            const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
+            double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0, cost = 0;
+            if (act) {
+                d3 h = (l == 0) ? ep : add3(mv33(Rc, ep), scl3(rho, tc));
+                const double iz = fast_rcp(h.z);
+                const double Hp0[3] = {iz, 0, -(h.x * iz) * iz}, Hp1[3] = {0, iz, -(h.y * iz) * iz};
+                double HR0[3], HR1[3];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    HR0[b] = Hp0[0] * Rc.m[b] + Hp0[1] * Rc.m[3 + b] + Hp0[2] * Rc.m[6 + b];
+                    HR1[b] = Hp1[0] * Rc.m[b] + Hp1[1] * Rc.m[3 + b] + Hp1[2] * Rc.m[6 + b];
+                }
+                double H0[3], H1[3];
+                H0[0] = HR0[0] * J00 + HR0[1] * J10 + HR0[2] * J20;
+                H0[1] = HR0[0] * J01 + HR0[2] * J21;
+                H1[0] = HR1[0] * J00 + HR1[1] * J10 + HR1[2] * J20;
+                H1[1] = HR1[0] * J01 + HR1[2] * J21;
+                if (l == 0) { H0[2] = 0; H1[2] = 0; }
+                else { H0[2] = Hp0[0] * tc.x + Hp0[2] * tc.z; H1[2] = Hp1[1] * tc.y + Hp1[2] * tc.z; }
+                const float px = (float)(h.x * iz), py = (float)(h.y * iz);
+                const double e0 = (double)(mx - px), e1 = (double)(my - py);
+                cost = (e0 * ri) * e0 + (e1 * ri) * e1;
+                c00 = (H0[0] * ri) * H0[0] + (H1[0] * ri) * H1[0];
+                c01 = (H0[0] * ri) * H0[1] + (H1[0] * ri) * H1[1];
+                c02 = (H0[0] * ri) * H0[2] + (H1[0] * ri) * H1[2];
+                c11 = (H0[1] * ri) * H0[1] + (H1[1] * ri) * H1[1];
+                c12 = (H0[1] * ri) * H0[2] + (H1[1] * ri) * H1[2];
+                c22 = (H0[2] * ri) * H0[2] + (H1[2] * ri) * H1[2];
+                g0 = (H0[0] * ri) * e0 + (H1[0] * ri) * e1;
+                g1 = (H0[1] * ri) * e0 + (H1[1] * ri) * e1;
+                g2 = (H0[2] * ri) * e0 + (H1[2] * ri) * e1;
+            }
+            cost = row16_sum_b(cost);
+            c00 = row16_sum_b(c00); c01 = row16_sum_b(c01); c02 = row16_sum_b(c02);
+            c11 = row16_sum_b(c11); c12 = row16_sum_b(c12); c22 = row16_sum_b(c22);
+            g0 = row16_sum_b(g0); g1 = row16_sum_b(g1); g2 = row16_sum_b(g2);
+            if (!done) {
+                if (cost <= lastCost) {
+                    const double a00 = c00 + lambda * c00, a11 = c11 + lambda * c11, a22 = c22 + lambda * c22;
+                    const double ptiny = 2.220446049250313e-16 * fmax(a00, fmax(a11, a22));
+                    const double i0 = a00 > ptiny ? fast_rcp(a00) : 0.0, l10 = c01 * i0, l20 = c02 * i0;
+                    const double dd1 = a11 - l10 * c01, i1 = dd1 > ptiny ? fast_rcp(dd1) : 0.0, l21 = (c12 - l20 * c01) * i1;
+                    const double dd2 = a22 - l20 * c02 - l21 * (c12 - l20 * c01), i2 = dd2 > ptiny ? fast_rcp(dd2) : 0.0;
+                    const double z0 = g0, z1 = g1 - l10 * z0, z2 = g2 - l20 * z0 - l21 * z1;
+                    const double d2 = z2 * i2, d1 = z1 * i1 - l21 * d2, d0 = z0 * i0 - l10 * d1 - l20 * d2;
+                    phi += d0; psi += d1; rho += d2;
+                    if (fabs(lastCost - cost) < 1e-6 && d2 < 1e-6) done = true;
+                    else { lambda *= .1; lastCost = cost; }
+                } else { lambda *= 10; lastCost = cost; }
+            }
+        }
+        if (valid && (fabs(phi) > .5 * 3.14 || fabs(psi) > .5 * 3.14 || isinf(rho) || rho < 0 || isnan(rho) || isnan(phi) || isnan(psi))) valid = false;
+    }
+    if (active) {
+        if (l == 0) { pfinv_out[3 * f] = phi; pfinv_out[3 * f + 1] = psi; pfinv_out[3 * f + 2] = rho; gvalid[f] = valid ? 1 : 0; }
+        double* gp = gpose + (size_t)f * (ML - 1) * 24;
+        for (int e = l; e < nPh * 24; e += 16) gp[e] = pose[e];
+    }
 }
 
 // =============================================================== U7 compression, information form (reduction stage)

@@ -58,6 +58,8 @@ struct rvio_hip {
     double *partial = nullptr, *block = nullptr, *Ab = nullptr, *Tbuf = nullptr, *W = nullptr, *Mg = nullptr, *U = nullptr, *G = nullptr,
            *Pt1 = nullptr, *tm_global = nullptr, *gamma = nullptr, *pfinv = nullptr;
     int *nrows = nullptr, *acc = nullptr, *ndof = nullptr, *gram_cnt = nullptr;
+    double* gpose = nullptr;   // batch handles (max_len <= 16): the pose chains geom4_kernel leaves for feat_build_kernel<4>, [Fu][(max_len-1) x 24]
+    int* gvalid = nullptr;     // ... and the validity flag of each triangulation
     size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
     int feat_threads = 64;
     size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
@@ -292,6 +294,8 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
     DALLOC(h, t.n_feat, 1); DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
     if (need_tm_global) DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
+    static const bool no_geom4 = getenv("RVIO_NO_GEOM4") != nullptr;   // A/B timing
+    if (h->batch > 1 && d.max_len <= GEOM4_ML && !no_geom4) { DALLOC(h, h->gpose, (size_t)d.Fu * (d.max_len - 1) * 24); DALLOC(h, h->gvalid, d.Fu); }
     if (need_Mg) DALLOC(h, h->Mg, ldh * 2 * ldh);
     return RVIO_OK;
 }
@@ -758,11 +762,15 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     if (B == 1)   // one stream: the latency form (every operand load of a gate tile in flight at once)
     hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global, bs, h->bin, h->meta);
-    else
+                       h->tm_global, bs, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr);
+    else {
+    if (h->gpose)   // U1 + U2 four features per wave, ahead of the per-feature kernel (which then only fetches the pose chain and the triple)
+        hipLaunchKernelGGL(geom4_kernel, dim3((d.Fu + 3) / 4, 1, B), dim3(64), 0, h->stream, d, n, h->x[h->cur], h->t.n_feat, h->t.types, h->t.len, h->t.meas,
+                           h->gpose, h->pfinv, h->gvalid, bs, h->bin);
     hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global, bs, h->bin, h->meta);
+                       h->tm_global, bs, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid);
+    }
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
     // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
     const int gram_chunk = (B == 1) ? 64 : 256;
@@ -1691,11 +1699,11 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             if (h->batch == 1)
             hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
-                               h->slab_bytes, h->bin, h->meta);
+                               h->slab_bytes, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr);
             else
             hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
-                               h->slab_bytes, h->bin, h->meta);
+                               h->slab_bytes, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid);
         } else if (which == 3 && h->batch >= 128 && h->gram_batch_lds) {
             hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, h->batch), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block,
                                h->slab_bytes, h->bin);
