@@ -708,13 +708,14 @@ static int ensure_imu_capacity(rvio_hip* h, int m) {
     h->imu_cap = cap;
     return RVIO_OK;
 }
-static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0) {   // imu_bs = 0: every instance integrates the same samples
+static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0, hipStream_t st = nullptr) {   // imu_bs = 0: every instance integrates the same samples
     static const bool prop_b = getenv("RVIO_NO_PROP_B") == nullptr;   // A/B timing
+    if (!st) st = h->stream;
     if (h->batch > 8 && prop_b)
-        hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
+        hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                            h->slab_bytes, imu_bs);
     else
-    hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, h->stream, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
+    hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                        h->slab_bytes, imu_bs);
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -1335,15 +1336,29 @@ int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride
     HIPCHK(h, hipSetDevice(h->device));
     const DevCfg& d = h->dc;
     h->img_count++;
-    int rc = propagate_dev(h, d_imu, m, (size_t)imu_stride * sizeof(rvio_imu));
+    const bool upd = h->n_clones_host > h->cfg.min_track_len - 1;   // System.cc:266
+    // A filter-only batch: PreIntegrator::propagate (one latency-bound workgroup per instance, two per CU) runs on the handle's second stream
+    // BESIDE the per-feature stage of the update — U1-U5 and the share reduction read only the clone states and P[24:,24:], which propagation does
+    // not touch (the reason feat_prop_kernel may fuse them for one stream) — and joins in front of the solve, which needs the propagated rows.
+    static const bool no_overlap = getenv("RVIO_NO_PROP_OVERLAP") != nullptr;   // A/B timing
+    const bool overlap = upd && h->batch > 1 && !h->front_end && !h->one_stream && !no_overlap;
+    int rc;
+    if (overlap) {
+        HIPCHK(h, hipEventRecord(h->evD0, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_t, h->evD0, 0));
+        rc = propagate_dev(h, d_imu, m, (size_t)imu_stride * sizeof(rvio_imu), h->stream_t);
+        HIPCHK(h, hipEventRecord(h->evD1, h->stream_t));
+    } else rc = propagate_dev(h, d_imu, m, (size_t)imu_stride * sizeof(rvio_imu));
     if (rc != RVIO_OK) return rc;
-    if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
+    if (upd) {
         const TrackerDev t0 = h->t;
         const BatchIn b0 = h->bin;
         h->t.n_feat = const_cast<int*>(d_n_feat); h->t.types = const_cast<unsigned char*>(d_types);
         h->t.len = const_cast<int*>(d_len); h->t.meas = const_cast<float*>(d_meas);
         h->bin = {0, sizeof(int32_t), (size_t)d.Fu, sizeof(int32_t) * (size_t)d.Fu, sizeof(float) * 2 * (size_t)d.Fu * d.max_len};
-        rc = rvio_hip_update_tracked(h);
+        rc = update_local_dev(h, 0, 1, true);
+        if (overlap) HIPCHK(h, hipStreamWaitEvent(h->stream, h->evD1, 0));
+        if (rc == RVIO_OK) rc = update_global_dev(h, h->block, 1, true);
         h->t = t0; h->bin = b0;
         if (rc != RVIO_OK) return rc;
     }
