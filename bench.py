@@ -373,7 +373,7 @@ def main():
         if args.batch_streams:
             safe_leg(out, "batched_streams", batched_streams_leg, cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
         if args.batch:
-            safe_leg(out, "batched_filter", batched_filter_leg, cfg, torch, [int(b) for b in args.batch.split(",") if b], name=args.config)
+            safe_leg(out, "batched_filter", batched_filter_leg, cfg, torch, [b for b in args.batch.split(",") if b], name=args.config)
         if not args.no_cpu:
             _CFG_NAME[0] = args.config
             try:
@@ -708,7 +708,8 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
     w_frame = float(np.mean(flops[n_warm:]))
     PEAK_F64 = 78.6
     res = []
-    for B in sizes:
+    for size in sizes:
+        B, nh = (int(v) for v in str(size).split("x")) if "x" in str(size) else (int(size), 1)   # "2048x2": two handles of 1024 instances, both in flight
         idx = np.arange(B) % seeds
         # [frame][instance] tables, resident in HBM before the timed region
         d_nf = torch.from_numpy(np.stack([tabs[i][0] for i in idx], 1).copy()).cuda()
@@ -717,32 +718,42 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
         d_me = torch.from_numpy(np.stack([tabs[i][3] for i in idx], 1).copy()).cuda()
         imu_h = np.stack([tabs[i][4][:, :m] for i in idx], 1).copy()            # [frame][instance][m]
         d_im = torch.from_numpy(imu_h.view(np.uint8).reshape(nf, B, -1)).cuda()
-        h = hip.RvioHip(cfg, batch=B)
-        h.set_state(*inits[0])
-        for b in range(B):
-            if idx[b] != 0:
-                h.set_state_at(b, *inits[idx[b]])
+        per = B // nh
+        assert per * nh == B
+        hs = [hip.RvioHip(cfg, batch=per) for _ in range(nh)]
+        for k, h in enumerate(hs):
+            h.set_state(*inits[idx[k * per]])
+            for b in range(per):
+                if idx[k * per + b] != idx[k * per]:
+                    h.set_state_at(b, *inits[idx[k * per + b]])
         torch.cuda.synchronize()
 
-        def frame(f):
-            h.frame_tracks_dev(d_im[f].data_ptr(), m, m, d_nf[f].data_ptr(), d_ty[f].data_ptr(), d_ln[f].data_ptr(), d_me[f].data_ptr())
+        def frame(f):       # the calls only enqueue: with several handles their chains run side by side on the device
+            for k, h in enumerate(hs):
+                a = k * per
+                h.frame_tracks_dev(d_im[f, a].data_ptr(), m, m, d_nf[f, a:].data_ptr(), d_ty[f, a].data_ptr(), d_ln[f, a].data_ptr(), d_me[f, a].data_ptr())
+
+        def sync():
+            for h in hs:
+                h.sync()
         for f in range(n_warm):
             frame(f)
-        h.sync()
+        sync()
         if barrier is not None:
             barrier()
         t0 = time.perf_counter()
         for f in range(n_warm, nf):
             frame(f)
-        h.sync()
+        sync()
         if barrier is not None:
             barrier()
         el = time.perf_counter() - t0
-        x_last = h.get_state_at(B - 1)[0]
-        h.close()
+        x_last = hs[-1].get_state_at(per - 1)[0]
+        for h in hs:
+            h.close()
         del d_nf, d_ty, d_ln, d_me, d_im
         tfl = w_frame * B * n_timed / el / 1e12
-        res.append({"instances": B, "ms_per_batched_frame": 1e3 * el / n_timed, "filter_frames_per_s": B * n_timed / el,
+        res.append({"instances": B, "handles": nh, "ms_per_batched_frame": 1e3 * el / n_timed, "filter_frames_per_s": B * n_timed / el,
                     "achieved_tflops_fp64": tfl, "frac_fp64_peak": tfl / PEAK_F64, "finite": bool(np.all(np.isfinite(x_last)))})
     return {"workload": "cfg%s filter only (propagate + update + augment/compose), direct-track hand-over tables of %d seeded sequences, "
                         "%d frames timed after %d, one launch per stage for all instances" % (name, seeds, n_timed, n_warm),
@@ -769,7 +780,8 @@ def batched_streams_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=12, n_timed
     it_l = 10
     by_klt = npx * (1 + 2 * (1 / 4 + 1 / 16 + 1 / 64)) + cfg.n_features * 4 * (16 * 16 * 5) + cfg.n_features * 4 * it_l * 16 * 16   # B_klt, SURVEY.md 8d
     res = []
-    for B in sizes:
+    for size in sizes:
+        B, nh = (int(v) for v in str(size).split("x")) if "x" in str(size) else (int(size), 1)   # "2048x2": two handles of 1024 instances, both in flight
         idx = np.arange(B) % seeds
         h = hip.RvioHip(cfg, batch=B, front_end=True)
         h.set_state(*inits[0])

@@ -1162,10 +1162,12 @@ __global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double
         for (int r = 0; r < 4; ++r) {
             const int row = lk + 4 * r;
             Us[row * lds + jt * 16 + li] = acc[r];
-            if (i0 + row < d && bj < c6) U[(size_t)(i0 + row) * ldh + bj] = acc[r];
         }
     }
     __syncthreads();
+    // U^T (k-major, leading dimension ld: UT[k][i] = U[i][k]) from the LDS strip — final_kernel reads U and G with the row index along the
+    // lanes, which a row-major U made 64 scattered 8-byte loads per instruction; 16 consecutive rows of one k are one 128-byte segment
+    for (int e = threadIdx.x; e < c6 * 16; e += 256) { const int k = e >> 4, r = e & 15; if (i0 + r < d) U[(size_t)k * ld + i0 + r] = Us[r * lds + k]; }
     // G strip: A = Us[i][k], B = A[k][j] (Ab row-major; A is symmetric)
     for (int jt = wave; jt < c6t; jt += 4) {
         const int bj = jt * 16 + li; const bool bok = bj < c6;
@@ -1185,10 +1187,10 @@ __global__ __launch_bounds__(256) void ug_kernel(DevCfg cfg, int n, const double
         for (int r = 0; r < 4; ++r) {
             const int row = lk + 4 * r;
             Gs[row * lds + jt * 16 + li] = acc[r];
-            if (i0 + row < d && bj < c6) G[(size_t)(i0 + row) * ldh + bj] = acc[r];
         }
     }
     __syncthreads();
+    for (int e = threadIdx.x; e < c6 * 16; e += 256) { const int k = e >> 4, r = e & 15; if (i0 + r < d) G[(size_t)k * ld + i0 + r] = Gs[r * lds + k]; }
     // P1 strip = P - G Pc^T: A = Gs[i][k], B[k][j] = Pc[j][k] = P[j + (24+k) ld]
     for (int jt = wave; jt < dt; jt += 4) {
         const int bj = jt * 16 + li; const bool bok = bj < d;
@@ -1227,9 +1229,9 @@ __device__ __forceinline__ d4 final_tile(const double* P1, const double* G, cons
             const int k = k0 + 4 * u + lk;
             const bool kok = k < c6;
             a1[u] = (aok && kok) ? P1[(size_t)ai + (size_t)(24 + k) * ld] : 0.0;   // P1c[i][k]
-            b1[u] = (bok && kok) ? G[(size_t)bj * ldh + k] : 0.0;                  // G[j][k]
-            a2[u] = (aok && kok) ? G[(size_t)ai * ldh + k] : 0.0;                  // G[i][k]
-            b2[u] = (bok && kok) ? U[(size_t)bj * ldh + k] : 0.0;                  // U[j][k]
+            b1[u] = (bok && kok) ? G[(size_t)k * ld + bj] : 0.0;                   // G[j][k]  (G and U are stored k-major by ug_kernel)
+            a2[u] = (aok && kok) ? G[(size_t)k * ld + ai] : 0.0;                   // G[i][k]
+            b2[u] = (bok && kok) ? U[(size_t)k * ld + bj] : 0.0;                   // U[j][k]
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1274,6 +1276,197 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
         if (row < d && col < d) {
             Pout[(size_t)row + (size_t)col * ld] = v;
             if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+        }
+    }
+}
+
+// =============================================================== batch handles, 6n <= 60: U, G, P1 and the Joseph form in ONE kernel
+// ug_kernel + final_kernel move P1, U and G through HBM / L2 between them and fetch every MFMA operand from global memory inside the k-loop (at B = 2048:
+// 0.55 ms of the 1.94 ms batched frame for 125 us of matrix-core work).  Here ONE workgroup of JB_WAVES waves owns an instance from P to P+: W (then A), Pc,
+// U, G live in LDS (row-major, leading dimension 6n + 1), the tiles of P (then P1) stay in the registers of the wave that needs them again — fetched with the
+// kernel's first loads, long before their use —, P1c takes Pc's place once every tile of P1 exists.  The operands, the order of the MFMAs inside a tile and
+// the closing expressions are those of ug_kernel / final_kernel, so the result is theirs.  LDS: (3 d + 6n)(6n + 1) doubles = 152 KB at 6n = 60 — one
+// workgroup per CU, 8 instances per CU at B = 2048.
+#ifndef JB_WAVES
+#define JB_WAVES 12
+#endif
+#define JB_THREADS (64 * JB_WAVES)
+#define JB_PAIRS ((21 + JB_WAVES - 1) / JB_WAVES)            /* tile pairs of P per wave (nt <= 6: at most 21) */
+#define JB_NWA ((60 * 60 + JB_THREADS - 1) / JB_THREADS)     /* elements of W / A per thread */
+#define JB_NPC ((60 * 84 + JB_THREADS - 1) / JB_THREADS)     /* elements of Pc per thread */
+#define JB_TL_DOUBLES (JB_WAVES * 16 * 17)
+__global__ __launch_bounds__(JB_THREADS) void joseph_batch_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W,
+                                                                   const double* __restrict__ Ab, double* __restrict__ Pout, size_t bs) {
+    extern __shared__ __align__(16) double jl[];
+    const int z = blockIdx.z;          // (grid (1, 1, B) like every batch kernel) nothing is shared between instances: the round-robin of workgroups over the XCDs is the mapping wanted
+    P = zoffi(P, bs, z); W = zoffi(W, bs, z); Ab = zoffi(Ab, bs, z); Pout = zoffi(Pout, bs, z);
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, LS = c6 + 1;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    double* const R0 = jl;                 // Pc[r][k] = P[r][24 + k], r < d;  later P1c[r][k]
+    double* const R1 = R0 + d * LS;        // U[r][k]
+    double* const R2 = R1 + d * LS;        // G[r][k]
+    double* const R3 = R2 + d * LS;        // W[k][j], then A[k][j], then the waves' transposition tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    // the unordered tile pairs (I <= J) of P: pair wave + JB_WAVES s belongs to this wave in the P1 stage and in the closing stage
+    const int nt = (d + 15) / 16, npair = nt * (nt + 1) / 2;
+    int pi[JB_PAIRS], pj[JB_PAIRS];
+    d4 pa[JB_PAIRS], pb[JB_PAIRS];         // tile (I, J) and tile (J, I) of P, then of P1
+#pragma unroll
+    for (int s = 0; s < JB_PAIRS; ++s) {
+        int I = 0, rem = wave + JB_WAVES * s;
+        if (rem < npair) while (rem >= nt - I) { rem -= nt - I; ++I; }
+        pi[s] = I; pj[s] = I + rem;
+    }
+    // rows i0 .. i0+15 of an LDS matrix as MFMA operand (A: [i][k]; B of X Y^T: [k][j] = Y[j][k]), k = 32 h .. 32 h + 31
+    auto rows8 = [&](const double* R, int i0, int h, double (&v)[8]) {
+        const int r = i0 + li;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = 32 * h + 4 * u + lk; v[u] = (r < d && k < c6) ? R[r * LS + k] : 0.0; }
+    };
+    // columns j0 .. j0+15 of W / A (row-major [k][j], 6n columns) as B operand
+    auto cols8 = [&](const double* R, int j0, int h, double (&v)[8]) {
+        const int c = j0 + li;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = 32 * h + 4 * u + lk; v[u] = (c < c6 && k < c6) ? R[k * LS + c] : 0.0; }
+    };
+    {
+        double vw[JB_NWA], va[JB_NWA], vp[JB_NPC];
+#pragma unroll
+        for (int u = 0; u < JB_NWA; ++u) {
+            const int e = tid + u * JB_THREADS, k = e / c6, j = e - k * c6;
+            const bool ok = k < c6;
+            vw[u] = ok ? W[(size_t)k * ldh + j] : 0.0;
+            va[u] = ok ? Ab[(size_t)k * ldh + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < JB_NPC; ++u) {      // column-major source: consecutive threads walk down a column of P
+            const int e = tid + u * JB_THREADS, k = e / d, r = e - k * d;
+            vp[u] = (k < c6) ? P[(size_t)r + (size_t)(24 + k) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < JB_PAIRS; ++s) {    // the wave's tiles of P, needed in the third stage: in flight from here
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = wave + JB_WAVES * s < npair;
+                { const int row = pi[s] * 16 + lk + 4 * q, c = pj[s] * 16 + li; pa[s][q] = (on && row < d && c < d) ? P[(size_t)row + (size_t)c * ld] : 0.0; }
+                { const int row = pj[s] * 16 + lk + 4 * q, c = pi[s] * 16 + li; pb[s][q] = (on && row < d && c < d) ? P[(size_t)row + (size_t)c * ld] : 0.0; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < JB_NWA; ++u) { const int e = tid + u * JB_THREADS, k = e / c6, j = e - k * c6; if (k < c6) R3[k * LS + j] = vw[u]; }
+#pragma unroll
+        for (int u = 0; u < JB_NPC; ++u) { const int e = tid + u * JB_THREADS, k = e / d, r = e - k * d; if (k < c6) R0[r * LS + k] = vp[u]; }
+        __syncthreads();
+        const int ntj = (c6 + 15) / 16, ntile = nt * ntj;
+        // U = Pc W
+#pragma unroll 1
+        for (int t = wave; t < ntile; t += JB_WAVES) {
+            const int it = t / ntj, jt = t - it * ntj, i0 = it * 16, c = jt * 16 + li;
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double av[8], bv[8];
+                rows8(R0, i0, h, av); cols8(R3, jt * 16, h, bv);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = i0 + lk + 4 * q; if (row < d && c < c6) R1[row * LS + c] = acc[q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < JB_NWA; ++u) { const int e = tid + u * JB_THREADS, k = e / c6, j = e - k * c6; if (k < c6) R3[k * LS + j] = va[u]; }
+        __syncthreads();
+        // G = U A
+#pragma unroll 1
+        for (int t = wave; t < ntile; t += JB_WAVES) {
+            const int it = t / ntj, jt = t - it * ntj, i0 = it * 16, c = jt * 16 + li;
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double av[8], bv[8];
+                rows8(R1, i0, h, av); cols8(R3, jt * 16, h, bv);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = i0 + lk + 4 * q; if (row < d && c < c6) R2[row * LS + c] = acc[q]; }
+        }
+        __syncthreads();
+    }
+    // X Y^T, tile (i0, j0): rows i0.. of X times rows j0.. of Y
+    auto xyT = [&](const double* X, int i0, const double* Y, int j0) -> d4 {
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double av[8], bv[8];
+            rows8(X, i0, h, av); rows8(Y, j0, h, bv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // P1 = P - G Pc^T
+#pragma unroll
+    for (int s = 0; s < JB_PAIRS; ++s) {
+        if (wave + JB_WAVES * s < npair) {
+            const int I = pi[s], J = pj[s];
+            const d4 acc = xyT(R2, I * 16, R0, J * 16);
+            if (I != J) {
+                const d4 acc2 = xyT(R2, J * 16, R0, I * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pb[s][q] = pb[s][q] - acc2[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pa[s][q] = pa[s][q] - acc[q];
+            if (I == J) pb[s] = pa[s];
+        }
+    }
+    __syncthreads();            // every read of Pc is done: P1c = P1[:, 24:] takes its place
+#pragma unroll
+    for (int s = 0; s < JB_PAIRS; ++s) {
+        if (wave + JB_WAVES * s < npair) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                { const int row = pi[s] * 16 + lk + 4 * q, c = pj[s] * 16 + li; if (row < d && c < d && c >= 24) R0[row * LS + c - 24] = pa[s][q]; }
+                if (pi[s] != pj[s]) { const int row = pj[s] * 16 + lk + 4 * q, c = pi[s] * 16 + li; if (row < d && c < d && c >= 24) R0[row * LS + c - 24] = pb[s][q]; }
+            }
+        }
+    }
+    __syncthreads();
+    // X = P1 - P1c G^T + s2 G U^T per tile;  P+ = .5 (X + X^T)
+    double* const tl = R3 + wave * (16 * 17);
+#pragma unroll
+    for (int s = 0; s < JB_PAIRS; ++s) {
+        if (wave + JB_WAVES * s < npair) {
+            const int I = pi[s], J = pj[s];
+            d4 xij, xji;
+            {
+                const d4 acc = xyT(R0, I * 16, R2, J * 16);               // P1c_I G_J^T
+                const d4 acc2 = xyT(R2, I * 16, R1, J * 16);              // G_I U_J^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xij[q] = pa[s][q] - acc[q] + s2 * acc2[q];
+            }
+            xji = xij;
+            if (I != J) {
+                const d4 acc = xyT(R0, J * 16, R2, I * 16);               // P1c_J G_I^T
+                const d4 acc2 = xyT(R2, J * 16, R1, I * 16);              // G_J U_I^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xji[q] = pb[s][q] - acc[q] + s2 * acc2[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl[(lk + 4 * q) * 17 + li] = xji[q];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = lk + 4 * q, row = I * 16 + rr, col = J * 16 + li;
+                const double v = .5 * (xij[q] + tl[li * 17 + rr]);     // X_JI[col_local][row_local]
+                if (row < d && col < d) {
+                    Pout[(size_t)row + (size_t)col * ld] = v;
+                    if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -62,7 +62,7 @@ struct rvio_hip {
     int* gvalid = nullptr;     // ... and the validity flag of each triangulation
     size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
     int feat_threads = 64;
-    size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0;
+    size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
@@ -523,6 +523,12 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             }
         }
         const size_t c6t = (c6m + 15) / 16;
+        if (batch >= 128 && c6m <= 60 && !getenv("RVIO_NO_JOSEPH_FUSED")) {   // the Joseph form of a batch handle in one kernel, one workgroup per instance
+            const size_t ls = c6m + 1, dmx = 24 + c6m;
+            h->jb_lds = (3 * dmx * ls + std::max((size_t)c6m * ls, (size_t)JB_TL_DOUBLES)) * sizeof(double);
+            if (h->jb_lds > 160 * 1024) h->jb_lds = 0;
+            else HIPCHK(h, hipFuncSetAttribute((const void*)joseph_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->jb_lds));
+        }
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UGL_LDS_DOUBLES * sizeof(double))));
@@ -834,7 +840,9 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     double* Pc = h->P[h->cur];
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
     static const bool no_ugl = getenv("RVIO_NO_UGL") != nullptr;   // A/B timing
-    if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
+    if (h->jb_lds && ug && fin) {   // batch handle, 6n <= 60: P -> P+ in one kernel (U, G, P1 never leave the CU)
+        hipLaunchKernelGGL(joseph_batch_kernel, dim3(1, 1, B), dim3(JB_THREADS), h->jb_lds, h->stream, d, n, Pc, h->W, Ab, Pn, bs);
+    } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
         if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
         if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
     } else {
