@@ -7,8 +7,9 @@
 //                        measurement compression (Updater.cc:469-536) in information form [A|b] = Hw^T [Hw | r], with the
 //                        reference's rank truncation (Updater.cc:516-529) in its structural form   
 //   gemm_T_kernel        FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
-//   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG)
+//   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG; U, G stored k-major for final_kernel)
 //   final_kernel         P+ = sym( P1 - P1c G^T + s2 G U^T )   (Joseph form, Updater.cc:615-619)
+//   joseph_batch_kernel  both stages for a batch handle (>= 128 instances, 6n <= 60): one workgroup per instance from P to P+, U / G / P1c in LDS
 //   ug_lds_kernel, final_lds_kernel
 //                        the same two stages for ONE instance with 6n <= 64: every operand of a workgroup staged in LDS by one batch of loads
 // (propagate / augmentation + composition: filter_kernels2.hip; T, W = T^-1, dx, state injection: solve7.hip — solve6.hip / solve4.hip behind

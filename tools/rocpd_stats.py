@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max (us).
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / median / min / max (us).  (The median is the figure to
+quote for a kernel whose first launch carries a one-off of several ms — code object load, LDS re-partition —, which the average does not hide.)
 usage: tools/rocpd_stats.py results.db [out.md] [--grid-z N]   (--grid-z: only dispatches whose grid has N workgroups/items in z,
 e.g. the launches of a batch handle)"""
 import re
@@ -27,13 +28,13 @@ rows = cur.execute("select %s, start, end from kernels%s" % (name_col, where)).f
 agg = {}
 for name, s, e in rows:
     name = re.sub(r"\(.*", "", name)
-    a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
+    a = agg.setdefault(name, [0, 0.0, 1e30, 0.0, []])
     d = (e - s) / 1e3
-    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d); a[4].append(d)
 tot = sum(a[1] for a in agg.values())
-lines = ["| kernel | calls | total us | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+lines = ["| kernel | calls | total us | avg us | median us | min us | max us | % |", "|---|---|---|---|---|---|---|---|"]
 for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    lines.append("| %s | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % (name, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / tot))
+    lines.append("| %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %.1f |" % (name, a[0], a[1], a[1] / a[0], sorted(a[4])[len(a[4]) // 2], a[2], a[3], 100 * a[1] / tot))
 txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 2:
