@@ -958,6 +958,7 @@ __host__ __device__ inline size_t gram_batch_lds_doubles(int max_len, int ldh) {
     const size_t a = (size_t)(ldh - 1) * ldh, t = trunc_lds_doubles(max_len);
     return a > t ? a : t;
 }
+template <int NT>      // row / column tiles of [A|b]: 4 for 6n <= 63, 6 for 6n <= 95
 __global__ __launch_bounds__(256) void gram_reduce_batch_kernel(DevCfg cfg, int n, const double* __restrict__ partial, const int* __restrict__ nrows,
                                                                 const unsigned char* __restrict__ types, const int* __restrict__ lens, double* __restrict__ block,
                                                                 size_t bs, BatchIn bin) {
@@ -1012,27 +1013,37 @@ __global__ __launch_bounds__(256) void gram_reduce_batch_kernel(DevCfg cfg, int 
     const int r = tid >> 4, c = tid & 15, trq = c6 >> 4;
     // pass 0: every feature (direct) or the type-'2' features (candidate); pass 1 (candidate only): the type-'1' features
     for (int pass = 0; pass < (cand ? 2 : 1); ++pass) {
-        for (int e = tid; e < total; e += 256) acc[e] = 0.0;
-        __syncthreads();
+        // the thread's element of each of the NT (NT + 1) / 2 tiles on and above the diagonal, in registers: a feature's stored tiles are ALL in flight at once
+        // (an LDS sum behind chunks of 8 tile slots had 7 + 3 loads in flight for a full-window feature, and a read-modify-write of LDS per slot)
+        double a[NT * (NT + 1) / 2];
+#pragma unroll
+        for (int ti = 0; ti < NT * (NT + 1) / 2; ++ti) a[ti] = 0.0;
+#pragma unroll 2
         for (int t = 0; t < ng; ++t) {
             const int fl = s_list[t];
             if (cand && (((fl >> 30) & 1) != (pass == 0))) continue;
             const double* sh = partial + (size_t)(fl & 0xffff) * gs;
-            const int t0 = (fl >> 16) & 15, t1 = (fl >> 20) & 15, nts = t1 - t0 + 1, nq = nts + ((trq > t1) ? 1 : 0);
-            // the feature's stored tiles, up to 8 loads in flight per thread
-            for (int tb = 0; tb < nts * nq; tb += 8) {
-                double v[8]; int eo[8];
+            const int t0 = (fl >> 16) & 15, t1 = (fl >> 20) & 15;
+            int ti = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int tile = tb + u;
-                    const int pt = t0 + tile / nq, qi = tile % nq, qt = (qi < nts) ? t0 + qi : trq;
+            for (int pt = 0; pt < NT; ++pt) {
+#pragma unroll
+                for (int qt = pt; qt < NT; ++qt, ++ti) {
                     const int pp = 16 * pt + r, qq = 16 * qt + c;
-                    const bool on = tile < nts * nq && qt >= pt && pp < c6 && qq <= c6;
-                    eo[u] = on ? pp * ldh + qq : -1;
-                    v[u] = on ? sh[(size_t)pp * ldh + qq] : 0.0;
+                    const bool on = pt >= t0 && pt <= t1 && ((qt >= t0 && qt <= t1) || qt == trq) && pp < c6 && qq <= c6;
+                    a[ti] += on ? sh[(size_t)pp * ldh + qq] : 0.0;      // (+ 0.0 leaves the sum as it is)
                 }
+            }
+        }
+        {
+            int ti = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (eo[u] >= 0) acc[eo[u]] += v[u];
+            for (int pt = 0; pt < NT; ++pt) {
+#pragma unroll
+                for (int qt = pt; qt < NT; ++qt, ++ti) {
+                    const int pp = 16 * pt + r, qq = 16 * qt + c;
+                    if (pp < c6 && qq <= c6) acc[pp * ldh + qq] = a[ti];
+                }
             }
         }
         __syncthreads();

@@ -482,7 +482,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     if (batch > 1 && gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double) <= 64 * 1024) {
         h->gram_batch_lds = gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double);
-        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
+        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
+        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
     h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
@@ -755,6 +756,15 @@ static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
     return RVIO_OK;
 }
 
+// the share reduction of a batch handle whose [A|b] fits in LDS (6n <= 90): tiles of 16, 4 x 4 up to 6n = 63, 6 x 6 beyond
+static void launch_gram_batch(rvio_hip* h, int n) {
+    const dim3 g(1, 1, h->batch), b(256);
+    if (h->dc.ldh - 1 <= 63)
+        hipLaunchKernelGGL(gram_reduce_batch_kernel<4>, g, b, h->gram_batch_lds, h->stream, h->dc, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, h->slab_bytes, h->bin);
+    else
+        hipLaunchKernelGGL(gram_reduce_batch_kernel<6>, g, b, h->gram_batch_lds, h->stream, h->dc, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, h->slab_bytes, h->bin);
+}
+
 static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host;
@@ -783,7 +793,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const int gram_chunk = (B == 1) ? 64 : 256;
     static const bool no_gram_batch = getenv("RVIO_NO_GRAM_BATCH") != nullptr;   // A/B timing
     if (B >= 128 && world == 1 && combine && h->gram_batch_lds && !no_gram_batch)   // batch handle, [A|b] fits in LDS: one workgroup per instance, stored tiles only
-        hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, B), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, bs, h->bin);
+        launch_gram_batch(h, n);
     else
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + gram_chunk - 1) / gram_chunk)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
                        h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, (B == 1) ? 1 : 0, bs, h->bin);
@@ -1728,8 +1738,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
                                h->slab_bytes, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid);
         } else if (which == 3 && h->batch >= 128 && h->gram_batch_lds) {
-            hipLaunchKernelGGL(gram_reduce_batch_kernel, dim3(1, 1, h->batch), dim3(256), h->gram_batch_lds, h->stream, d, n, h->partial, h->nrows, h->t.types, h->t.len, h->block,
-                               h->slab_bytes, h->bin);
+            launch_gram_batch(h, n);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
             hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + (h->batch == 1 ? 63 : 255)) / (h->batch == 1 ? 64 : 256))), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
                                h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);

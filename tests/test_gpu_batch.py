@@ -285,21 +285,23 @@ def test_one_update_batch_vs_plain_is_rounding_only(gpu_required, recs3, B):
     assert n >= 6 and worst_x <= 1e-13 and worst_p <= 1e-13, (n, worst_x, worst_p)
 
 
-@pytest.mark.parametrize("name,frames", [("A", 30), ("E", 44)])
-def test_batch_handles_cover_the_long_windows(gpu_required, name, frames):
+@pytest.mark.parametrize("name,frames,B", [("A", 30, 2), ("E", 44, 2), ("A", 30, 128)], ids=["A-30", "E-44", "A-30-128-instances"])
+def test_batch_handles_cover_the_long_windows(gpu_required, name, frames, B):
     """cfg A (the stock 14-clone window) and cfg E (config 5 of BASELINE.json: 1600 features / 30 clones, 6n = 180): the instance-sharded
     fleet — the multi-GPU mode that scales — needs batch handles at these windows too.  Two differently seeded instances behind one handle
-    against the recorded oracle states and against plain handles."""
+    against the recorded oracle states and against plain handles.  (128 instances at cfg A: the large-batch forms at a window of 6 x 6 tiles —
+    gram_reduce_batch_kernel<6>, the fat augmentation workgroups; the k-loop Joseph kernels, 6n = 84 being beyond joseph_batch_kernel.)"""
     from rvio_amd import hip
     import torch
     cfg = abi.config_named(name, enable_equalizer=0)
-    recs = [S.record_sequence(cfg, n_frames=frames, seed=s, duration=5.0)[1] for s in (0, 1)]
-    B = 2
+    n_seq = 2
+    recs = spread([S.record_sequence(cfg, n_frames=frames, seed=s, duration=5.0)[1] for s in range(n_seq)], B)
     hb = hip.RvioHip(cfg, batch=B)
-    hs = [hip.RvioHip(cfg) for _ in range(B)]
+    hs = [hip.RvioHip(cfg) for _ in range(n_seq)]
     hb.set_state(recs[0][0]["x0"], recs[0][0]["P0"])
     for i in range(B):
         hb.set_state_at(i, recs[i][0]["x0"], recs[i][0]["P0"])
+    for i in range(n_seq):
         hs[i].set_state(recs[i][0]["x0"], recs[i][0]["P0"])
     n_upd = 0
     for f in range(frames):
@@ -308,7 +310,7 @@ def test_batch_handles_cover_the_long_windows(gpu_required, name, frames):
         d = [torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda() for a in (imu, n_feat, types, lens, meas)]
         torch.cuda.synchronize()
         hb.frame_tracks_dev(d[0].data_ptr(), m, m, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr())
-        for i in range(B):
+        for i in range(n_seq):
             do_update, do_augment = hs[i].frame_plan()
             hs[i].propagate(imu[i])
             if do_update:
@@ -316,9 +318,10 @@ def test_batch_handles_cover_the_long_windows(gpu_required, name, frames):
                 n_upd += 1
             hs[i].augment_compose(do_augment)
         hb.sync()
+        plain = [h.get_state() for h in hs]
         for i in range(B):
             xa, Pa = hb.get_state_at(i)
-            xb, Pb = hs[i].get_state()
+            xb, Pb = plain[i % n_seq]
             assert same_filter_state(xa, Pa, xb, Pb, 1e-10), (name, f, i)
             assert S.state_delta(xa, rf[i]["x3"]) <= 1e-8, (name, f, i)
     assert n_upd > frames and (len(xa) - 26) // 7 == cfg.max_track_len - 1
