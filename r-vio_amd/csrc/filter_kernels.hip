@@ -7,6 +7,7 @@
 //                        measurement compression (Updater.cc:469-536) in information form [A|b] = Hw^T [Hw | r], with the
 //                        reference's rank truncation (Updater.cc:516-529) in its structural form   
 //   gemm_T_kernel        FP64-MFMA (v_mfma_f64_16x16x4_f64) tiled GEMM:  T = s2 I + A Pcc
+//   gemm_T_lds_kernel    the same for a batch handle (>= 128 instances, 6n <= 64): one workgroup per instance, operands staged in LDS
 //   ug_kernel            U = Pc W, G = U A, P1 = P - G Pc^T   (FP64 MFMA, one 16-row strip / WG; U, G stored k-major for final_kernel)
 //   final_kernel         P+ = sym( P1 - P1c G^T + s2 G U^T )   (Joseph form, Updater.cc:615-619)
 //   joseph_batch_kernel  both stages for a batch handle (>= 128 instances, 6n <= 60): one workgroup per instance from P to P+, U / G / P1c in LDS
@@ -1133,6 +1134,57 @@ __global__ __launch_bounds__(256) void gemm_T_kernel(DevCfg cfg, int n, const do
         for (int r = 0; r < 4; ++r) {
             const int row = i0 + lk + 4 * r;
             if (row < c6) Tm[(size_t)row * ldh + col] = acc[r] + ((row == col) ? s2 : 0.0);
+        }
+    }
+}
+
+// T = s2 I + A Pcc for a batch handle (>= 128 instances, 6n <= 64): ONE workgroup per instance, both operands staged in LDS by coalesced loads
+// (gemm_T_kernel reads its operands inside the k-loop with the row index along the lanes — 16 scattered 32-byte pieces per instruction, four dependent
+// rounds per tile: 93 us per launch at B = 2048 for 2 us of matrix-core work).  Same MFMA order per tile, same closing expression.
+// LDS: As[i][k], Bs[j][k] = Pcc[k][j], leading dimension 6n + 1: 2 * 6n (6n + 1) doubles (57 KB at 6n = 60, two workgroups per CU).
+__global__ __launch_bounds__(256) void gemm_T_lds_kernel(DevCfg cfg, int n, const double* __restrict__ Ab, const double* __restrict__ P, double* __restrict__ Tm, size_t bs) {
+    extern __shared__ __align__(16) double gt[];
+    const int z = blockIdx.z;
+    Ab = zoffi(Ab, bs, z); P = zoffi(P, bs, z); Tm = zoffi(Tm, bs, z);
+    const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax, LS = c6 + 1;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    double* const As = gt; double* const Bs = gt + c6 * LS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    {
+        double va[16], vb[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {      // A: rows of 6n doubles; Pcc: columns of 6n doubles — both walks are contiguous in the source
+            const int e = tid + u * 256, i = e / c6, k = e - i * c6;
+            const bool ok = i < c6;
+            va[u] = ok ? Ab[(size_t)i * ldh + k] : 0.0;
+            vb[u] = ok ? P[(size_t)(24 + k) + (size_t)(24 + i) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = tid + u * 256, i = e / c6, k = e - i * c6; if (i < c6) { As[i * LS + k] = va[u]; Bs[i * LS + k] = vb[u]; } }
+    }
+    __syncthreads();
+    const int nt1 = (c6 + 15) / 16;
+    for (int t = wave; t < nt1 * nt1; t += 4) {
+        const int it = t / nt1, jt = t - it * nt1, r = it * 16 + li, c = jt * 16 + li;
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 32 * h + 4 * u + lk;
+                av[u] = (r < c6 && k < c6) ? As[r * LS + k] : 0.0;
+                bv[u] = (c < c6 && k < c6) ? Bs[c * LS + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        if (c < c6) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = it * 16 + lk + 4 * q;
+                if (row < c6) Tm[(size_t)row * ldh + c] = acc[q] + ((row == c) ? s2 : 0.0);
+            }
         }
     }
 }

@@ -482,6 +482,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     if (batch > 1 && gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double) <= 64 * 1024) {
         h->gram_batch_lds = gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double);
+        HIPCHK(h, hipFuncSetAttribute((const void*)gemm_T_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(double)));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
@@ -878,7 +879,13 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
-    if (!h->solve7_variant) hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
+    static const bool no_gtl = getenv("RVIO_NO_GEMM_T_LDS") != nullptr;   // A/B timing
+    if (!h->solve7_variant) {
+        if (B >= 128 && d.ldh - 1 <= 64 && !no_gtl)
+            hipLaunchKernelGGL(gemm_T_lds_kernel, dim3(1, 1, B), dim3(256), (size_t)2 * c6 * (c6 + 1) * sizeof(double), h->stream, d, n, Ab, Pc, h->Tbuf, bs);
+        else
+            hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
+    }
     launch_solve(h, n, Ab);
     launch_ug_final(h, n, Ab, Pn, true, true);
     HIPCHK(h, hipGetLastError());
