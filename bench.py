@@ -670,6 +670,15 @@ def filter_flops(cfg, n, lens, types, m):
     return w
 
 
+def parse_batch_size(size):
+    """an entry of --batch: "2048" = one batch handle of 2048 instances; "2048x2" = 2048 instances as two handles of 1024, both in flight"""
+    txt = str(size)
+    B, nh = (int(v) for v in txt.split("x")) if "x" in txt else (int(txt), 1)
+    if B < 1 or nh < 1 or B % nh:
+        raise ValueError("--batch entry %r: instances must be a positive multiple of the handle count" % (size,))
+    return B, nh
+
+
 def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=40, seed0=0, barrier=None):
     """B independent filter instances advanced by ONE launch per stage (rvio_hip_create_batch).  The hand-over
     tables come from `seeds` direct-track sequences (different landmark/noise seeds) run through plain handles first; instance b
@@ -709,7 +718,7 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
     PEAK_F64 = 78.6
     res = []
     for size in sizes:
-        B, nh = (int(v) for v in str(size).split("x")) if "x" in str(size) else (int(size), 1)   # "2048x2": two handles of 1024 instances, both in flight
+        B, nh = parse_batch_size(size)
         idx = np.arange(B) % seeds
         # [frame][instance] tables, resident in HBM before the timed region
         d_nf = torch.from_numpy(np.stack([tabs[i][0] for i in idx], 1).copy()).cuda()
@@ -719,7 +728,6 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
         imu_h = np.stack([tabs[i][4][:, :m] for i in idx], 1).copy()            # [frame][instance][m]
         d_im = torch.from_numpy(imu_h.view(np.uint8).reshape(nf, B, -1)).cuda()
         per = B // nh
-        assert per * nh == B
         hs = [hip.RvioHip(cfg, batch=per) for _ in range(nh)]
         for k, h in enumerate(hs):
             h.set_state(*inits[idx[k * per]])
@@ -781,7 +789,7 @@ def batched_streams_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=12, n_timed
     by_klt = npx * (1 + 2 * (1 / 4 + 1 / 16 + 1 / 64)) + cfg.n_features * 4 * (16 * 16 * 5) + cfg.n_features * 4 * it_l * 16 * 16   # B_klt, SURVEY.md 8d
     res = []
     for size in sizes:
-        B, nh = (int(v) for v in str(size).split("x")) if "x" in str(size) else (int(size), 1)   # "2048x2": two handles of 1024 instances, both in flight
+        B, nh = parse_batch_size(size)
         idx = np.arange(B) % seeds
         h = hip.RvioHip(cfg, batch=B, front_end=True)
         h.set_state(*inits[0])

@@ -116,3 +116,33 @@ def test_a_failing_secondary_leg_becomes_an_error_object():
         raise RuntimeError("leg died")
     bench.safe_leg(out, "pose_latency_unpipelined", boom)
     assert out["value"] == 1.0 and "leg died" in out["pose_latency_unpipelined"]["error"]
+
+
+def test_batch_size_entries():
+    """--batch entries: plain counts and "instances x handles" """
+    assert bench.parse_batch_size("2048") == (2048, 1) and bench.parse_batch_size(256) == (256, 1)
+    assert bench.parse_batch_size("2048x2") == (2048, 2) and bench.parse_batch_size("4096x4") == (4096, 4)
+    for bad in ("0", "10x3", "8x0", "x2"):
+        with pytest.raises(ValueError):
+            bench.parse_batch_size(bad)
+
+
+def test_rocpd_stats_reports_the_median(tmp_path):
+    """tools/rocpd_stats.py on a hand-made rocpd database: one slow first launch must not hide in the figure quoted (the median)"""
+    import sqlite3
+    import subprocess
+    import sys
+    db = tmp_path / "k.db"
+    con = sqlite3.connect(str(db))
+    con.execute("create table kernels (name text, start integer, end integer, grid_size_z integer, workgroup_size_z integer)")
+    rows = [("joseph(int)", 0, 11000000, 2048, 1)] + [("joseph(int)", 0, 340000 + 1000 * i, 2048, 1) for i in range(9)] + [("other(int)", 0, 5000, 1, 1)]
+    con.executemany("insert into kernels values (?, ?, ?, ?, ?)", rows)
+    con.commit()
+    con.close()
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rocpd_stats.py")
+    out = subprocess.run([sys.executable, tool, str(db), "--grid-z", "2048"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("| joseph")]
+    assert len(line) == 1 and "other" not in out.stdout
+    cells = [c.strip() for c in line[0].strip("|").split("|")]
+    assert int(cells[1]) == 10 and abs(float(cells[4]) - 345.0) < 1e-6 and float(cells[3]) > 1400.0     # median 345 us, mean dragged up by the 11 ms launch
