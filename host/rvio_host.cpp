@@ -170,6 +170,14 @@ bool System::record_to(const std::string& dir, bool force) {
     return true;
 }
 
+int System::device_flags() {
+    if (!h_) return 0;
+    rvio_frame_info fi{};
+    const int rc = rvio_hip_get_frame_info(h_, &fi);
+    if (rc != RVIO_OK && rc != RVIO_ERR_STATE) { err_ = rvio_hip_last_error(h_); return -1; }
+    return fi.reserved[0];
+}
+
 int System::MonoVIO(PoseLine* pose) {
     ImageData image;
     std::vector<ImuData> imus;

@@ -83,6 +83,9 @@ public:
     // waiting behind each — so that the two spans of time_cost.dat (System.cc:254-260,367: t2-t1 and t3-t2, milliseconds) mean what they
     // mean there; without it the frame is one pipelined rvio_hip_frame call.  No-op unless the settings ask for it (or `force`).
     bool record_to(const std::string& dir, bool force = false);
+    // the handle's sticky device-side flags (rvio_frame_info.reserved[0]: 1 singular pivot, 2 a track dropped, 4 a stage counter timed out,
+    // 8 a non-positive gate pivot; 0 = none) — waits for everything in flight, so a replay reads it once at its end.  -1: the query failed.
+    int device_flags();
     bool recording() const { return rec_; }
     bool is_ready() const { return ready_; }
     int frames_after_init() const { return n_img_; }

@@ -109,5 +109,9 @@ int main(int argc, char** argv) {
     }
     std::fprintf(stderr, "rvio_replay: %ld images, %ld filtered frames, %.3f ms per MonoVIO call (host wall clock, pose read-back included)\n",
                  n_images, n_frames, n_images ? 1e3 * t_filter / n_images : 0.0);
+    // anything only the device saw (0 in every test and bench run): said out loud, the poses above are suspect if it is not 0
+    const int flags = sys.device_flags();
+    if (flags) std::fprintf(stderr, "rvio_replay: DEVICE-SIDE FLAGS %d (1 singular pivot in the solve, 2 a track the window cannot hold was dropped, "
+                                    "4 a stage counter timed out, 8 non-positive gate pivot)%s%s\n", flags, flags < 0 ? ": " : "", flags < 0 ? sys.error().c_str() : "");
     return 0;
 }

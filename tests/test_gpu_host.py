@@ -92,6 +92,14 @@ def oracle_replay(cfg, root, seq, frames):
     return np.array(poses)
 
 
+def per_frame(a, b, stderr):
+    """assertion message: the largest pose difference of every frame (where a divergence starts says which frame's inputs to look at) and
+    what the binary said (it reports the handle's device-side flags at its end)"""
+    if a.shape != b.shape:
+        return (a.shape, b.shape, stderr)
+    return ("max |diff| per frame: " + " ".join("%.1e" % v for v in np.abs(a[:, 1:] - b[:, 1:]).max(axis=1)), stderr)
+
+
 @pytest.mark.parametrize("as_png", [False, True])
 def test_replay_matches_the_oracle_host_loop(gpu_required, tmp_path, as_png):
     cfg = abi.config_named("A", enable_equalizer=1)          # the stock settings file = cfg A (200 features, 14 clones)
@@ -109,7 +117,7 @@ def test_replay_matches_the_oracle_host_loop(gpu_required, tmp_path, as_png):
     assert len(want) >= 5 and got.shape == want.shape, (got.shape, want.shape, r.stderr)
     assert np.array_equal(got[:, 0], want[:, 0])             # same frames went through the filter
     q = got[:, 4:8] * np.sign(got[:, 7:8]) - want[:, 4:8] * np.sign(want[:, 7:8])
-    assert np.abs(got[:, 1:4] - want[:, 1:4]).max() <= 1e-6 and np.abs(q).max() <= 1e-6
+    assert np.abs(got[:, 1:4] - want[:, 1:4]).max() <= 1e-6 and np.abs(q).max() <= 1e-6, per_frame(got, want, r.stderr)
 
 
 def test_record_outputs_writes_the_references_two_files(gpu_required, tmp_path):
@@ -144,4 +152,4 @@ def test_record_outputs_writes_the_references_two_files(gpu_required, tmp_path):
     assert np.all(tc[:, 1] > 0) and np.all(tc[:, 2] > 0) and np.all(tc[:, 1:] < 50.0)
     # the staged frame and the pipelined frame are the same arithmetic
     pp = np.loadtxt(str(piped), ndmin=2)
-    assert pp.shape == got.shape and np.abs(pp - got).max() <= 1e-9
+    assert pp.shape == got.shape and np.abs(pp - got).max() <= 1e-9, per_frame(pp, got, r0.stderr)
