@@ -378,8 +378,19 @@ def main():
             _CFG_NAME[0] = args.config
             try:
                 pin = long_inputs()
-                npar = min(len(pin[0]), 240)
+                # (the CPU sample covers the frames of the timed run when that is affordable — <= 300 frames, ~4 s of oracle — so that the END
+                # STATE OF THE TIMED, UN-SYNCHRONISED RUN itself is compared below, not only the synchronised replay of the parity leg)
+                npar = len(pin[0]) if len(pin[0]) <= 300 else 240
                 out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, npar)
+                if n_frames <= len(cpu_states):
+                    xc, Pc = cpu_states[n_frames - 1][0], cpu_states[n_frames - 1][1]
+                    out["timed_run_max_state_delta"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(xc))))
+                    out["timed_run_max_cov_rel_delta"] = float(np.max(np.abs(P_gpu - Pc)) / max(1e-300, float(np.max(np.abs(Pc)))))
+                    out["timed_run_parity"] = {"frames": n_frames, "tolerance": 1e-6, "ok": bool(out["timed_run_max_state_delta"] <= 1e-6),
+                                               "what": "state and covariance the TIMED loop itself left behind (1 + warmup + steps frames enqueued back to back, no host "
+                                                       "synchronisation) against the literal CPU oracle after the same frames"}
+                else:
+                    out["timed_run_parity"] = {"skipped": "%d frames in the timed run, CPU sample of %d" % (n_frames, len(cpu_states))}
                 if _MULTI[0] is not None:
                     out["cpu_baseline_multicore"] = _MULTI[0]
                 out["parity"] = parity_leg(cfg, torch, pin, wi, ai, ni, npar, cpu_states)
@@ -687,7 +698,7 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
     Fu, ML = abi.fu(cfg), cfg.max_track_len
     nf = n_warm + n_timed
     k0 = K0
-    tabs, inits, flops = [], [], np.zeros(nf)
+    tabs, inits, ends, flops = [], [], [], np.zeros(nf)
     for sd in range(seed0, seed0 + seeds):
         seq = rv.synth.SynthSequence(cfg, duration=(k0 + nf + 3) / 20.0 + 1.0, seed=sd)
         wi, ai, ni = seq.init_from_static(k0)
@@ -710,8 +721,10 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
             types[f, : len(l)], lens[f, : len(l)], meas[f, : len(l)] = t, l, me
             imus.append(inp["imu"])
             flops[f] += filter_flops(cfg, ncl, l, t, len(inp["imu"])) / seeds
+        x_end = h.get_state()[0]           # the plain handle after the same nf frames: what every instance replaying this sequence must end at
         h.close()
         m = min(len(i) for i in imus)
+        ends.append((x_end, all(len(i) == m for i in imus)))
         tabs.append((n_feat, types, lens, meas, np.stack([i[:m] for i in imus]), m))
     m = min(t[5] for t in tabs)
     w_frame = float(np.mean(flops[n_warm:]))
@@ -757,12 +770,17 @@ def batched_filter_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=16, n_timed=
             barrier()
         el = time.perf_counter() - t0
         x_last = hs[-1].get_state_at(per - 1)[0]
+        x_first = hs[0].get_state_at(0)[0]
+        same_m = all(ends[i][1] and tabs[i][5] == m for i in (idx[0], idx[B - 1]))   # (the plain handle integrated every IMU sample of its frames; the batch the common first m)
+        d_plain = max(float(np.max(np.abs(_qfix(x_first) - _qfix(ends[idx[0]][0])))), float(np.max(np.abs(_qfix(x_last) - _qfix(ends[idx[B - 1]][0])))))
         for h in hs:
             h.close()
         del d_nf, d_ty, d_ln, d_me, d_im
         tfl = w_frame * B * n_timed / el / 1e12
         res.append({"instances": B, "handles": nh, "ms_per_batched_frame": 1e3 * el / n_timed, "filter_frames_per_s": B * n_timed / el,
-                    "achieved_tflops_fp64": tfl, "frac_fp64_peak": tfl / PEAK_F64, "finite": bool(np.all(np.isfinite(x_last)))})
+                    "achieved_tflops_fp64": tfl, "frac_fp64_peak": tfl / PEAK_F64, "finite": bool(np.all(np.isfinite(x_last))),
+                    "max_state_delta_vs_plain_handle": d_plain if same_m else None,
+                    "plain_handle_note": "instances 0 and B-1 after the timed run against the plain (one-instance, latency-form) handles that ran the same %d frames" % nf})
     return {"workload": "cfg%s filter only (propagate + update + augment/compose), direct-track hand-over tables of %d seeded sequences, "
                         "%d frames timed after %d, one launch per stage for all instances" % (name, seeds, n_timed, n_warm),
             "algorithmic_mflop_per_filter_frame": w_frame / 1e6, "peak_tflops_fp64": PEAK_F64, "sizes": res}

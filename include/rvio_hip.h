@@ -307,6 +307,17 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy);
  * 2 = per-feature Jacobian/nullspace/gate kernel, 3 = reduction of the per-feature information shares (+ rank truncation),
  * 4 = U/G/P1 strips, 5 = Joseph-form kernel (4, 5: in the form this handle launches), 6 = cornerSubPix on the last corner list. */
 int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us);
+/* Test hook against results that depend on LEFT-OVER state (scratch in HBM, LDS contents, stale hand-over entries).  Drains every stream of
+ * the handle, then: what & 1 fills the filter's scratch and the spare state / covariance buffer with 0xff bytes (NaN); & 2 rewrites the LDS
+ * of the whole chip with NaN patterns; & 4 does the same to the Tracker -> Updater hand-over tables (types / len / meas; counts stay) and the
+ * tracker's per-frame scratch; & 8 sets the device-side error bit 4 ("a stage counter timed out", RVIO_ERR_STATE at the next
+ * rvio_hip_sync) so that the recovery path — rvio_hip_initialize — can be exercised.  1 | 2 | 4 between the frames of a sequence must not
+ * change any result. */
+int rvio_hip_debug_poison(rvio_hip* h, int what);
+/* Test hook against ordering holes between the handle's streams: occupies stream `which` (0 filter, 1 tracker / image chain 0, 2 side stream
+ * — KLT, RANSAC, book-keeping —, 3 image chain 1) with a sleeping one-wave kernel for `usec` microseconds, enqueued where the call is made.
+ * A frame sequence with stalls sprinkled over the streams must give the results of the synchronised run bit for bit. */
+int rvio_hip_debug_stall(rvio_hip* h, int which, int usec);
 
 #ifdef __cplusplus
 }

@@ -439,9 +439,13 @@ __global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev 
 // stream ~19 us of its serial chain per frame in the pipelined run (an AQL barrier packet between augcomp and the per-feature launch, with
 // four queues busy); this one-workgroup kernel polls the device-side counter instead (~5 us, launch gaps included).  One workgroup only:
 // a poll inside the ~100 LDS-heavy workgroups of the per-feature launch is a priority inversion.
-__global__ __launch_bounds__(64) void stage_gate_kernel(const unsigned long long* ctr, unsigned long long target, FilterMeta* meta, int dbg_tag) {
+// A frame sequence broken by a timed-out counter (error bit 4: the hand-over half of book-keeping left WITHOUT rewriting its table, or this
+// poll itself gave up) must not reach the filter as a stale hand-over table: the gate empties the table of its frame — race-free here, the
+// table's previous reader (the filter of frame k - kHand) ran earlier on this very stream — and the update of the frame passes the state through.
+__global__ __launch_bounds__(64) void stage_gate_kernel(const unsigned long long* ctr, unsigned long long target, FilterMeta* meta, int* n_feat, int dbg_tag) {
     DBG_I(true, dbg_tag, 4);
-    stage_wait(ctr, target, meta);
+    const bool ok = stage_wait(ctr, target, meta);
+    if (threadIdx.x == 0 && (!ok || (__hip_atomic_load(&meta->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4))) *n_feat = 0;
     DBG_I(true, dbg_tag, 5);
 }
 // ... and the other direction of the same idea: one workgroup behind cornerSubPix says "the corners of this frame are final"

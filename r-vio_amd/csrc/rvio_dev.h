@@ -239,9 +239,13 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
 // ---------------------------------------------------------------- device-side completion counter (augcomp_kernel2 -> bookkeep_kernel)
 // device memory, zero at creation.  aug: bumped by every workgroup of the last kernel of a frame's filter chain (-> book-keeping of frame k+2);
 // handover: bumped once by the hand-over half of book-keeping (-> the gate in front of the filter of the same frame);
-// corners: bumped once behind cornerSubPix (-> the refill half of book-keeping).  One-workgroup consumers poll them; a stream-level event in
-// their place costs the WAITING stream ~10-20 us of its serial chain in the pipelined run (measured in situ, profiles/r03_chain_clocks.txt).
-struct StageSync { unsigned long long aug, handover, corners; };
+// corners[c]: bumped once behind cornerSubPix of image chain c (-> the refill half of book-keeping).  ONE PRODUCER QUEUE PER COUNTER: the image
+// chains of consecutive frames run on different queues and nothing orders them against each other, so each chain counts its own frames
+// (round 3 had one counter for both chains: chain k+1 finishing first let the refill of frame k read a half-written corner list).
+// One-workgroup consumers poll them; a stream-level event in their place costs the WAITING stream ~10-20 us of its serial chain in the
+// pipelined run (measured in situ, profiles/r03_chain_clocks.txt).
+#define RVIO_MAX_IC 3
+struct StageSync { unsigned long long aug, handover, corners[RVIO_MAX_IC]; };
 // every thread of the workgroup calls these
 __device__ __forceinline__ void stage_signal(unsigned long long* c) {
     __threadfence();                         // each wave: its stores written back and performed at agent scope

@@ -66,7 +66,7 @@ struct rvio_hip {
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
-    StageSync stage_tgt = {0};
+    StageSync stage_tgt = {};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
@@ -154,10 +154,37 @@ struct rvio_hip {
     double* d_pose = nullptr;
 };
 
-// The handle's events only order kernels of ONE device across its streams and are never inspected by the host (the host waits with
-// hipStreamSynchronize): no timing, and no system-scope fence when they are recorded — that fence writes the dirty L2 lines of the
-// recording queue back before the NEXT kernel of that queue may start (measured: a 35 us hole in the tracker stream per frame)
-static const unsigned kEvFlags = getenv("RVIO_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+// ---------------------------------------------------------------- environment surface of the SHIPPING library: two variables.
+//   RVIO_PARANOID     every cross-queue hand-off in its most conservative form (A/B against the default, and the thing to set when a
+//                     runtime / firmware is suspected).  "1" = all of it; a larger value is a bit mask for bisection:
+//                       2  events with the default flags (system-scope release at every record) instead of hipEventDisableSystemFence
+//                       4  no device-side polls: every hand-off is a stream-level event (no StageSync counters, no gate / signal kernels)
+//                       8  plain hipStreamCreateWithFlags(hipStreamNonBlocking) streams instead of CU-mask streams with private queues
+//                      16  rvio_hip_frame waits on the host for its H2D staging copies before it enqueues the frame
+//                      32  every whole-frame call drains all streams of the handle before it returns
+//   RVIO_NO_RUNAHEAD  the pipelined path without the run-ahead image chains (book-keeping back on the tracker stream)
+// Every other RVIO_* switch (kernel forms, stream layouts, unsafe timing experiments) exists in the instrumented build only
+// (-DRVIO_DBG_CLOCKS, tools/chain_clocks.py): a stray environment variable cannot change what the shipping pipeline launches.
+enum { PAR_SYSFENCE = 2, PAR_NO_DEVPOLL = 4, PAR_PLAIN_STREAMS = 8, PAR_SYNC_COPIES = 16, PAR_DRAIN = 32, PAR_ALL = 62 };
+static int paranoid_bits() {
+    static const int v = [] {
+        const char* e = getenv("RVIO_PARANOID");
+        if (!e || !*e || !std::strcmp(e, "0")) return 0;
+        const int b = atoi(e);
+        return b > 1 ? (b & PAR_ALL) : (int)PAR_ALL;
+    }();
+    return v;
+}
+#ifdef RVIO_DBG_CLOCKS
+static const char* ab_env(const char* name) { return getenv(name); }
+#else
+static const char* ab_env(const char*) { return nullptr; }
+#endif
+// The handle's events only order kernels of ONE device across its streams; the host only ever WAITS for them (hipEventSynchronize on the
+// pinned ring's events, hipStreamSynchronize elsewhere): no timing, and no system-scope fence when they are recorded — that fence writes the
+// dirty L2 lines of the recording queue back before the NEXT kernel of that queue may start (measured: a 35 us hole in the tracker stream per frame)
+static unsigned ev_flags() { return (paranoid_bits() & PAR_SYSFENCE) || ab_env("RVIO_EVENT_SYSFENCE") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence); }
+#define kEvFlags ev_flags()
 // Timing experiments that DROP correctness-critical stream waits exist only in an instrumented build (-DRVIO_DBG_CLOCKS, tools/chain_clocks.py):
 // a stray environment variable must not be able to turn the shipping pipeline racy.
 #ifdef RVIO_DBG_CLOCKS
@@ -294,7 +321,7 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
     DALLOC(h, t.n_feat, 1); DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
     if (need_tm_global) DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
-    static const bool no_geom4 = getenv("RVIO_NO_GEOM4") != nullptr;   // A/B timing
+    static const bool no_geom4 = ab_env("RVIO_NO_GEOM4") != nullptr;   // A/B timing
     if (h->batch > 1 && d.max_len <= GEOM4_ML && !no_geom4) { DALLOC(h, h->gpose, (size_t)d.Fu * (d.max_len - 1) * 24); DALLOC(h, h->gvalid, d.Fu); }
     if (need_Mg) DALLOC(h, h->Mg, ldh * 2 * ldh);
     return RVIO_OK;
@@ -349,7 +376,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
 // as before (many streams per GPU are what batch handles are for).
 static std::atomic<int> g_private_queue_handles{0};
 static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = false) {
-    static const int mode = getenv("RVIO_STREAM_MODE") ? atoi(getenv("RVIO_STREAM_MODE")) : 1;
+    static const int mode = (paranoid_bits() & PAR_PLAIN_STREAMS) ? 0 : (ab_env("RVIO_STREAM_MODE") ? atoi(ab_env("RVIO_STREAM_MODE")) : 1);
     if (mode == 0 || !h->private_queues) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, h->device);
@@ -358,7 +385,7 @@ static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = fals
     std::vector<uint32_t> mask((size_t)std::max(words, 1), 0xffffffffu);
     if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
     // experiment: the front-end streams leave every `fe_skip`-th CU to the filter stream (RVIO_FE_SKIP=4: three quarters of the chip)
-    static const int fe_skip = getenv("RVIO_FE_SKIP") ? atoi(getenv("RVIO_FE_SKIP")) : 0;
+    static const int fe_skip = ab_env("RVIO_FE_SKIP") ? atoi(ab_env("RVIO_FE_SKIP")) : 0;
     if (front_end && fe_skip > 1) for (int c = 0; c < prop.multiProcessorCount; ++c) if (c % fe_skip == 0) mask[c / 32] &= ~(1u << (c % 32));
     e = hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
     if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
@@ -381,7 +408,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->cfg = *cfg; h->device = device; h->batch = batch;
     h->front_end = front_end; h->det_in_slab = front_end && batch > 1;
     h->wide_px = batch >= 8;
-    if (const char* e = getenv("RVIO_WIDE_PX")) h->wide_px = atoi(e) != 0;   // A/B timing and tests (the two forms must agree bit for bit)
+    if (const char* e = ab_env("RVIO_WIDE_PX")) h->wide_px = atoi(e) != 0;   // A/B timing and tests (the two forms must agree bit for bit)
     fill_devcfg(cfg, &h->dc);
     const DevCfg& d = h->dc;
     if (d.grid_cols * d.grid_rows < 1) { delete h; return RVIO_ERR_INVALID; }
@@ -390,7 +417,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->private_queues = g_private_queue_handles.fetch_add(1) == 0;
     if (!h->private_queues) g_private_queue_handles.fetch_sub(1);
     HIPCHK(h, make_stream(h, &h->stream));
-    h->one_stream = getenv("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
+    h->one_stream = ab_env("RVIO_ONE_STREAM") != nullptr;   // profiling only: every kernel on the filter stream (clean per-kernel times)
     if (h->one_stream) h->stream_t = h->stream_d = h->stream_c = h->stream_e = h->stream;
     else {
         HIPCHK(h, make_stream(h, &h->stream_t, true));
@@ -399,7 +426,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         // Image chains in flight.  Two (default): with the filter, tracker and side streams that makes FOUR busy queues.  A third chain on a
         // fifth queue was measured (RVIO_IC=3): the frame period goes from 131 to 180-250 us whatever CUs the front end is kept off — beyond
         // four busy queues the command processor time-slices them.
-        if (const char* e = getenv("RVIO_IC")) h->n_ic = std::max(1, std::min((int)rvio_hip::kIC, atoi(e)));
+        if (const char* e = ab_env("RVIO_IC")) h->n_ic = std::max(1, std::min((int)rvio_hip::kIC, atoi(e)));
         if (h->n_ic > 2) HIPCHK(h, make_stream(h, &h->stream_e, true));
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
@@ -419,7 +446,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     // launch geometry (decides two optional slab members)
     if (d.Fu > GRAM_MAX_FEATS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
-    if (const char* ft = getenv("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
+    if (const char* ft = ab_env("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->trunc_lds = trunc_lds_doubles(d.max_len) * sizeof(double);
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     bool need_tm_global = false;
@@ -486,7 +513,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
-    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !getenv("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
+    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !ab_env("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
     if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
@@ -501,14 +528,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 8; }
             else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 12; }
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
-            if (getenv("RVIO_SOLVE4")) h->solve5_variant = 0;
+            if (ab_env("RVIO_SOLVE4")) h->solve5_variant = 0;
             h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
-            if (getenv("RVIO_SOLVE6") || getenv("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
+            if (ab_env("RVIO_SOLVE6") || ab_env("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
             // (round 3, measured and NOT adopted: solve7 with T through the L2 scratch instead of LDS — 11 KB of LDS, eight workgroups per CU, no gemm_T
             // launch — as the batch form at 6n <= 64, RVIO_BATCH_SOLVE7: 2.62 ms per batched frame at B = 2048 against 2.29 with solve6 behind gemm_T)
-            if (batch > 1 && h->solve5_variant && !getenv("RVIO_SOLVE7") && !(h->solve7_variant == 1 && getenv("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
+            if (batch > 1 && h->solve5_variant && !ab_env("RVIO_SOLVE7") && !(h->solve7_variant == 1 && ab_env("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
             if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
             if (h->solve7_variant == 1)
             {
@@ -525,7 +552,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             }
         }
         const size_t c6t = (c6m + 15) / 16;
-        if (batch >= 128 && c6m <= 60 && !getenv("RVIO_NO_JOSEPH_FUSED")) {   // the Joseph form of a batch handle in one kernel, one workgroup per instance
+        if (batch >= 128 && c6m <= 60 && !ab_env("RVIO_NO_JOSEPH_FUSED")) {   // the Joseph form of a batch handle in one kernel, one workgroup per instance
             const size_t ls = c6m + 1, dmx = 24 + c6m;
             h->jb_lds = (3 * dmx * ls + std::max((size_t)c6m * ls, (size_t)JB_TL_DOUBLES)) * sizeof(double);
             if (h->jb_lds > 160 * 1024) h->jb_lds = 0;
@@ -576,16 +603,24 @@ void rvio_hip_destroy(rvio_hip* h) {
 }
 const char* rvio_hip_last_error(const rvio_hip* h) { return h ? h->err.c_str() : "null handle"; }
 void* rvio_hip_stream(rvio_hip* h) { return h ? (void*)h->stream : nullptr; }
+// every stream of the handle, nothing else (no error check: the recovery paths use it)
+static int drain_all(rvio_hip* h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    SYNC_FRONT(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+// (Read-backs go through the handle's own stream: the CU-mask streams of the first live handle are created by
+// hipExtStreamCreateWithCUMask as BLOCKING streams, a later handle's as non-blocking ones — a NULL-stream hipMemcpy would synchronise with
+// the former only, and with whatever else the process has on its NULL stream.)
 int rvio_hip_sync(rvio_hip* h) {
     if (!h) return RVIO_ERR_INVALID;
-    if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
-    if (h->stream_e) HIPCHK(h, hipStreamSynchronize(h->stream_e));
-    if (h->stream_d) HIPCHK(h, hipStreamSynchronize(h->stream_d));
-    HIPCHK(h, hipStreamSynchronize(h->stream_t));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    // a device-side stage counter that timed out (stage_wait, rvio_dev.h) left the frame sequence broken: a hard error, not a flag to poll
+    { const int rc = drain_all(h); if (rc != RVIO_OK) return rc; }
+    // a device-side stage counter that timed out (stage_wait, rvio_dev.h) left the frame sequence broken: a hard error, not a flag to poll.
+    // rvio_hip_initialize is the way out of it (it resets the counters and clears the flag).
     int e = 0;
-    HIPCHK(h, hipMemcpy(&e, &h->meta->err, sizeof e, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpyAsync(&e, &h->meta->err, sizeof e, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     if (e & 4) { h->err = "a device-side stage counter timed out (filter -> book-keeping): the frame sequence is invalid, re-initialise"; return RVIO_ERR_STATE; }
     return RVIO_OK;
 }
@@ -674,9 +709,15 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
     // a (re-)initialised filter starts with an empty window: the tracker starts over too (mbIsTheFirstImage, Tracker.cc:88), or its
     // histories would be longer than the window they refer to
     if (h->front_end) {
-        HIPCHK(h, hipSetDevice(h->device));
-        int rc0 = rvio_hip_sync(h);
+        // (plain drains, not rvio_hip_sync: re-initialising is the recovery path after a stage counter timed out — RVIO_ERR_STATE —, so the
+        // sticky flag must not keep the handle from getting here; set_state below rewrites FilterMeta, flag included)
+        int rc0 = drain_all(h);
         if (rc0 != RVIO_OK) return rc0;
+        // the device-side counters start over together with their host-side targets: after a time-out they no longer agree
+        HIPCHK(h, hipMemsetAsync(h->stage_sync, 0, sizeof(StageSync), h->stream));
+        h->stage_tgt = StageSync{};
+        for (int b = 0; b < rvio_hip::kHand; ++b) { h->fin_mode[b] = 0; h->fin_target[b] = 0; }
+        h->book_wait = nullptr; h->book_dev = false; h->book_target = 0; h->gate_pending = false; h->gate_target = 0; h->last_ra = false;
         std::vector<int> ones((size_t)h->batch, 1);
         HIPCHK(h, hipMemcpy2DAsync(h->t.first, h->slab_bytes, ones.data(), sizeof(int), sizeof(int), (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
         for (int i = 0; i < h->batch; ++i) {
@@ -700,7 +741,7 @@ int rvio_hip_initialize(rvio_hip* h, const double w[3], const double a[3], int n
 // handle's streams, allocates, goes on) instead of being refused.
 static int ensure_imu_capacity(rvio_hip* h, int m) {
     if (m <= h->imu_cap) return RVIO_OK;
-    int rc = rvio_hip_sync(h);
+    int rc = drain_all(h);   // (an earlier device-side error stays visible through rvio_hip_sync / rvio_hip_get_frame_info)
     if (rc != RVIO_OK) return rc;
     const int cap = std::max(2 * h->imu_cap, (m + 63) & ~63);
     auto grow = [&](rvio_imu** p) -> int {
@@ -717,7 +758,7 @@ static int ensure_imu_capacity(rvio_hip* h, int m) {
     return RVIO_OK;
 }
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0, hipStream_t st = nullptr) {   // imu_bs = 0: every instance integrates the same samples
-    static const bool prop_b = getenv("RVIO_NO_PROP_B") == nullptr;   // A/B timing
+    static const bool prop_b = ab_env("RVIO_NO_PROP_B") == nullptr;   // A/B timing
     if (!st) st = h->stream;
     if (h->batch > 8 && prop_b)
         hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
@@ -792,7 +833,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
     // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
     const int gram_chunk = (B == 1) ? 64 : 256;
-    static const bool no_gram_batch = getenv("RVIO_NO_GRAM_BATCH") != nullptr;   // A/B timing
+    static const bool no_gram_batch = ab_env("RVIO_NO_GRAM_BATCH") != nullptr;   // A/B timing
     if (B >= 128 && world == 1 && combine && h->gram_batch_lds && !no_gram_batch)   // batch handle, [A|b] fits in LDS: one workgroup per instance, stored tiles only
         launch_gram_batch(h, n);
     else
@@ -808,7 +849,7 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const dim3 gb(1, 1, h->batch);
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
     case 1: {
-        static const int nw = getenv("RVIO_S7_NW") ? atoi(getenv("RVIO_S7_NW")) : 4;
+        static const int nw = ab_env("RVIO_S7_NW") ? atoi(ab_env("RVIO_S7_NW")) : 4;
         const size_t lds = (size_t)(3 * 64 * 65 + 24 * 64) * sizeof(double);
         if (nw == 8) hipLaunchKernelGGL((solve7_kernel<1, 8, 8>), gb, dim3(512), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
         else if (nw == 16) hipLaunchKernelGGL((solve7_kernel<1, 4, 16>), gb, dim3(1024), lds, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
@@ -816,7 +857,7 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         return;
     }
     case 2: {
-        static const int nw2 = getenv("RVIO_S7_V2") ? atoi(getenv("RVIO_S7_V2")) : 12;   // waves of the 6n <= 96 form (measured at 6n = 84: 8 -> 109 us, 12 -> 102, 16 -> 119)
+        static const int nw2 = ab_env("RVIO_S7_V2") ? atoi(ab_env("RVIO_S7_V2")) : 12;   // waves of the 6n <= 96 form (measured at 6n = 84: 8 -> 109 us, 12 -> 102, 16 -> 119)
         if (nw2 == 16) hipLaunchKernelGGL((solve7_kernel<2, 6, 16>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
         else if (nw2 == 12) hipLaunchKernelGGL((solve7_kernel<2, 8, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
         else hipLaunchKernelGGL((solve7_kernel<2, 12, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes);
@@ -850,7 +891,7 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     const size_t bs = h->slab_bytes;
     double* Pc = h->P[h->cur];
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
-    static const bool no_ugl = getenv("RVIO_NO_UGL") != nullptr;   // A/B timing
+    static const bool no_ugl = ab_env("RVIO_NO_UGL") != nullptr;   // A/B timing
     if (h->jb_lds && ug && fin) {   // batch handle, 6n <= 60: P -> P+ in one kernel (U, G, P1 never leave the CU)
         hipLaunchKernelGGL(joseph_batch_kernel, dim3(1, 1, B), dim3(JB_THREADS), h->jb_lds, h->stream, d, n, Pc, h->W, Ab, Pn, bs);
     } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
@@ -879,7 +920,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
-    static const bool no_gtl = getenv("RVIO_NO_GEMM_T_LDS") != nullptr;   // A/B timing
+    static const bool no_gtl = ab_env("RVIO_NO_GEMM_T_LDS") != nullptr;   // A/B timing
     if (!h->solve7_variant) {
         if (B >= 128 && d.ldh - 1 <= 64 && !no_gtl)
             hipLaunchKernelGGL(gemm_T_lds_kernel, dim3(1, 1, B), dim3(256), (size_t)2 * c6 * (c6 + 1) * sizeof(double), h->stream, d, n, Ab, Pc, h->Tbuf, bs);
@@ -947,7 +988,7 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const int c = h->cur, o = c ^ 1;
     // one stream: width (one entry per thread, ~29 workgroups); a batch: every workgroup builds Vk first (a serial section of one thread),
     // so few fat workgroups per instance (the chip is full anyway)
-    static const int aug_wgs = getenv("RVIO_AUG_WGS") ? atoi(getenv("RVIO_AUG_WGS")) : 4;   // A/B timing
+    static const int aug_wgs = ab_env("RVIO_AUG_WGS") ? atoi(ab_env("RVIO_AUG_WGS")) : 4;   // A/B timing
     const int cg = 1 + (h->batch >= 128 ? std::max(1, aug_wgs) : std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256)));
     unsigned long long* done = nullptr;
     if (h->batch == 1) { done = &h->stage_sync->aug; h->stage_tgt.aug += (unsigned long long)cg; }
@@ -1142,7 +1183,8 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         if (rc != RVIO_OK) return rc;
         // corners of frame k ready (the refill half of book-keeping on the side stream waits for it): a one-workgroup signal behind
         // cornerSubPix that book-keeping polls, or a stream-level event
-        if (h->dev_sync) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, image_stream(h), &h->stage_sync->corners); h->stage_tgt.corners++; }
+        // (one counter per image chain: each has ONE producer queue, so "count >= the frames this chain has been handed" means THIS frame's corners)
+        if (h->dev_sync) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, image_stream(h), &h->stage_sync->corners[h->ic]); h->stage_tgt.corners[h->ic]++; }
         else if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));
     }
     if (!pyramid_done) launch_pyramid(h->side);
@@ -1155,7 +1197,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     const size_t bs = h->slab_bytes;
     const unsigned B = (unsigned)h->batch;
     // run-ahead mode: RANSAC rides in the launch of book-keeping's hand-over half (both one workgroup, back to back on the side stream)
-    static const bool no_ra_fuse = getenv("RVIO_NO_FUSED_RANSAC") != nullptr;
+    static const bool no_ra_fuse = ab_env("RVIO_NO_FUSED_RANSAC") != nullptr;
     const bool fused = h->use_det && h->runahead && !no_ra_fuse;
     if (!fused)
     hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
@@ -1182,7 +1224,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, hand);
             // the Updater's input is complete: the filter of this frame waits for THIS — the gate kernel on the filter stream polls the
             // counter the launch above bumps, and the refill half below polls the detector's; or two stream-level events
-            if (h->dev_sync) { h->gate_pending = true; h->gate_target = h->stage_tgt.handover; corners = &h->stage_sync->corners; corners_target = h->stage_tgt.corners; }
+            if (h->dev_sync) { h->gate_pending = true; h->gate_target = h->stage_tgt.handover; corners = &h->stage_sync->corners[h->ic]; corners_target = h->stage_tgt.corners[h->ic]; }
             else {
                 HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));
                 h->handover_evt = true;
@@ -1216,7 +1258,7 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     // A/B timing: stream-level events instead.  Also when a counter-collecting profiler is attached (rocprofv3 --pmc exports
     // ROCPROF_COUNTER_COLLECTION): it serialises kernels across queues, and a kernel that polls a counter another queue's kernel bumps would sit
     // there until its 30 s time-out.
-    static const bool no_devsync = getenv("RVIO_NO_DEVFLAG") != nullptr || getenv("RVIO_NO_DEVSYNC") != nullptr || profiler_serialises();
+    static const bool no_devsync = (paranoid_bits() & PAR_NO_DEVPOLL) || ab_env("RVIO_NO_DEVFLAG") != nullptr || ab_env("RVIO_NO_DEVSYNC") != nullptr || profiler_serialises();
     h->dev_sync = h->runahead && h->batch == 1 && !no_devsync;
     h->gate_pending = false;
     h->dslot = h->runahead ? (int)(h->frame_no % 3) : h->par;
@@ -1365,7 +1407,7 @@ int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride
     // A filter-only batch: PreIntegrator::propagate (one latency-bound workgroup per instance, two per CU) runs on the handle's second stream
     // BESIDE the per-feature stage of the update — U1-U5 and the share reduction read only the clone states and P[24:,24:], which propagation does
     // not touch (the reason feat_prop_kernel may fuse them for one stream) — and joins in front of the solve, which needs the propagated rows.
-    static const bool no_overlap = getenv("RVIO_NO_PROP_OVERLAP") != nullptr;   // A/B timing
+    static const bool no_overlap = ab_env("RVIO_NO_PROP_OVERLAP") != nullptr;   // A/B timing
     const bool overlap = upd && h->batch > 1 && !h->front_end && !h->one_stream && !no_overlap;
     int rc;
     if (overlap) {
@@ -1414,7 +1456,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     } else if (!h->piped) HIPCHK(h, hipStreamSynchronize(h->stream));   // first pipelined frame: everything enqueued so far is done
     h->piped = true;
     if (m < 0) return RVIO_ERR_INVALID;
-    static const bool dbg_host = getenv("RVIO_DBG_HOST") != nullptr;
+    static const bool dbg_host = ab_env("RVIO_DBG_HOST") != nullptr;
     static double acc[5] = {0, 0, 0, 0, 0}; static long nacc = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg_host ? now() : 0;
@@ -1438,7 +1480,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     HIPCHK(h, hipEventRecord(h->evT[h->frame_no & 3], h->tail));      // behind book-keeping, on the stream that ran it
     // the filter needs the hand-over, not the refill: in run-ahead mode it waits for the first half of book-keeping only
     if (h->gate_pending) {
-        if (!(kDbgSkip & 16)) hipLaunchKernelGGL(stage_gate_kernel, dim3(1), dim3(64), 0, h->stream, &h->stage_sync->handover, h->gate_target, h->meta, (int)h->frame_no);
+        if (!(kDbgSkip & 16)) hipLaunchKernelGGL(stage_gate_kernel, dim3(1), dim3(64), 0, h->stream, &h->stage_sync->handover, h->gate_target, h->meta, h->t.n_feat, (int)h->frame_no);
         h->gate_pending = false;
     } else if (!(kDbgSkip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
@@ -1449,7 +1491,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const double t4 = dbg_host ? now() : 0;
     // the filter of this frame is finished when ... single instance in run-ahead mode: its last kernel has bumped the device-side counter
     // (book-keeping of frame k+2 polls it); otherwise an event behind it
-    static const bool no_devflag = getenv("RVIO_NO_DEVFLAG") != nullptr || profiler_serialises();
+    static const bool no_devflag = (paranoid_bits() & PAR_NO_DEVPOLL) || ab_env("RVIO_NO_DEVFLAG") != nullptr || profiler_serialises();
     if (ra && h->batch == 1 && !no_devflag) { h->fin_mode[hb] = 1; h->fin_target[hb] = h->stage_tgt.aug; }
     else { if (!(kDbgSkip & 8)) HIPCHK(h, hipEventRecord(h->evF[hb], h->stream)); h->fin_mode[hb] = 0; }
     if (dbg_host) {
@@ -1458,6 +1500,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
         if (++nacc % 100 == 0) { std::fprintf(stderr, "host us/frame: propagate %.1f track %.1f evT %.1f tail %.1f evF %.1f\n", acc[0] / 100, acc[1] / 100, acc[2] / 100, acc[3] / 100, acc[4] / 100); for (double& a : acc) a = 0; }
     }
     h->frame_no++;
+    if (rc == RVIO_OK && (paranoid_bits() & PAR_DRAIN)) rc = drain_all(h);
     return rc;
 }
 int rvio_hip_frame_dev(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand) {
@@ -1497,6 +1540,7 @@ int rvio_hip_frame_end(rvio_hip* h) {
     h->fin_mode[h->frame_no % rvio_hip::kHand] = 0;
     h->frame_no++;
     h->in_frame = false;
+    if (paranoid_bits() & PAR_DRAIN) return drain_all(h);
     return RVIO_OK;
 }
 // RCCL's ncclAllGather, resolved at run time from the RCCL instance the process has ALREADY loaded (the communicator the caller hands over
@@ -1622,6 +1666,12 @@ int rvio_hip_frame(rvio_hip* h, const uint8_t* img, int stride, const rvio_imu* 
         HIPCHK(h, hipEventRecord(h->evPin[ps], h->stream_t));
     }
     h->last_ra = ra;
+    if (paranoid_bits() & PAR_SYNC_COPIES) {   // the staging copies have landed before anything that reads them is enqueued
+        HIPCHK(h, hipStreamSynchronize(h->stream_d));
+        HIPCHK(h, hipStreamSynchronize(h->stream_t));
+        if (h->stream_c) HIPCHK(h, hipStreamSynchronize(h->stream_c));
+        if (h->stream_e) HIPCHK(h, hipStreamSynchronize(h->stream_e));
+    }
     return frame_dev_impl(h, h->hb_img[b], h->dc.W, h->hb_imu[imu_slot], m, cand_xy ? h->hb_cand[b] : nullptr, nc, true);
 }
 // direct-track variant of the whole frame (host inputs)
@@ -1671,12 +1721,14 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     SYNC_FRONT(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int cnt = 0;
-    HIPCHK(h, hipMemcpy(&cnt, h->det_nout + h->dslot, sizeof cnt, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpyAsync(&cnt, h->det_nout + h->dslot, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n) *n = cnt;
-    if (xy && cnt > 0) HIPCHK(h, hipMemcpy(xy, h->det_xy2[h->dslot], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
+    if (xy && cnt > 0) HIPCHK(h, hipMemcpyAsync(xy, h->det_xy2[h->dslot], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, h->stream));
     const DetDev& ds_ = h->dets[h->det_set_last];
-    if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpy(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost));
-    if (eig) HIPCHK(h, hipMemcpy(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost));
+    if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpyAsync(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, h->stream));
+    if (eig) HIPCHK(h, hipMemcpyAsync(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }
 // pyramid level `level` of the most recent image: u8 image (w*h) and int16 (dx,dy) derivative (w*h*2)
@@ -1766,6 +1818,94 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     *avg_us = ms * 1e3f / iters;
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
+// Test hook against results that depend on LEFT-OVER state: every stream is drained, then
+//   what & 1   the filter's scratch — per-feature shares, information block, T, W, U, G, the d x d temporary, the gate's diagnostics, and the
+//              SPARE state / covariance buffer (every stage writes its output in full) — is filled with 0xff bytes (NaN doubles, -1 ints)
+//   what & 2   a kernel of 160 KB workgroups rewrites the LDS of the whole chip with signalling-NaN patterns
+//   what & 4   the Tracker -> Updater hand-over tables (types / len / meas of all kHand tables; the counts stay) and the tracker's per-frame
+//              scratch (vFeatsTracked, vFeatsUndistNorm, the next-frame order being built, FindNewer flags, ChessGrid cells) likewise
+//   what & 8   sets the device-side error bit 4 ("a stage counter timed out"): the recovery path through rvio_hip_initialize can be tested
+// A frame sequence must give the same results with any of 1 | 2 | 4 between its frames (tests/test_gpu_leftover.py).
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long pattern, int* sink) {
+    extern __shared__ __align__(16) unsigned long long lp[];
+    const int nw = 160 * 1024 / 8;
+    for (int i = threadIdx.x; i < nw; i += 256) lp[i] = pattern ^ (unsigned long long)i;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);   // 20 us: long enough for every CU to be handed a workgroup
+    if (lp[(threadIdx.x * 977) % nw] == 1ull && sink) *sink = 1;      // (keeps the stores alive)
+}
+int rvio_hip_debug_poison(rvio_hip* h, int what) {
+    if (!h) return RVIO_ERR_INVALID;
+    { const int rc = drain_all(h); if (rc != RVIO_OK) return rc; }
+    const DevCfg& d = h->dc;
+    const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
+    auto fill = [&](void* p, size_t bytes) -> hipError_t {
+        if (!p || !bytes) return hipSuccess;
+        hipError_t e = hipSuccess;
+        for (int z = 0; z < h->batch && e == hipSuccess; ++z) e = hipMemsetAsync((char*)p + (size_t)z * h->slab_bytes, 0xff, bytes, h->stream);
+        return e;
+    };
+    if (what & 1) {
+        HIPCHK(h, fill(h->partial, sizeof(double) * d.Fu * ldh * ldh));
+        HIPCHK(h, fill(h->block, sizeof(double) * 2 * ldh * ldh)); HIPCHK(h, fill(h->Ab, sizeof(double) * 2 * ldh * ldh));
+        HIPCHK(h, fill(h->Tbuf, sizeof(double) * ldh * ldh)); HIPCHK(h, fill(h->W, sizeof(double) * ldh * ldh));
+        HIPCHK(h, fill(h->U, sizeof(double) * dm * ldh)); HIPCHK(h, fill(h->G, sizeof(double) * dm * ldh));
+        HIPCHK(h, fill(h->Pt1, sizeof(double) * PP));
+        HIPCHK(h, fill(h->gamma, sizeof(double) * d.Fu)); HIPCHK(h, fill(h->pfinv, sizeof(double) * 3 * d.Fu));
+        HIPCHK(h, fill(h->nrows, sizeof(int) * d.Fu)); HIPCHK(h, fill(h->acc, sizeof(int) * d.Fu)); HIPCHK(h, fill(h->ndof, sizeof(int) * d.Fu));
+        if (h->tm_global) HIPCHK(h, fill(h->tm_global, sizeof(double) * d.Fu * d.rho_max * ldh));
+        if (h->Mg) HIPCHK(h, fill(h->Mg, sizeof(double) * ldh * 2 * ldh));
+        if (h->gpose) { HIPCHK(h, fill(h->gpose, sizeof(double) * d.Fu * (d.max_len - 1) * 24)); HIPCHK(h, fill(h->gvalid, sizeof(int) * d.Fu)); }
+        HIPCHK(h, fill(h->x[h->cur ^ 1], sizeof(double) * d.xdmax)); HIPCHK(h, fill(h->P[h->cur ^ 1], sizeof(double) * PP));
+    }
+    if ((what & 4) && h->front_end) {
+        const TrackerDev& t = h->t;
+        for (int k = 0; k < rvio_hip::kHand; ++k) {
+            HIPCHK(h, fill(h->tout[k].types, d.Fu)); HIPCHK(h, fill(h->tout[k].len, sizeof(int) * d.Fu));
+            HIPCHK(h, fill(h->tout[k].meas, sizeof(float) * 2 * d.Fu * d.max_len));
+        }
+        HIPCHK(h, fill(t.tracked, sizeof(float) * 2 * d.F)); HIPCHK(h, fill(t.un2, sizeof(float) * 2 * d.F));
+        HIPCHK(h, fill(t.tmp_feats, sizeof(float) * 2 * d.F)); HIPCHK(h, fill(t.tmp_un, sizeof(float) * 2 * d.F)); HIPCHK(h, fill(t.tmp_slot, sizeof(int) * d.F));
+        HIPCHK(h, fill(t.cand_acc, sizeof(int) * d.F));
+        HIPCHK(h, fill(t.cell_pts, sizeof(float) * (size_t)d.grid_cols * d.grid_rows * 2 * d.F * 2));
+    }
+    if (what & 2) {
+        static bool attr = false;
+        if (!attr) { HIPCHK(h, hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(256), 160 * 1024, h->stream, 0x7ff4dead00000000ull, (int*)nullptr);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (what & 8) {
+        const int four = 4;   // (|= 4 on a drained handle: read-modify-write through the host)
+        int e = 0;
+        HIPCHK(h, hipMemcpyAsync(&e, &h->meta->err, sizeof e, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        e |= four;
+        HIPCHK(h, hipMemcpyAsync(&h->meta->err, &e, sizeof e, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RVIO_OK;
+}
+
+// Test hook against ordering holes between the handle's streams: a one-wave kernel that occupies `which` (0 filter stream, 1 tracker /
+// image chain 0, 2 side stream: KLT, RANSAC, book-keeping, 3 image chain 1) for `usec` microseconds, enqueued where the call is made.
+// Every dependency of the pipeline has to hold under ANY pacing of its queues, so a frame sequence with stalls sprinkled over its streams
+// must give the results of the synchronised run bit for bit (tests/test_gpu_flatout.py) — independent of how fast the box happens to be.
+__global__ __launch_bounds__(64) void stall_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+int rvio_hip_debug_stall(rvio_hip* h, int which, int usec) {
+    if (!h || which < 0 || which > 3 || usec < 0 || usec > 1000000) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = which == 0 ? h->stream : which == 1 ? h->stream_t : which == 2 ? h->stream_d : h->stream_c;
+    if (!st) return RVIO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)usec * 100ull);   // the constant 100 MHz clock
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }

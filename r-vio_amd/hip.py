@@ -23,7 +23,7 @@ SYMBOLS = [
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
     "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
-    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at", "rvio_hip_frame_sharded_dev",
+    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at", "rvio_hip_frame_sharded_dev", "rvio_hip_debug_poison", "rvio_hip_debug_stall",
 ]
 
 _LIB = None
@@ -358,6 +358,14 @@ class RvioHip:
         us = C.c_float(0)
         self._ck(self.L.rvio_hip_debug_time_kernel(self.h, int(which), int(iters), C.byref(us)), "debug_time_kernel")
         return float(us.value)
+
+    def poison(self, what=7):
+        """drain the handle, then overwrite left-over state: 1 filter scratch, 2 LDS of the chip, 4 hand-over tables + tracker scratch, 8 set error bit 4"""
+        self._ck(self.L.rvio_hip_debug_poison(self.h, int(what)), "debug_poison")
+
+    def stall(self, which, usec):
+        """occupy one of the handle's streams (0 filter, 1 tracker / image chain 0, 2 side, 3 image chain 1) for usec microseconds"""
+        self._ck(self.L.rvio_hip_debug_stall(self.h, int(which), int(usec)), "debug_stall")
 
     def frame_info(self):
         info = abi.rvio_frame_info()
