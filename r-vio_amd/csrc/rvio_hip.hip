@@ -1184,7 +1184,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         // corners of frame k ready (the refill half of book-keeping on the side stream waits for it): a one-workgroup signal behind
         // cornerSubPix that book-keeping polls, or a stream-level event
         // (one counter per image chain: each has ONE producer queue, so "count >= the frames this chain has been handed" means THIS frame's corners)
-        if (h->dev_sync) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, image_stream(h), &h->stage_sync->corners[h->ic]); h->stage_tgt.corners[h->ic]++; }
+        // (instrumented build, RVIO_DBG_ONE_CORNERS: round 3's single counter for both chains — what tests/test_gpu_flatout.py was measured against)
+        static const bool one_corners = ab_env("RVIO_DBG_ONE_CORNERS") != nullptr;
+        const int cix = one_corners ? 0 : h->ic;
+        if (h->dev_sync) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, image_stream(h), &h->stage_sync->corners[cix]); h->stage_tgt.corners[cix]++; }
         else if (h->runahead) HIPCHK(h, hipEventRecord(h->evD1, image_stream(h)));
     }
     if (!pyramid_done) launch_pyramid(h->side);
@@ -1224,7 +1227,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, hand);
             // the Updater's input is complete: the filter of this frame waits for THIS — the gate kernel on the filter stream polls the
             // counter the launch above bumps, and the refill half below polls the detector's; or two stream-level events
-            if (h->dev_sync) { h->gate_pending = true; h->gate_target = h->stage_tgt.handover; corners = &h->stage_sync->corners[h->ic]; corners_target = h->stage_tgt.corners[h->ic]; }
+            if (h->dev_sync) { h->gate_pending = true; h->gate_target = h->stage_tgt.handover; const int cix = ab_env("RVIO_DBG_ONE_CORNERS") ? 0 : h->ic; corners = &h->stage_sync->corners[cix]; corners_target = h->stage_tgt.corners[cix]; }
             else {
                 HIPCHK(h, hipEventRecord(h->evH[h->frame_no & 3], h->tail));
                 h->handover_evt = true;
