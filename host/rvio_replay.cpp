@@ -75,6 +75,7 @@ struct FrameDump {            // what the device holds behind a frame (read with
 struct PassOptions {
     bool sync_every_frame = false;   // rvio_hip_sync behind every MonoVIO call (the reference pacing: nothing overlaps)
     long stall_seed = -1;            // >= 0: sleeping kernels on random streams in front of random frames (rvio_hip_debug_stall)
+    int noise_wgs = 0;               // > 0: that many workgroups of HBM / L2 / LDS traffic beside every fourth frame (rvio_hip_debug_noise)
     long dump_at = -1;               // filtered-frame index behind which the streams are drained and the hand-over is read back
     long max_frames = -1;
 };
@@ -109,6 +110,7 @@ static int run_pass(const Settings& s, const AslDataset& d, int device, const Pa
         ++n_images;
         if (o.stall_seed >= 0 && sys.is_ready())
             for (unsigned k = rnd(3); k > 0; --k) rvio_hip_debug_stall(sys.handle(), (int)rnd(4), 30 + (int)rnd(870));
+        if (o.noise_wgs > 0 && sys.is_ready() && n_images % 4 == 0) rvio_hip_debug_noise(sys.handle(), o.noise_wgs, 1500);
         PoseLine p;
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = sys.MonoVIO(&p);
@@ -154,14 +156,14 @@ static void print_runtime() {
 // --selfcheck: the pipelined replay against the SAME binary's synchronised pass (rvio_hip_sync behind every frame), pose by pose and bit for
 // bit; on a mismatch the pipelined pass is repeated up to the first differing frame, drained there, and the first table that differs —
 // front-end counters, hand-over count / types / lengths / measurements — is printed beside the synchronised pass's.  Exit status 3.
-static int selfcheck(const Settings& s, const AslDataset& d, int device, long max_frames, long stall_seed) {
+static int selfcheck(const Settings& s, const AslDataset& d, int device, long max_frames, long stall_seed, int noise_wgs) {
     std::string err;
     std::vector<PoseLine> ref, got;
     std::vector<FrameDump> dref;
     PassOptions o; o.max_frames = max_frames;
     PassOptions os = o; os.sync_every_frame = true;
     if (run_pass(s, d, device, os, &ref, &dref, nullptr, nullptr, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
-    PassOptions op = o; op.stall_seed = stall_seed;
+    PassOptions op = o; op.stall_seed = stall_seed; op.noise_wgs = noise_wgs;
     int flags = 0;
     if (run_pass(s, d, device, op, &got, nullptr, nullptr, &flags, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
     long first = -1; double worst = 0;
@@ -202,12 +204,12 @@ int main(int argc, char** argv) {
     if (argc >= 3 && !std::strcmp(argv[1], "--check-image")) return check_image(argv[2], !(argc >= 4 && !std::strcmp(argv[3], "--bgr")));
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s <settings.yaml> <asl_root> [<poses_out.dat>] [--device N] [--max-frames K] [--record-dir DIR] [--record]\n"
-                             "          [--sync-every-frame] [--stall-seed S] [--selfcheck]\n", argv[0]);
+                             "          [--sync-every-frame] [--stall-seed S] [--noise WGS] [--selfcheck]\n", argv[0]);
         return 2;
     }
     const char* out_path = nullptr;
     int device = 0; long max_frames = -1, stall_seed = -1;
-    const char* record_dir = "."; bool force_record = false, sync_every = false, self = false;
+    const char* record_dir = "."; bool force_record = false, sync_every = false, self = false; int noise_wgs = 0;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--max-frames") && i + 1 < argc) max_frames = std::atol(argv[++i]);
@@ -215,6 +217,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--record")) force_record = true;                          // as if the settings said INI.RecordOutputs: 1
         else if (!std::strcmp(argv[i], "--sync-every-frame")) sync_every = true;                   // rvio_hip_sync behind every frame (A/B of the pipelining)
         else if (!std::strcmp(argv[i], "--stall-seed") && i + 1 < argc) stall_seed = std::atol(argv[++i]);   // sleeping kernels on random streams (A/B of the ordering)
+        else if (!std::strcmp(argv[i], "--noise") && i + 1 < argc) noise_wgs = std::atoi(argv[++i]);         // a loaded chip beside the replay (A/B of timing inside kernels)
         else if (!std::strcmp(argv[i], "--selfcheck")) self = true;
         else out_path = argv[i];
     }
@@ -224,10 +227,10 @@ int main(int argc, char** argv) {
     AslDataset d;
     if (!read_asl(argv[2], &d, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
     print_runtime();
-    if (self) return selfcheck(s, d, device, max_frames, stall_seed);
-    if (sync_every || stall_seed >= 0) {   // the plain replay with one of the two A/B pacings
+    if (self) return selfcheck(s, d, device, max_frames, stall_seed, noise_wgs);
+    if (sync_every || stall_seed >= 0 || noise_wgs > 0) {   // the plain replay with one of the two A/B pacings
         std::vector<PoseLine> poses; double ms = 0; int flags = 0;
-        PassOptions o; o.max_frames = max_frames; o.sync_every_frame = sync_every; o.stall_seed = stall_seed;
+        PassOptions o; o.max_frames = max_frames; o.sync_every_frame = sync_every; o.stall_seed = stall_seed; o.noise_wgs = noise_wgs;
         if (run_pass(s, d, device, o, &poses, nullptr, &ms, &flags, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
         if (out_path) { std::ofstream out(out_path); if (!out) { std::fprintf(stderr, "cannot write %s\n", out_path); return 1; } for (const PoseLine& p : poses) out << format_pose(p); }
         std::fprintf(stderr, "rvio_replay: %zu filtered frames, %.3f ms per MonoVIO call, device flags %d\n", poses.size(), ms, flags);

@@ -318,6 +318,9 @@ int rvio_hip_debug_poison(rvio_hip* h, int what);
  * — KLT, RANSAC, book-keeping —, 3 image chain 1) with a sleeping one-wave kernel for `usec` microseconds, enqueued where the call is made.
  * A frame sequence with stalls sprinkled over the streams must give the results of the synchronised run bit for bit. */
 int rvio_hip_debug_stall(rvio_hip* h, int which, int usec);
+/* Test hook against timing dependence inside kernels: `wgs` workgroups on a stream of their own load HBM, L2 and LDS for `usec`
+ * microseconds beside whatever the handle has in flight (a box under load); results must not move by a bit. */
+int rvio_hip_debug_noise(rvio_hip* h, int wgs, int usec);
 
 #ifdef __cplusplus
 }

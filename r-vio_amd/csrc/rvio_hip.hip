@@ -1913,6 +1913,42 @@ int rvio_hip_debug_stall(rvio_hip* h, int which, int usec) {
     return RVIO_OK;
 }
 
+// Test hook against timing dependence INSIDE kernels (cross-wave hand-overs through LDS flags, last-block patterns, atomics): `wgs`
+// workgroups on a stream of their own hammer HBM, L2 and LDS for `usec` microseconds beside whatever the handle has in flight — a box
+// under load.  Waves of the pipeline's kernels then share SIMDs, LDS ports and L2 slices with the noise and run at a different relative
+// pace; not one bit of any result may move (tests/test_gpu_flatout.py).
+__global__ __launch_bounds__(256) void noise_kernel(unsigned long long ticks, double* scratch, size_t n_per_wg) {
+    __shared__ double sh[4096];
+    double* g = scratch + (size_t)blockIdx.x * n_per_wg;
+    for (int i = threadIdx.x; i < 4096; i += 256) sh[i] = (double)i;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    double acc = 0;
+    unsigned it = 0;
+    while (wall_clock64() - t0 < ticks) {
+        for (size_t i = threadIdx.x; i < n_per_wg; i += 256) { const double v = g[i] + sh[(i + it) & 4095]; g[i] = v * 0.999; acc += v; }
+        sh[(threadIdx.x * 17 + it) & 4095] = acc;
+        __syncthreads();
+        ++it;
+    }
+    if (acc == 1.2345e300) g[0] = acc;
+}
+int rvio_hip_debug_noise(rvio_hip* h, int wgs, int usec) {
+    if (!h || wgs < 1 || wgs > 4096 || usec < 0 || usec > 1000000) return RVIO_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    static hipStream_t ns = nullptr;
+    static double* scratch = nullptr;
+    const size_t per = 8192;   // 64 KB per workgroup: L2-resident for a few hundred workgroups, HBM beyond
+    if (!ns) {
+        HIPCHK(h, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        HIPCHK(h, hipMalloc((void**)&scratch, sizeof(double) * per * 4096));
+        HIPCHK(h, hipMemset(scratch, 0, sizeof(double) * per * 4096));
+    }
+    hipLaunchKernelGGL(noise_kernel, dim3(wgs), dim3(256), 0, ns, (unsigned long long)usec * 100ull, scratch, per);
+    HIPCHK(h, hipGetLastError());
+    return RVIO_OK;
+}
+
 int rvio_hip_debug_ring(rvio_hip* h, long long* out512, int* frame) {
     if (!h || !out512 || !frame) return RVIO_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));

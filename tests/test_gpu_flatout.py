@@ -57,7 +57,7 @@ def pose_delta(a, b):
     return max(float(np.abs(a[:, :3] - b[:, :3]).max()), float(np.abs(qa - qb).max()))
 
 
-def run_hip(d, mode, pose_between, stalls=None, delay_us=0, sync_every=False, n=None, poison=0):
+def run_hip(d, mode, pose_between, stalls=None, delay_us=0, sync_every=False, n=None, poison=0, noise=None):
     """mode 'host': rvio_hip_frame on host buffers; 'dev': rvio_hip_frame_dev on resident frames.  Returns poses (if read), final state, lists"""
     from rvio_amd import hip
     cfg, imgs, imus = d["cfg"], d["imgs"], d["imus"]
@@ -75,6 +75,8 @@ def run_hip(d, mode, pose_between, stalls=None, delay_us=0, sync_every=False, n=
         if rng is not None:
             for _ in range(int(rng.integers(0, 3))):     # 0..2 stalls in front of this frame, any stream, 30..900 us
                 h.stall(int(rng.integers(0, 4)), int(rng.integers(30, 900)))
+        if noise is not None and i % noise[2] == 0:
+            h.noise(noise[0], noise[1])
         if mode == "dev":
             h.frame_dev(d_imgs[i].data_ptr(), cfg.width, d_imus[i].data_ptr(), len(imus[i]), 0, 0)
         else:
@@ -147,6 +149,46 @@ def test_stalled_queues_do_not_change_a_bit(gpu_required, stock_b, sync_ref, mod
         assert same_bits(r, ref), first_diff(r, ref)
     else:
         assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["P"], ref["P"]) and np.array_equal(r["pts"], ref["pts"])
+
+
+@pytest.mark.parametrize("mode", ["host", "dev"])
+@pytest.mark.parametrize("noise", [(64, 400, 2), (256, 1500, 6), (1024, 3000, 10)], ids=["64wg", "256wg", "1024wg"])
+def test_a_loaded_chip_does_not_change_a_bit(gpu_required, stock_b, sync_ref, mode, noise):
+    """64 / 256 / 1024 workgroups of HBM + L2 + LDS traffic beside the pipeline (rvio_hip_debug_noise: the pipeline's waves share SIMDs, LDS
+    ports and L2 slices with them): the hand-overs INSIDE kernels — LDS flags of the solve, last-block patterns, atomics of the detector —
+    hold at any relative pace of the waves; flat out, and with stalled queues on top"""
+    for stalls in (None, 11):
+        r = run_hip(stock_b, mode, False, stalls=stalls, n=60, noise=noise)
+        ref = sync_ref[mode]
+        assert np.array_equal(r["pts"], ref["pts"]) and np.array_equal(r["hl"], ref["hl"]), (stalls, "feature lists")
+        assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["P"], ref["P"]), (stalls, S.state_delta(r["x"], ref["x"]))
+
+
+@pytest.fixture(scope="module")
+def stock_a():
+    """cfg A = the stock settings file (14-clone window, 6n = 84: the 12-wave, two-rows-per-lane form of the solve; what host/rvio_replay's
+    tests run) — 70 frames, literal oracle end state, synchronised device reference"""
+    cfg, seq, imgs, imus = stock("A", 70)
+    init = seq.init_from_static(K0)
+    s = O.System(cfg)
+    s.set_state(*O.initialize(cfg, *init))
+    for img, imu in zip(imgs, imus):
+        s.frame(imu, None, img=img)
+    d = dict(cfg=cfg, init=init, imgs=imgs, imus=imus, x=s.get_state()[0], pts=s.tracker().get_points()[0])
+    d["ref"] = run_hip(d, "host", True, sync_every=True)
+    return d
+
+
+@pytest.mark.parametrize("kind", ["flat", "stall1", "stall2", "stall3", "noise64", "noise256", "noise1024+stall"])
+def test_stock_settings_file_window_under_every_pacing(gpu_required, stock_a, kind):
+    """the same bars for cfg A: the synchronised run tracks the literal oracle (<= 1e-6, bit-exact feature list), and flat out / stalled /
+    loaded runs reproduce the synchronised run bit for bit"""
+    ref = stock_a["ref"]
+    assert np.array_equal(ref["pts"], stock_a["pts"]) and S.state_delta(ref["x"], stock_a["x"]) <= 1e-6
+    kw = {"flat": {}, "stall1": dict(stalls=1), "stall2": dict(stalls=2), "stall3": dict(stalls=3), "noise64": dict(noise=(64, 400, 2)),
+          "noise256": dict(noise=(256, 1500, 6)), "noise1024+stall": dict(noise=(1024, 3000, 10), stalls=4)}[kind]
+    r = run_hip(stock_a, "host", True, **kw)
+    assert same_bits(r, ref), first_diff(r, ref)
 
 
 def test_a_delayed_image_chain_cannot_be_overtaken(gpu_required, stock_b, sync_ref):

@@ -169,6 +169,14 @@ def _asl(tmp_path, n=34):
     return str(yaml), root
 
 
+@pytest.mark.parametrize("noise", [64, 512])
+def test_selfcheck_on_a_loaded_chip(gpu_required, tmp_path, noise):
+    """... and with `noise` workgroups of HBM / L2 / LDS traffic beside the replay (rvio_hip_debug_noise), stalled queues on top"""
+    yaml, root = _asl(tmp_path)
+    r = subprocess.run([ensure_bin(), yaml, root, "--selfcheck", "--noise", str(noise), "--stall-seed", "9"], capture_output=True, text=True)
+    assert r.returncode == 0 and "first differing frame -1" in r.stderr and "device flags 0" in r.stderr, r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("stall_seed", [-1, 1, 2, 3, 4, 5])
 def test_selfcheck_pipelined_pass_equals_the_synchronised_pass(gpu_required, tmp_path, stall_seed):
     """rvio_replay --selfcheck: the pipelined pass (rvio_hip_frame + rvio_hip_get_pose per image) against the same binary's synchronised
