@@ -374,6 +374,9 @@ def main():
             safe_leg(out, "batched_streams", batched_streams_leg, cfg, torch, [int(b) for b in args.batch_streams.split(",") if b], name=args.config)
         if args.batch:
             safe_leg(out, "batched_filter", batched_filter_leg, cfg, torch, [b for b in args.batch.split(",") if b], name=args.config)
+            big = [parse_batch_size(b)[0] for b in args.batch.split(",") if b and parse_batch_size(b)[0] >= 256 and parse_batch_size(b)[1] == 1]
+            if big:
+                safe_leg(out, "batched_filter_at_defined_load", batched_at_load_leg, cfg, torch, big[-1:], name=args.config)
         if not args.no_cpu:
             _CFG_NAME[0] = args.config
             try:
@@ -598,6 +601,72 @@ def update_at_load_leg(cfg, torch, name="B", reps=60):
                                  "note": "the reference's FP64 work for these tracks (gate, Givens nullspace + compression, EKF) over the p50 update time of ONE stream"}}
     h.close()
     return {"workload": "cfg%s, window full (%d clones, 6n = %d), one stream: rvio_hip_update_tracked on full loads" % (name, n, c6), **res}
+
+
+def batched_at_load_leg(cfg, torch, sizes, name="B", reps=10):
+    """The batched filter at SURVEY.md 8d's DEFINED direct-track load — exactly ceil(F/2) features per instance and frame: "half" = every
+    second feature type '2' at the maximum length, the others type '1' with L ~ U[3, n+1]; "long" = every feature type '1' at L = n+1 (the
+    worst case W_filter is quoted on) — beside `batched_filter`, whose load is the natural track flow of the synthetic scene (a dozen
+    features per frame).  Every instance starts each repetition from the same full-window state (re-seeded, untimed); timed with HIP events
+    on the handle's stream: ONE whole filter frame (propagate + update + augment / compose) of all B instances."""
+    from rvio_amd import hip
+    Fu, ML = abi.fu(cfg), cfg.max_track_len
+    seq = rv.synth.SynthSequence(cfg, duration=(K0 + 40) / 20.0 + 1.0)
+    h1 = hip.RvioHip(cfg)
+    h1.initialize(*seq.init_from_static(K0))
+    drv = rv.synth.DirectTrackDriver(seq)
+    nfill = cfg.max_track_len + 8
+    for f in range(nfill):
+        inp = drv.inputs(K0 + 1 + f)
+        h1.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        drv.after(h1.get_points()[0])
+    x0, P0 = h1.get_state()
+    imu = seq.imu_between(K0 + 1 + nfill)
+    h1.propagate(imu)
+    x1, _ = h1.get_state()
+    h1.close()
+    n = (len(x1) - 26) // 7
+    PEAK_F64 = 78.6
+    d_imu = torch.from_numpy(np.ascontiguousarray(imu).view(np.uint8)).cuda()
+    res = []
+    for B in sizes:
+        hb = hip.RvioHip(cfg, batch=B)
+        st = torch.cuda.ExternalStream(hb.stream())
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        entry = {"instances": B}
+        for mix in ("half", "long"):
+            types, lens, meas = rv.synth.worst_case_tracks(cfg, x1, mix=mix)
+            nf = len(types)
+            t_nf = np.full(B, nf, np.int32)
+            t_ty, t_ln, t_me = np.zeros((B, Fu), np.uint8), np.zeros((B, Fu), np.int32), np.zeros((B, Fu, ML, 2), np.float32)
+            t_ty[:, :nf], t_ln[:, :nf] = types, lens
+            t_me[:, :nf, : meas.shape[1]] = meas
+            d = [torch.from_numpy(a_).cuda() for a_ in (t_nf, t_ty, t_ln, t_me)]
+            torch.cuda.synchronize()
+            ts, info = [], None
+            for r in range(reps + 2):
+                hb.set_state(x0, P0)
+                with torch.cuda.stream(st):
+                    ev0.record()
+                hb.frame_tracks_dev(d_imu.data_ptr(), 0, len(imu), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr())
+                with torch.cuda.stream(st):
+                    ev1.record()
+                hb.sync()
+                if r >= 2:
+                    ts.append(ev0.elapsed_time(ev1))
+            x_last = hb.get_state_at(B - 1)[0]
+            w_alg = filter_flops(cfg, n, lens, types, len(imu))
+            p50 = float(np.median(ts))
+            tfl = w_alg * B / (p50 * 1e-3) / 1e12
+            entry[mix] = {"n_feat": int(nf), "stacked_rows_if_all_accepted": int(np.sum(2 * np.where(types == ord("2"), (lens + 1) // 2, lens) - 3)),
+                          "ms_per_batched_frame": p50, "filter_frames_per_s": B / (p50 * 1e-3), "w_filter_mflop_per_instance": w_alg / 1e6,
+                          "achieved_tflops_fp64": tfl, "frac_fp64_peak": tfl / PEAK_F64, "finite": bool(np.all(np.isfinite(x_last)))}
+            del d
+        hb.close()
+        res.append(entry)
+    return {"workload": "cfg%s filter only, window full (%d clones): every instance runs ONE filter frame on ceil(F/2) = %d features (SURVEY.md 8d's defined "
+                        "direct-track load), all instances from the same state, %d repetitions" % (name, n, Fu, reps),
+            "peak_tflops_fp64": PEAK_F64, "sizes": res}
 
 
 def multi_stream(cfg, fs, wi, ai, ni, n_warm, streams=8, threads=1):

@@ -15,6 +15,9 @@ The device (and oracle/filter.cpp:orc_update_local/global, its CPU mirror) compr
 These tests hold the structural rule against the LITERAL restatement (orc_update: sequential Givens + scan) on the stock image
 workload, and show that the literal decision itself is stable (not decided by rounding noise): +-1 ulp on every entry of the
 stacked Hw and random feature orders leave nRank and the updated state where they were."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -250,3 +253,17 @@ def test_the_reference_itself_is_ill_conditioned_at_rest():
             worst = max(worst, S.state_delta(per.get_state()[0], lit.get_state()[0]))
         res[motion] = worst
     assert res["stationary"] > 1e-8 and res["sinus"] < 1e-11, res
+
+
+def test_last_bit_noise_per_frame_moves_the_reference_by_1e_7_at_rest():
+    """The floor under any free-running comparison at rest (tools/at_rest_sensitivity.py; VERDICT round 3, "the at-rest sequence needs a
+    relaxed bar"): the LITERAL oracle against itself with +-1 ulp of noise on every state / covariance entry after every frame — less than
+    what two correct implementations of any stage differ by — ends 2e-7 .. 2e-6 apart after 100 stationary frames (five seeds measured; two
+    here), while the information-form mirror of the device's U7-U10, every other stage shared bit for bit, ends 3e-7 from the literal form:
+    inside that band.  So the measurement-space form would not buy the device a 1e-6 free-running bar at rest; what the forms owe each other
+    is agreement per update (tests/test_gpu_truncation.py: 1e-9 asked, 6.5e-14 measured on direct tracks)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import at_rest_sensitivity as A
+    noise, mirror = A.study("stationary", frames=100, seeds=2)
+    assert max(noise) > 1e-7, noise          # last-bit noise alone reaches 1e-7 (measured 2e-7 .. 2e-6)
+    assert mirror < 20 * max(noise) and mirror < 5e-6, (mirror, noise)
