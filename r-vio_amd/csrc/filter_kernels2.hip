@@ -7,6 +7,9 @@
 // limiter), no loops over dependent global loads.
 #pragma once
 #include "rvio_dev.h"
+#ifdef RVIO_DBG_CLOCKS
+#include "solve8.hip"   // (measured, not adopted: instrumented build only — see its header)
+#endif
 
 // skew(v)[i][j] with v in LDS (dynamic indexing is fine there):  [[0,-z,y],[z,0,-x],[-y,x,0]]
 __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
@@ -206,13 +209,18 @@ __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterM
 // U1-U5 read only the clone states and P[24:,24:], which propagation does not touch (it rewrites the IMU state, P[0:24,0:24] and the
 // cross terms P[0:24,24:] / P[24:,0:24]), so the two are independent; the last workgroup IS propagate_kernel3, the others ARE
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
+// pinv != NULL (instrumented build, RVIO_SOLVE8: the solve without a pivot search — measured, not adopted, solve8.hip): one more workgroup
+// inverts the clone block Pcc, the measurement-independent half of that solve (propagation leaves Pcc alone, so it is the Pcc the solve will see).
 __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
-                                                        FilterMeta* meta, const rvio_imu* imu, int m) {
+                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* pinv) {
     DBG_R(blockIdx.x == 0, 0);
     if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
+#ifdef RVIO_DBG_CLOCKS
+    if (pinv && blockIdx.x == gridDim.x - 2) { extern __shared__ __align__(16) double fp_dyn[]; pinv_role<4>(cfg, n, P, pinv, meta, fp_dyn); return; }
+#endif
     feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta, (int)blockIdx.x);
 }
 

@@ -89,10 +89,12 @@ __device__ long long g_ring3[64 * 8];   // the image chain of frame `tag` (CLAHE
 #endif
 #ifdef RVIO_DBG_CLOCKS
 #define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)
+#define DBG_W(cond, i) do { if (cond) g_dbg[i] = wall_clock64(); } while (0)   /* constant 100 MHz clock: comparable across kernels */
 #define DBG_R(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring_frame = g_ring_frame + 1; g_ring[(g_ring_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #define DBG_S(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring2_frame = g_ring2_frame + 1; g_ring2[(g_ring2_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #else
 #define DBG_T(i) do { } while (0)
+#define DBG_W(cond, i) do { } while (0)
 #define DBG_R(cond, id) do { } while (0)
 #define DBG_S(cond, id) do { } while (0)
 #endif

@@ -20,6 +20,9 @@
 #include "solve4.hip"
 #include "solve6.hip"
 #include "solve7.hip"
+#ifdef RVIO_DBG_CLOCKS
+#include "solve8.hip"   // the solve without a pivot search: measured, NOT adopted (its header says why); instrumented build only, RVIO_SOLVE8=1
+#endif
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #include "klt3.hip"
@@ -62,12 +65,15 @@ struct rvio_hip {
     int* gvalid = nullptr;     // ... and the validity flag of each triangulation
     size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
     int feat_threads = 64;
-    size_t feat_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
+    size_t feat_lds = 0, fprop_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
     int solve_use_lds = 0, solve_nch = 1;
     int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
+    bool solve8 = false;         // one instance, 6n <= 64: the solve without a pivot search (solve8.hip) — Pcc^-1 beside the per-feature stage, B^-1 on the chain
+    bool pinv_ready = false;     // Pinv holds the inverse of the clone block the next solve will see (written by the fused per-feature launch)
+    double* Pinv = nullptr;      // 64 x 64
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
@@ -313,6 +319,7 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     DALLOC(h, h->gram_cnt, 8);
     DALLOC(h, h->stage_sync, 1);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
+    DALLOC(h, h->Pinv, 64 * 64);
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
     DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
@@ -513,8 +520,15 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
-    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024 && !ab_env("RVIO_NO_FUSED_PROPAGATE");   // (+ propagate's 44 KB of static LDS)
-    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
+    // (instrumented build: + the 18 KB of static LDS of solve8's inverse role, which also stages Pcc in the launch's dynamic LDS)
+#ifdef RVIO_DBG_CLOCKS
+    h->fprop_lds = std::max(h->feat_lds, (size_t)S8_PINV_LDS_DOUBLES * sizeof(double));
+    h->fuse_ok = batch == 1 && h->fprop_lds + 64 * 1024 <= 160 * 1024 && !ab_env("RVIO_NO_FUSED_PROPAGATE");
+#else
+    h->fprop_lds = h->feat_lds;
+    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024;   // (+ propagate's 44 KB of static LDS)
+#endif
+    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
@@ -537,6 +551,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             // launch — as the batch form at 6n <= 64, RVIO_BATCH_SOLVE7: 2.62 ms per batched frame at B = 2048 against 2.29 with solve6 behind gemm_T)
             if (batch > 1 && h->solve5_variant && !ab_env("RVIO_SOLVE7") && !(h->solve7_variant == 1 && ab_env("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
             if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
+#ifdef RVIO_DBG_CLOCKS
+            h->solve8 = h->solve7_variant == 1 && batch == 1 && ab_env("RVIO_SOLVE8");
+            if (h->solve8) {
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_LDS_DOUBLES * sizeof(double))));
+                HIPCHK(h, hipFuncSetAttribute((const void*)solve8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_LDS_DOUBLES * sizeof(double))));
+                HIPCHK(h, hipFuncSetAttribute((const void*)pinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_PINV_LDS_DOUBLES * sizeof(double))));
+            }
+#endif
             if (h->solve7_variant == 1)
             {
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
@@ -813,9 +835,11 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const size_t bs = h->slab_bytes;
     const int B = h->batch;
     if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
-        hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + 1), dim3(256), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+        const bool pinv = h->solve8 && world == 1 && combine;   // (the unsharded update of this very launch follows: the solve will want Pcc^-1)
+        hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                            h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                           h->meta, h->fuse_imu, h->fuse_m);
+                           h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
+        h->pinv_ready = pinv;
         h->fuse_m = -1;
     } else
     if (B == 1)   // one stream: the latency form (every operand load of a gate tile in flight at once)
@@ -847,6 +871,16 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     const dim3 gb(1, 1, h->batch);
+#ifdef RVIO_DBG_CLOCKS
+    if (h->solve8) {   // no pivot search: Pcc^-1 (from the fused per-feature launch, or a launch of its own right here), then B^-1 on the chain
+        if (!h->pinv_ready) hipLaunchKernelGGL(pinv_kernel, dim3(1), dim3(64 * S8_NW), S8_PINV_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->Pinv, h->meta);
+        h->pinv_ready = false;
+        static const int gjw = ab_env("RVIO_S8_GJ") ? atoi(ab_env("RVIO_S8_GJ")) : 4;   // (A/B timing: waves that run the elimination)
+        if (gjw == 8) hipLaunchKernelGGL(solve8_kernel<8>, dim3(1), dim3(64 * S8_NW), S8_LDS_DOUBLES * sizeof(double), h->stream, d, h->meta, n, Ab, xin, Pc, h->Pinv, h->W, xout);
+        else hipLaunchKernelGGL(solve8_kernel<4>, dim3(1), dim3(64 * S8_NW), S8_LDS_DOUBLES * sizeof(double), h->stream, d, h->meta, n, Ab, xin, Pc, h->Pinv, h->W, xout);
+        return;
+    }
+#endif
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
     case 1: {
         static const int nw = ab_env("RVIO_S7_NW") ? atoi(ab_env("RVIO_S7_NW")) : 4;
@@ -1782,6 +1816,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
+            h->pinv_ready = h->solve8;   // (time what the chain sees: the solve kernel alone; Pcc^-1 rides in the per-feature launch)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
     __shared__ double s_ipiv[6 * RVIO_MAX_LEN];
     __shared__ double s_y[6 * RVIO_MAX_LEN];
     __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    DBG_W(threadIdx.x == 0, 45);
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
@@ -343,5 +344,7 @@ __global__ __launch_bounds__(64 * NW) void solve7_kernel(DevCfg cfg, FilterMeta*
         stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
         for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
     }
+    DBG_W(tid == 0, 46);
+    DBG_W(tid == NT - 1, 47);
     DBG_R(true, 7);
 }

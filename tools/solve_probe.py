@@ -1,0 +1,34 @@
+"""Phase stamps + live time of the solve kernel on a full-load update (instrumented build): RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so python tools/solve_probe.py"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pkgload import load_pkg
+rv = load_pkg()
+from rvio_amd import hip
+abi = rv.abi
+cfg = abi.config_named("B", enable_equalizer=0)
+seq = rv.synth.SynthSequence(cfg, duration=5.0)
+h = hip.RvioHip(cfg)
+h.initialize(*seq.init_from_static(38))
+drv = rv.synth.DirectTrackDriver(seq)
+for f in range(cfg.max_track_len + 8):
+    inp = drv.inputs(39 + f)
+    h.frame_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+    drv.after(h.get_points()[0])
+h.propagate(seq.imu_between(39 + cfg.max_track_len + 8))
+x1, P1 = h.get_state()
+types, lens, meas = rv.synth.worst_case_tracks(cfg, x1, mix="half")
+for _ in range(3):
+    h.set_state(x1, P1)
+    h.update(types, lens, meas)
+h.sync()
+out = (C.c_longlong * 64)()
+h.L.rvio_hip_debug_clocks(h.h, out)
+t = np.array(list(out))
+idx = [i for i in (56, 57, 58, 60, 63, 61, 62) if t[i] != 0]
+print("solve phases (cycles):", " ".join("%d->%d:%d" % (a, b, t[b] - t[a]) for a, b in zip(idx[:-1], idx[1:])), "total", t[idx[-1]] - t[idx[0]])
+print("wall clock inside the kernel (us): start -> thread 0 done %.2f, -> last thread done %.2f" % ((t[46] - t[45]) / 100.0, (t[47] - t[45]) / 100.0))
+h.set_state(x1, P1); h.update_tracked(); h.sync()
+print("solve kernel live avg us:", h.time_kernel(0, 50))
+h.close()
