@@ -66,6 +66,70 @@ __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* _
     if (tid < 256) lut[(size_t)t * 256 + tid] = (uint8_t)v;
 }
 
+// Round 4: the histogram without LDS-atomic conflicts.  clahe_lut_kernel lets the 64 lanes of a wave add into ONE 256-bin histogram: an image
+// region has few grey levels, so most lanes of an instruction hit the same bins and the LDS serialises them (731 us per batched frame of 128
+// streams — 63 GB/s of image bytes —, 12.7 us for one).  Here every LANE owns a column of the histogram: hist[bin][lane] as 16-bit counters
+// packed in pairs (a counter sees one lane column of the tile, ceil(tw / 64) th pixels <= 65535; 256 x 32 words = 32 KB, five workgroups per CU), so an instruction's 64 additions go to
+// 64 different counters (two lanes share a word: a two-way conflict at worst), and the four waves of the workgroup meet only by coincidence.
+// The counts are integers: the same histogram, hence the same LUT bit for bit.  256 threads: wave <-> every fourth row of the tile.
+#define CLAHE_LUT2_T 256
+__global__ __launch_bounds__(CLAHE_LUT2_T) void clahe_lut_kernel2(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
+                                                                  int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs, int dbg_tag) {
+    DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 0);
+    src = zoff(src, src_bs); lut = zoff(lut, bs);
+    __shared__ unsigned hist2[256 * 32];
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x, ty = t / tiles_x, tx = t % tiles_x;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) hist2[tid + 256 * k] = 0u;
+    __syncthreads();
+    const unsigned one = 1u << (16 * (lane & 1));
+    unsigned* const mine = hist2 + (lane >> 1);
+    // four rows x 64 columns of byte loads in flight before the LDS additions
+    for (int c0 = 0; c0 < tw; c0 += 64) {
+        const int c = c0 + lane;
+        const bool cok = c < tw;
+        const int xs = reflect1(tx * tw + (cok ? c : 0), w);
+        for (int r0 = wv; r0 < th; r0 += 16) {
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 4 * j;
+                v[j] = (cok && r < th) ? (int)src[(size_t)reflect1(ty * th + r, h) * stride + xs] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (v[j] >= 0) atomicAdd(&mine[v[j] * 32], one);
+        }
+    }
+    __syncthreads();
+    int hv = 0;
+    {   // bin tid: the sum of its 64 counters (the 32 words read in a rotated order: consecutive bins sit 32 words apart)
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { const unsigned q = hist2[tid * 32 + ((k + tid) & 31)]; lo += q & 0xffffu; hi += q >> 16; }
+        hv = (int)(lo + hi);
+    }
+    if (clip_limit > 0) {
+        const int excess = hv > clip_limit ? hv - clip_limit : 0;
+        hv -= excess;
+        int clipped;
+        block_exscan(excess, &clipped, s_w);
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            const int step = 256 / residual > 1 ? 256 / residual : 1;
+            if (tid % step == 0 && tid / step < residual) hv += 1;
+        }
+    }
+    int total;
+    const int sum = block_exscan(hv, &total, s_w) + hv;      // inclusive
+    int v = (int)rintf((float)sum * lut_scale);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    lut[(size_t)t * 256 + tid] = (uint8_t)v;
+}
+
 #define CLAHE_MAX_TILES 64
 __global__ __launch_bounds__(256) void clahe_interp_kernel(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tiles_y,
                                                            float inv_tw, float inv_th, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst,

@@ -1177,6 +1177,13 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         uint8_t* eq = h->d_eq2[h->eq_slot];
         hipStream_t cs = image_stream(h);
         uint8_t* lut = h->d_lut2[h->runahead ? h->ic : h->par];
+        // (lane-private 16-bit histogram columns, no LDS-atomic conflicts: every handle.  A counter sees the pixels of ONE lane column of the tile,
+        // ceil(tw / 64) th of them — 1296 at 1080p —, so 16 bits hold for any image a camera delivers; the 32-bit per-wave form stays as the fall-back)
+        static const bool lut1 = ab_env("RVIO_CLAHE_LUT1") != nullptr;   // A/B timing
+        if (((h->cl_tw + 63) / 64) * h->cl_th <= 65535 && !lut1)
+            hipLaunchKernelGGL(clahe_lut_kernel2, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT2_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
+                               h->cl_clip, h->cl_scale, lut, src_bs, bs, (int)h->frame_no);
+        else
         hipLaunchKernelGGL(clahe_lut_kernel, dim3(h->cl_tx * h->cl_ty, 1, B), dim3(CLAHE_LUT_T), 0, cs, d_img, d.W, d.H, stride, h->cl_tx, h->cl_tw, h->cl_th,
                            h->cl_clip, h->cl_scale, lut, src_bs, bs, (int)h->frame_no);
         if (h->wide_px && d.W % 4 == 0 && stride % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && src_bs % 4 == 0)

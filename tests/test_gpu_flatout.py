@@ -191,6 +191,40 @@ def test_stock_settings_file_window_under_every_pacing(gpu_required, stock_a, ki
     assert same_bits(r, ref), first_diff(r, ref)
 
 
+@pytest.mark.parametrize("mode", ["host", "dev"])
+def test_queues_descheduled_for_milliseconds(gpu_required, stock_b, sync_ref, mode):
+    """An oversubscribed GPU (other tenants hold hardware queue slots) time-slices the handle's four queues with a quantum of milliseconds: one
+    chain stands still while the others run to completion.  Emulated with 4-8 ms stalls, one stream at a time, every few frames — the pacing at
+    which round 3's shared `corners` counter let the next frame's image chain announce corners the stalled chain had not written yet."""
+    from rvio_amd import hip
+    cfg, imgs, imus = stock_b["cfg"], stock_b["imgs"], stock_b["imus"]
+    if mode == "dev":
+        import torch
+        d_imgs = torch.from_numpy(imgs[:60]).cuda()
+        d_imus = [torch.from_numpy(i.view(np.uint8)).cuda() for i in imus[:60]]
+        torch.cuda.synchronize()
+    h = hip.RvioHip(cfg)
+    h.initialize(*stock_b["init"])
+    for i in range(60):
+        if i % 5 == 2:
+            h.stall((i // 5) % 4, 4000 + 1000 * ((i // 5) % 5))
+        if mode == "dev":
+            h.frame_dev(d_imgs[i].data_ptr(), cfg.width, d_imus[i].data_ptr(), len(imus[i]), 0, 0)
+        else:
+            h.frame(imgs[i], imus[i], None)
+        if i % 3 == 0:
+            h.pose()
+    h.sync()
+    x, P = h.get_state()
+    pts, hl = h.get_points()
+    info = h.frame_info()
+    h.close()
+    ref = sync_ref[mode]
+    assert info["device_error"] == 0
+    assert np.array_equal(pts, ref["pts"]) and np.array_equal(hl, ref["hl"])
+    assert np.array_equal(x, ref["x"]) and np.array_equal(P, ref["P"])
+
+
 def test_a_delayed_image_chain_cannot_be_overtaken(gpu_required, stock_b, sync_ref):
     """the `corners` hand-off: the image chain of every other frame is held back by 600 us, so the NEXT frame's chain (other queue) finishes
     first — the refill half of book-keeping must still see its own frame's corner list"""
