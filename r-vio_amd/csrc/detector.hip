@@ -32,6 +32,8 @@ struct DetDev {
     int* nb;                        // general path: stronger neighbours within the distance, per candidate  [n_cap][DET_NBCAP]
     int* nb_cnt;                    // list length, or -1 if it overflowed (that candidate scans its cells every round)
     int n_cap;                      // candidates with a neighbour list (the rest scan)
+    unsigned long long* prov;       // provisional candidates of the fused min-eigenvalue + local-maximum pass: every strict 3x3 local maximum, the
+                                    // image-wide threshold not applied yet (it needs the maximum of the whole map) [W*H]; count in counters[3]
     unsigned long long* cand;       // flat candidate keys      [W*H]
     unsigned long long* acc;        // accepted keys            [W*H]
     unsigned char* state;           // general path, per candidate: 1 undecided, 2 taken, 3 dropped
@@ -49,7 +51,7 @@ struct DetDev {
 // batched launches: every buffer of instance z lies z * bs bytes behind instance 0's (the cornerSubPix window is shared)
 __device__ __forceinline__ void det_shift(DetDev& d, size_t off) {
     zmove(d.first, off); zmove(d.eig, off); zmove(d.maxkey, off); zmove(d.counters, off); zmove(d.cell_cnt, off); zmove(d.cell_ent, off);
-    zmove(d.cell_ci, off); zmove(d.nb, off); zmove(d.nb_cnt, off); zmove(d.cand, off); zmove(d.acc, off); zmove(d.state, off);
+    zmove(d.cell_ci, off); zmove(d.nb, off); zmove(d.nb_cnt, off); zmove(d.prov, off); zmove(d.cand, off); zmove(d.acc, off); zmove(d.state, off);
     zmove(d.raw_xy, off); zmove(d.xy, off); zmove(d.n_out, off);
 }
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : (b ^ 0x7fffffff); }
@@ -220,6 +222,141 @@ __global__ __launch_bounds__(DET_T) void mineig_kernel4(const uint8_t* __restric
     }
 }
 
+// ---------------------------------------------------------------- round 4: min-eigenvalue map + 3x3 local maxima in ONE pass
+// goodFeaturesToTrack thresholds the map at quality x its MAXIMUM and keeps the strict 3x3 local maxima (cv::dilate + compare).  The two
+// kernels of rounds 1-3 wrote the whole float map (1.44 MB at 752 x 480) for the second one to read back (1.07 MB after the threshold test):
+// 2.5 MB of HBM / L2 round trip per frame for a result of ~2 k candidates.  The local-maximum test does not need the maximum; only the
+// threshold does.  So: one workgroup computes the map on its 64 x 16 tile PLUS a one-pixel ring (the neighbours' values, recomputed —
+// the same arithmetic, hence the same bits), keeps it in LDS, appends every local maximum (value != 0) to a provisional list and folds the
+// tile's maximum into the image maximum; nms_threshold_kernel then applies  value > quality x maximum  to that list (a few thousand
+// entries instead of the 361 k-pixel map) and fills the candidate list and the cell buckets exactly as nms_kernel did.  The map itself
+// is no longer stored (one stream; batch handles of >= 8 instances keep the two-pass throughput form, see nms_kernel4);
+// rvio_hip_get_corners(eig) recomputes it on demand with mineig_kernel.
+// Arithmetic = mineig_kernel's, in the separable form of round 2's throughput kernel: raw pixels staged once (one byte load per pixel),
+// Scharr-scaled Sobel gradients in float, the three product planes' vertical three-sums (p(i) + p(i+1)) + p(i+2) formed once per column in
+// double and shared through LDS, a pixel adds three of them left to right: the canonical additions in the canonical order.
+#define DET_FH 16                                   // tile rows of the fused pass
+__global__ __launch_bounds__(DET_T) void mineig_nms_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
+    DBG_I(blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, dbg_tag, 1);
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    constexpr int TH = DET_FH, TW = DET_TW;
+    constexpr int EW = TW + 2, EH = TH + 2;          // map incl. the ring:    rows y0-1 .. y0+TH,   columns x0-1 .. x0+TW
+    constexpr int GW = TW + 4, GH = TH + 4;          // gradients:             rows y0-2 .. y0+TH+1, columns x0-2 .. x0+TW+1
+    constexpr int RW = TW + 6, RH = TH + 6;          // raw pixels:            rows y0-3 .. y0+TH+2, columns x0-3 .. x0+TW+2
+    __shared__ unsigned char raw[RH][RW + 2];
+    __shared__ float sdx[GH][GW], sdy[GH][GW];
+    __shared__ double cs[3][EH][GW];                 // cs[k][i][c] = (p_k(i, c) + p_k(i+1, c)) + p_k(i+2, c) on gradient rows i .. i+2, gradient column c
+    __shared__ float se[EH][EW];
+    __shared__ int s_max[DET_T / 64];
+    const int W = d.W, H = d.H;
+    const int tid = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {        // per-frame reset of the detector's counters (nothing in this kernel reads them; [3] is the provisional count)
+        for (int i = tid; i < d.max_cells; i += DET_T) d.cell_cnt[i] = 0;
+        if (tid < 3) d.counters[tid] = 0;
+    }
+    // raw[tr][tc] = pixel (y0 - 3 + tr, x0 - 3 + tc) clamped into the image (positions the reflections below never address hold a copy of an edge pixel)
+    for (int e = tid; e < RH * RW; e += DET_T) {
+        const int tr = e / RW, tc = e % RW;
+        const int yy = min(max(y0 - 3 + tr, 0), H - 1), xx = min(max(x0 - 3 + tc, 0), W - 1);
+        raw[tr][tc] = src[(size_t)yy * stride + xx];
+    }
+    __syncthreads();
+    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+    const float k1 = (float)scale, k0 = (float)(2.0 * scale);
+    // gradient at grid position (ly, lx) <-> pixel (y0 - 2 + ly, x0 - 2 + lx); outside the image: the gradient AT the reflected position
+    // (cornerMinEigenVal's BORDER_DEFAULT box filter over a Sobel image computed with BORDER_DEFAULT), as mineig_kernel does
+    for (int e = tid; e < GW * GH; e += DET_T) {
+        const int ly = e / GW, lx = e % GW;
+        const int py = y0 - 2 + ly, px = x0 - 2 + lx;
+        float dxv = 0.f, dyv = 0.f;
+        if (py >= -1 && py < H + 1 && px >= -1 && px < W + 1) {
+            const int gy = reflect1(py, H), gx = reflect1(px, W);
+            const unsigned char* r0 = raw[reflect1(gy - 1, H) - y0 + 3];
+            const unsigned char* r1 = raw[gy - y0 + 3];
+            const unsigned char* r2 = raw[reflect1(gy + 1, H) - y0 + 3];
+            const int xl = reflect1(gx - 1, W) - x0 + 3, xc = gx - x0 + 3, xr = reflect1(gx + 1, W) - x0 + 3;
+            const float a00 = r0[xl], a01 = r0[xc], a02 = r0[xr], a10 = r1[xl], a12 = r1[xr], a20 = r2[xl], a21 = r2[xc], a22 = r2[xr];
+            const float rr0 = a02 - a00, rr1 = a12 - a10, rr2 = a22 - a20;
+            dxv = k0 * rr1 + k1 * (rr0 + rr2);
+            const float q0 = k0 * a01 + k1 * (a00 + a02);
+            const float q2 = k0 * a21 + k1 * (a20 + a22);
+            dyv = q2 - q0;
+        }
+        sdx[ly][lx] = dxv; sdy[ly][lx] = dyv;
+    }
+    __syncthreads();
+    // vertical three-sums: item = (gradient column c, pair of map rows 2g, 2g+1) — map row i sums gradient rows i, i+1, i+2
+    for (int it = tid; it < GW * (EH / 2); it += DET_T) {
+        const int c = it % GW, r0 = 2 * (it / GW);
+        double p[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gx = sdx[r0 + r][c], gy = sdy[r0 + r][c];
+            const float pxx = gx * gx, pxy = gx * gy, pyy = gy * gy;
+            p[0][r] = (double)pxx; p[1][r] = (double)pxy; p[2][r] = (double)pyy;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cs[k][r0][c] = (p[k][0] + p[k][1]) + p[k][2];
+            cs[k][r0 + 1][c] = (p[k][1] + p[k][2]) + p[k][3];
+        }
+    }
+    __syncthreads();
+    // the map on the tile and its ring: map position (ey, ex) <-> pixel (y0 - 1 + ey, x0 - 1 + ex); -inf outside the image (never a neighbour
+    // that matters: candidates keep one pixel away from the border)
+    int key = (int)0x80000000;
+    for (int e = tid; e < EW * EH; e += DET_T) {
+        const int ey = e / EW, ex = e % EW;
+        const int y = y0 - 1 + ey, x = x0 - 1 + ex;
+        float ev = -INFINITY;
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            float cov[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cov[k] = (float)((cs[k][ey][ex] + cs[k][ey][ex + 1]) + cs[k][ey][ex + 2]);
+            const float a = cov[0] * 0.5f, b = cov[1], c = cov[2] * 0.5f;
+            ev = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            if (ex >= 1 && ex <= TW && ey >= 1 && ey <= TH) { const int k2 = f2ord(ev); key = k2 > key ? k2 : key; }   // the tile's own pixels feed the image maximum
+        }
+        se[ey][ex] = ev;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
+    if ((tid & 63) == 0) s_max[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+        int m = s_max[0];
+        for (int k = 1; k < DET_T / 64; ++k) m = s_max[k] > m ? s_max[k] : m;
+        atomicMax(d.maxkey, m);
+    }
+    // strict 3x3 local maxima of the tile's pixels, one pixel away from the image border (goodFeaturesToTrack: dilate, compare, skip the border).
+    // Collected in LDS first: ONE global atomic per workgroup reserves the tile's range of the provisional list (an atomic per local maximum —
+    // ~15 k per image on one counter — cost the image chain 40 us)
+    __shared__ unsigned long long s_list[TW * TH];
+    __shared__ int s_n, s_base;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int lx = tid & 63, x = x0 + lx;
+#pragma unroll
+    for (int rr = 0; rr < TH / (DET_T / 64); ++rr) {
+        const int ly = (tid >> 6) + (DET_T / 64) * rr, y = y0 + ly;
+        if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) continue;
+        const float v = se[ly + 1][lx + 1];
+        if (v == 0.f) continue;
+        float m = v;
+        m = fmaxf(m, se[ly][lx]);     m = fmaxf(m, se[ly][lx + 1]);     m = fmaxf(m, se[ly][lx + 2]);
+        m = fmaxf(m, se[ly + 1][lx]);                                   m = fmaxf(m, se[ly + 1][lx + 2]);
+        m = fmaxf(m, se[ly + 2][lx]); m = fmaxf(m, se[ly + 2][lx + 1]); m = fmaxf(m, se[ly + 2][lx + 2]);
+        if (v != m) continue;
+        const int idx = y * W + x;
+        s_list[atomicAdd(&s_n, 1)] = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)idx;
+    }
+    __syncthreads();
+    const int cnt = s_n;
+    if (tid == 0 && cnt > 0) s_base = atomicAdd(&d.counters[3], cnt);
+    __syncthreads();
+    for (int i = tid; i < cnt; i += DET_T) d.prov[s_base + i] = s_list[i];
+}
+
 __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* cell, int* gw, int* gh) {
     const float s = (*d.first) ? 1.f : 2.f;
     *md = s * d.min_dist;                                    // s*mnMinDistance (int * float)
@@ -227,6 +364,33 @@ __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* ce
     *gw = (d.W + *cell - 1) / *cell; *gh = (d.H + *cell - 1) / *cell;
 }
 
+// The image-wide threshold on the provisional list (value > quality x maximum: goodFeaturesToTrack's cv::threshold THRESH_TOZERO):
+// the survivors are the candidates; list and cell buckets as nms_kernel filled them (the order inside `cand` is an atomic append, as it was).
+#define NMS_T 256
+__global__ __launch_bounds__(NMS_T) void nms_threshold_kernel(DetDev d, size_t bs) {
+    det_shift(d, (size_t)blockIdx.z * bs);
+    const int W = d.W;
+    const int np = d.counters[3];
+    const float mx = ord2f(*d.maxkey);
+    const float thr = (float)((double)mx * d.quality);
+    float md; int cell, gw, gh;
+    det_geometry(d, &md, &cell, &gw, &gh);
+    for (int i = blockIdx.x * NMS_T + threadIdx.x; i < np; i += gridDim.x * NMS_T) {
+        const unsigned long long key = d.prov[i];
+        const float v = __int_as_float((int)(key >> 32));
+        if (!(v > thr)) continue;
+        const int idx = (int)(key & 0xffffffffull), x = idx % W, y = idx / W;
+        const int ci = atomicAdd(&d.counters[0], 1);
+        d.cand[ci] = key;
+        const int c = (y / cell) * gw + (x / cell);
+        const size_t slot = (size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1);
+        d.cell_ent[slot] = key;
+        d.cell_ci[slot] = ci;
+    }
+}
+
+// The two-pass form (the map through HBM): batch handles of >= 8 instances keep it — throughput, not latency: the fused pass recomputes the
+// ring (+27 % gradient / eigenvalue work) and holds 55 KB of LDS per workgroup (measured at 128 streams: 1.70 ms per batched frame fused, 1.59 two-pass)
 __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     det_shift(d, (size_t)blockIdx.z * bs);
     const int W = d.W, H = d.H;
@@ -562,7 +726,8 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
     DBG_T(60);
     if (tid == 0) {
         *d.n_out = na < d.F ? na : d.F;
-        *d.maxkey = (int)0x80000000;                       // consumed by nms_kernel; ready for the next image
+        *d.maxkey = (int)0x80000000;                       // consumed by the threshold pass; ready for the next image
+        d.counters[3] = 0;                                 // ... and so is the provisional list
     }
 }
 

@@ -1058,7 +1058,7 @@ static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE 
     DALLOC(h, q.cell_ent, (size_t)(d.W + cell2) * (d.H + cell2)); DALLOC(h, q.cell_ci, (size_t)(d.W + cell2) * (d.H + cell2));
     q.n_cap = (int)std::min(npx, (size_t)16384);
     DALLOC(h, q.nb, (size_t)q.n_cap * DET_NBCAP); DALLOC(h, q.nb_cnt, (size_t)q.n_cap);
-    DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
+    DALLOC(h, q.prov, npx); DALLOC(h, q.cand, npx); DALLOC(h, q.acc, npx); DALLOC(h, q.state, npx);
     DALLOC(h, q.raw_xy, (size_t)2 * d.F);
     return RVIO_OK;
 }
@@ -1124,16 +1124,20 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     const DetDev q = det_view(h);
     const hipStream_t ds = image_stream(h);
     h->det_set_last = h->runahead ? h->ic : 0;
-    const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
-    if (h->wide_px)
-        hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
-    else
-        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
-    if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
-    if (h->wide_px && d.W % 4 == 0)
-        hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
-    else
-        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
+    static const bool two_pass = ab_env("RVIO_DET_TWO_PASS") != nullptr;   // A/B timing
+    if (h->wide_px || two_pass) {   // batch handles of >= 8 instances: the two-pass throughput form (the map through HBM)
+        const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
+        if (h->wide_px) hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
+        else hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
+        if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
+        if (h->wide_px && d.W % 4 == 0) hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
+        else hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
+    } else {
+        // one stream: min-eigenvalue map + strict 3x3 local maxima in one pass (the map stays in LDS), then the image-wide threshold on the provisional list
+        hipLaunchKernelGGL(mineig_nms_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_FH - 1) / DET_FH, B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
+        if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // the threshold pass reads mbIsTheFirstImage (cell size) as book-keeping(k-1) left it
+        hipLaunchKernelGGL(nms_threshold_kernel, dim3(16, 1, B), dim3(NMS_T), 0, ds, q, bs);
+    }
     hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
     if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
@@ -1771,7 +1775,17 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
     if (xy && cnt > 0) HIPCHK(h, hipMemcpyAsync(xy, h->det_xy2[h->dslot], sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, h->stream));
     const DetDev& ds_ = h->dets[h->det_set_last];
     if (raw_xy && cnt > 0) HIPCHK(h, hipMemcpyAsync(raw_xy, ds_.raw_xy, sizeof(float) * 2 * cnt, hipMemcpyDeviceToHost, h->stream));
-    if (eig) HIPCHK(h, hipMemcpyAsync(eig, ds_.eig, sizeof(float) * h->dc.W * h->dc.H, hipMemcpyDeviceToHost, h->stream));
+    if (eig) {
+        // the pipeline no longer stores the min-eigenvalue map (mineig_nms_kernel keeps it in LDS): recomputed on demand from the image the
+        // detector saw — level 0 of the current pyramid — by the map-only kernel (same arithmetic); its side effects on the detector's
+        // per-frame scratch are undone (the image maximum returns to its rest value)
+        const DevCfg& d = h->dc;
+        hipLaunchKernelGGL(mineig_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, 1), dim3(DET_T), 0, h->stream, h->pyr[h->pyr_cur].img[0], d.W, ds_, (size_t)0,
+                           h->slab_bytes, 0);
+        const int rest = (int)0x80000000;
+        HIPCHK(h, hipMemcpyAsync(ds_.maxkey, &rest, sizeof rest, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(eig, ds_.eig, sizeof(float) * d.W * d.H, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
 }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-end measurement set (run on the GPU box through gpurun): PMC traffic, kernel-trace summaries, the bench lines.
 # usage: tools/measure_all.sh <out dir under gpurun_out/>
-# NOTE: rocprofv3 --pmc serialises kernels across queues; a kernel that polls a device-side counter another queue's kernel bumps (stage_gate_kernel,
-# the refill half of book-keeping) then waits for its 30 s time-out.  PMC passes of the pipelined single-stream path therefore run with
-# RVIO_NO_DEVFLAG=1 (stream-level events instead of the counters; same kernels otherwise).
+# NOTE: rocprofv3 --pmc serialises kernels across queues; the library sees ROCPROF_COUNTER_COLLECTION and switches its device-side polls (gate,
+# refill half of book-keeping) to stream-level events by itself for those passes (same kernels otherwise).
+#
 set -u
 OUT=gpurun_out/$1
 mkdir -p $OUT
@@ -11,23 +11,23 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 LEAN="--steps 20 --warmup 5 --no-cpu --no-streams --no-latency --batch '' --batch-streams ''"
 for C in ${PMC_CONFIGS:-B}; do
   for P in FETCH_SIZE WRITE_SIZE; do
-    eval RVIO_NO_DEVFLAG=1 timeout 240 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_${C}_$P -o p -- python bench.py $LEAN --config $C > /dev/null 2>&1
+    eval timeout -k 5 240 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_${C}_$P -o p -- python bench.py $LEAN --config $C > /dev/null 2>&1
   done
   F=$(find $OUT/pmc_${C}_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_${C}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
   python tools/pmc_traffic.py $F $W --json $OUT/pmc_traffic_cfg$C.json > $OUT/pmc_traffic_cfg$C.md 2>&1
-  cp $OUT/pmc_traffic_cfg$C.json profiles/r03_pmc_traffic_cfg$C.json
+  cp $OUT/pmc_traffic_cfg$C.json profiles/r04_pmc_traffic_cfg$C.json
   rm -rf $OUT/pmc_${C}_FETCH_SIZE $OUT/pmc_${C}_WRITE_SIZE
 done
 # kernel trace of the driver's own command
-timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_profiled.json 2> /dev/null
+timeout -k 5 400 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_profiled.json 2> /dev/null
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/kernel_stats_driver_cmd.md > /dev/null; rm -rf $OUT/kt
 # kernel trace of the plain single-stream loop only (no secondary legs): the per-frame kernels
-eval timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --steps 200 --warmup 40 --no-cpu --no-streams --no-latency --batch "''" --batch-streams "''" > /dev/null 2>&1
+eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --steps 200 --warmup 40 --no-cpu --no-streams --no-latency --batch "''" --batch-streams "''" > /dev/null 2>&1
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/kernel_stats_stream.md > /dev/null; rm -rf $OUT/kt
 # batched filter at B = 2048
-eval timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --batch-streams "''" > /dev/null 2>&1
+eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --batch-streams "''" > /dev/null 2>&1
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/batched_kernel_stats.md --grid-z 2048 > /dev/null; rm -rf $OUT/kt
-eval timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT/pm -o m -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --batch-streams "''" > /dev/null 2>&1
+eval timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT/pm -o m -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --batch-streams "''" > /dev/null 2>&1
 python tools/pmc_table.py $(find $OUT/pm -name "*counter_collection.csv" | head -1) --min-workgroups 2048 > $OUT/batched_mfma_counters.md 2>&1; rm -rf $OUT/pm
 # the bench lines
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
