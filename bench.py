@@ -523,7 +523,7 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     for c in cands + [detector]:
         c["frac"] = None if c["achieved"] is None else c["achieved"] / c["peak"]
         # HBM-side bytes per launch: PMC counters cannot be read live, so this is the committed rocprofv3 --pmc result OF THIS CONFIGURATION
-        # (profiles/r03_pmc_traffic_cfg<name>.json: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
+        # (profiles/r04_pmc_traffic_cfg<name>.json, else r03_: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
         c["traffic"], c["traffic_unit"] = pmc_traffic(name, c.pop("match"))
     cands.sort(key=lambda c: -c["avg_us"])
     res["roofline"] = dict(cands[0], dominant_by="largest live average among the hot path's longest kernels (rvio_hip_debug_time_kernel)",
@@ -536,7 +536,9 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
 
 def pmc_traffic(cfg_name, kernel_substr):
     """(bytes per launch, source) of a kernel from the committed rocprofv3 --pmc summary of THIS configuration, or (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg%s.json" % cfg_name)
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_cfg%s.json" % cfg_name)
+    if not os.path.exists(path):      # (configurations whose PMC pass was not repeated this round keep last round's: same kernels)
+        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg%s.json" % cfg_name)
     try:
         with open(path) as fh:
             e = [v for k, v in json.load(fh).items() if kernel_substr in k]
