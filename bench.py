@@ -156,6 +156,7 @@ def main():
                     help="feed a caller-side corner list (projected landmarks) instead of running the device detector")
     ap.add_argument("--batch", default="1,16,256,2048", help="instance counts of the batched-filter leg (SURVEY.md 8d (ii)); '' skips it")
     ap.add_argument("--batch-streams", default="1,16,128", help="instance counts of the batched camera-stream leg (whole frame, B streams per launch); '' skips it")
+    ap.add_argument("--no-defined-load", action="store_true", help="skip the batched filter at SURVEY 8d's defined load (profiling passes of the natural-flow leg)")
     ap.add_argument("--streams", type=int, default=8, help="independent filter instances for the aggregate-throughput leg")
     ap.add_argument("--stream-threads", type=int, default=1, help="host threads issuing the launches of the aggregate-throughput leg")
     args = ap.parse_args()
@@ -375,7 +376,7 @@ def main():
         if args.batch:
             safe_leg(out, "batched_filter", batched_filter_leg, cfg, torch, [b for b in args.batch.split(",") if b], name=args.config)
             big = [parse_batch_size(b)[0] for b in args.batch.split(",") if b and parse_batch_size(b)[0] >= 256 and parse_batch_size(b)[1] == 1]
-            if big:
+            if big and not args.no_defined_load:
                 safe_leg(out, "batched_filter_at_defined_load", batched_at_load_leg, cfg, torch, big[-1:], name=args.config)
         if not args.no_cpu:
             _CFG_NAME[0] = args.config

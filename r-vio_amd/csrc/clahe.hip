@@ -72,30 +72,32 @@ __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* _
 // packed in pairs (a counter sees one lane column of the tile, ceil(tw / 64) th pixels <= 65535; 256 x 32 words = 32 KB, five workgroups per CU), so an instruction's 64 additions go to
 // 64 different counters (two lanes share a word: a two-way conflict at worst), and the four waves of the workgroup meet only by coincidence.
 // The counts are integers: the same histogram, hence the same LUT bit for bit.  256 threads: wave <-> every fourth row of the tile.
-#define CLAHE_LUT2_T 256
-__global__ __launch_bounds__(CLAHE_LUT2_T) void clahe_lut_kernel2(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
-                                                                  int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs, int dbg_tag) {
+// T threads: 256 for batch handles (five workgroups per CU), 1024 for one stream (the tile's latency: 16 waves share the rows).
+template <int T>
+__global__ __launch_bounds__(T) void clahe_lut_kernel2(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
+                                                       int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs, int dbg_tag) {
     DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 0);
     src = zoff(src, src_bs); lut = zoff(lut, bs);
+    constexpr int NWV = T / 64;
     __shared__ unsigned hist2[256 * 32];
-    __shared__ int s_w[4];
+    __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t = blockIdx.x, ty = t / tiles_x, tx = t % tiles_x;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) hist2[tid + 256 * k] = 0u;
+    for (int k = 0; k < 256 * 32 / T; ++k) hist2[tid + T * k] = 0u;
     __syncthreads();
     const unsigned one = 1u << (16 * (lane & 1));
     unsigned* const mine = hist2 + (lane >> 1);
-    // four rows x 64 columns of byte loads in flight before the LDS additions
+    // four rows x 64 columns of byte loads in flight before the LDS additions; wave <-> every NWV-th row
     for (int c0 = 0; c0 < tw; c0 += 64) {
         const int c = c0 + lane;
         const bool cok = c < tw;
         const int xs = reflect1(tx * tw + (cok ? c : 0), w);
-        for (int r0 = wv; r0 < th; r0 += 16) {
+        for (int r0 = wv; r0 < th; r0 += 4 * NWV) {
             int v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r = r0 + 4 * j;
+                const int r = r0 + NWV * j;
                 v[j] = (cok && r < th) ? (int)src[(size_t)reflect1(ty * th + r, h) * stride + xs] : -1;
             }
 #pragma unroll
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(CLAHE_LUT2_T) void clahe_lut_kernel2(const uint8_t*
     }
     __syncthreads();
     int hv = 0;
-    {   // bin tid: the sum of its 64 counters (the 32 words read in a rotated order: consecutive bins sit 32 words apart)
+    if (tid < 256) {   // bin tid: the sum of its 64 counters (the 32 words read in a rotated order: consecutive bins sit 32 words apart)
         unsigned lo = 0, hi = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) { const unsigned q = hist2[tid * 32 + ((k + tid) & 31)]; lo += q & 0xffffu; hi += q >> 16; }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(CLAHE_LUT2_T) void clahe_lut_kernel2(const uint8_t*
     const int sum = block_exscan(hv, &total, s_w) + hv;      // inclusive
     int v = (int)rintf((float)sum * lut_scale);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    lut[(size_t)t * 256 + tid] = (uint8_t)v;
+    if (tid < 256) lut[(size_t)t * 256 + tid] = (uint8_t)v;
 }
 
 #define CLAHE_MAX_TILES 64
