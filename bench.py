@@ -593,7 +593,7 @@ def update_at_load_leg(cfg, torch, name="B", reps=60):
         h.set_state(x1, P1)
         h.update_tracked()
         h.sync()
-        kern = {k: h.time_kernel(w, 20) for k, w in (("feat_build", 2), ("gram_reduce", 3), ("solve", 0), ("ug", 4), ("final", 5))}
+        kern = {k: h.time_kernel(w, 20) for k, w in (("feat_build", 2), ("gram_reduce", 3), ("solve", 0), ("ug", 4), ("final", 5), ("ug_final_as_launched", 7))}
         w_alg = filter_flops(cfg, n, lens, types, 0)    # W_filter of SURVEY.md 8d for exactly these tracks (update only: m = 0)
         p50 = float(np.median(ts))
         res[mix] = {"n_feat": int(len(types)), "n_feat_accepted": int(info["n_feat_accepted"]), "n_rows": int(info["n_rows"]),

@@ -305,7 +305,8 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy);
  * of `iters` back-to-back launches of one hot kernel on the operands the last frame left in HBM.
  * which: 0 = solve kernel, 1 = KLT kernel (the current image matched back onto the previous one from the current feature positions),
  * 2 = per-feature Jacobian/nullspace/gate kernel, 3 = reduction of the per-feature information shares (+ rank truncation),
- * 4 = U/G/P1 strips, 5 = Joseph-form kernel (4, 5: in the form this handle launches), 6 = cornerSubPix on the last corner list. */
+ * 4 = U/G/P1 strips, 5 = Joseph-form kernel (4, 5: the two-launch forms), 6 = cornerSubPix on the last corner list,
+ * 7 = U/G/P1 + Joseph form as this handle launches them for an update (one instance, 6n <= 60: one fused kernel). */
 int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us);
 /* Test hook against results that depend on LEFT-OVER state (scratch in HBM, LDS contents, stale hand-over entries).  Drains every stream of
  * the handle, then: what & 1 fills the filter's scratch and the spare state / covariance buffer with 0xff bytes (NaN); & 2 rewrites the LDS

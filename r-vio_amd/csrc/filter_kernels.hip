@@ -1704,3 +1704,168 @@ __global__ __launch_bounds__(256) void final_lds_kernel(DevCfg cfg, int n, const
         }
     }
 }
+
+// =============================================================== round 4: the two stages above in ONE launch (single instance, 6n <= 60)
+// ug_lds_kernel + final_lds_kernel are two launches on the filter stream's serial chain (9.8 + 9.8 us and the boundary between them; U, G and P1
+// travel through L2 in between).  Here one workgroup owns an unordered tile pair (I, J) of P+ from the operands to the result: it forms the
+// strips it needs itself — U_I, U_J = Pc W;  G_I, G_J = U A;  P1c_I, P1c_J = Pc - G Pcc (the clone columns of P1 = P - G Pc^T) — and then
+//      X(I, J) = (P(I, J) - G_I Pc_J^T) - P1c_I G_J^T + s2 G_I U_J^T,        P+(I, J) = .5 (X(I, J) + X(J, I)^T)
+// exactly as the two kernels do (same operand order in every product, the same rounded intermediate P1 tile), so the result is theirs bit for
+// bit.  The strips are recomputed by every pair that touches them (~3.5x the products of the two-kernel form, spread over 21 CUs instead of 6).
+// Measured (tools/solve_probe.py, full-load update at cfg B): 16.8 us against 9.2 + 8.9 us for the two launches — the workgroup is bound by
+// its 480 FP64 MFMAs on four SIMDs (64 cycles each) plus the operand reads in front of every chain (loads 10.5 k cycles, the three strip
+// rounds ~7 k each, the closing stage 4.3 k) —, so what the fusion buys the pipelined frame is one launch boundary and one launch less for
+// the host: +1-2 % frames/s in same-box A/Bs (8.39 / 8.42 k against 8.32 / 8.30 k; a box whose host is the limit: 7.58 / 7.70 against 7.56 / 7.53).
+#define JL_LS 61
+#define JL_LDS_DOUBLES (3 * 60 * JL_LS + 8 * 16 * JL_LS + 16)
+__global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W, const double* __restrict__ Ab,
+                                                         double* __restrict__ Pout) {
+    extern __shared__ __align__(16) double jl[];
+    constexpr int LS = JL_LS;
+    double* const Wl = jl;                         // W[k][j]      (c6 x c6)
+    double* const Al = Wl + 60 * LS;               // A[k][j]
+    double* const Ccl = Al + 60 * LS;              // Pcc[c][k] = P[24 + c][24 + k]
+    // strips I (s = 0) and J (s = 1), 16 x LS each, strip s at base + s * 16 * LS
+    double* const PcS = Ccl + 60 * LS;             // Pc strips: Pc[r][k] = P[r][24 + k]
+    double* const Us = PcS + 2 * 16 * LS;
+    double* const Gs = Us + 2 * 16 * LS;
+    double* const Qs = Gs + 2 * 16 * LS;           // P1c strips
+    constexpr int SS = 16 * LS;                    // strip stride
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    DBG_R(blockIdx.x == 0, 3);
+    const int nt = (d + 15) / 16;
+    int I = 0, rem = blockIdx.x;
+    while (rem >= nt - I) { rem -= nt - I; ++I; }
+    const int J = I + rem;
+    const int r0[2] = {I * 16, J * 16};
+    DBG_T(20);
+    double p0[4] = {0, 0, 0, 0}, p0t[4] = {0, 0, 0, 0};   // wave 0: the P tiles of the closing stage, in flight from the start — p0[q] = P(I16 + lk + 4q, J16 + li),
+    if (wave == 0) {                                        // p0t[q] = P(J16 + li, I16 + lk + 4q) (the (J, I) tile in the transposed lane layout)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = r0[0] + lk + 4 * q, c = r0[1] + li;
+            const bool ok = row < d && c < d;
+            p0[q] = ok ? P[(size_t)row + (size_t)c * ld] : 0.0;
+            p0t[q] = ok ? P[(size_t)c + (size_t)row * ld] : 0.0;
+        }
+    }
+    {   // ONE batch of coalesced loads: W, A (row-major, ld = ldh), Pcc and the two Pc strips (column-major sources)
+        double vw[15], va[15], vc[15], vs[8];
+#pragma unroll
+        for (int u = 0; u < 15; ++u) {
+            const int e = tid + u * 256, k = e / 60, j = e - k * 60;            // 3600 = 60 x 60 elements
+            const bool ok = e < 3600 && k < c6 && j < c6;
+            vw[u] = ok ? W[(size_t)k * ldh + j] : 0.0;
+            va[u] = ok ? Ab[(size_t)k * ldh + j] : 0.0;
+            vc[u] = ok ? P[(size_t)(24 + j) + (size_t)(24 + k) * ld] : 0.0;      // element (row c = j, k) of Pcc read down column k: consecutive threads, consecutive rows
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;     // 2 strips x 60 columns x 16 rows
+            const int row = r0[sidx & 1] + rr;
+            vs[u] = (e < 1920 && k < c6 && row < d) ? P[(size_t)row + (size_t)(24 + k) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 15; ++u) {
+            const int e = tid + u * 256, k = e / 60, j = e - k * 60;
+            if (e < 3600) { Wl[k * LS + j] = vw[u]; Al[k * LS + j] = va[u]; Ccl[j * LS + k] = vc[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;
+            if (e < 1920) PcS[(sidx & 1) * SS + rr * LS + k] = vs[u];
+        }
+    }
+    __syncthreads();
+    DBG_T(21);
+    const int ntj = (c6 + 15) / 16;
+    // strip products: out[s][row][c] = sum_k X[s][row][k] * Y(k, c) for the 2 strips x ntj column tiles.  A wave takes tiles `wave` and `wave + 4`
+    // TOGETHER: all operands of both in flight, then the two accumulation chains interleaved (a lone chain of dependent FP64 MFMAs leaves the
+    // matrix pipe idle between issues; the pipe of one SIMD — 64 cycles per 16x16x4 — is what bounds this kernel).  Yt: Y(k, c) = Ym[c * LS + k]
+    auto strips = [&](const double* X, const double* Ym, bool Yt, double* out, const double* sub) {
+        const int t0 = wave, t1 = wave + 4, ntile = 2 * ntj;
+        const int s0 = t0 / ntj, c0 = (t0 - s0 * ntj) * 16 + li, s1 = t1 / ntj, c1 = (t1 - s1 * ntj) * 16 + li;
+        const bool v0 = t0 < ntile, v1 = t1 < ntile;
+        double a0[16], b0[16], a1[16], b1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = 4 * u + lk;
+            const bool kok = k < c6;
+            a0[u] = (kok && v0) ? X[s0 * SS + li * LS + k] : 0.0;
+            b0[u] = (kok && v0 && c0 < c6) ? (Yt ? Ym[c0 * LS + k] : Ym[k * LS + c0]) : 0.0;
+            a1[u] = (kok && v1) ? X[s1 * SS + li * LS + k] : 0.0;
+            b1[u] = (kok && v1 && c1 < c6) ? (Yt ? Ym[c1 * LS + k] : Ym[k * LS + c1]) : 0.0;
+        }
+        d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = lk + 4 * q;
+            if (v0 && c0 < c6) out[s0 * SS + row * LS + c0] = sub ? (sub[s0 * SS + row * LS + c0] - acc0[q]) : acc0[q];
+            if (v1 && c1 < c6) out[s1 * SS + row * LS + c1] = sub ? (sub[s1 * SS + row * LS + c1] - acc1[q]) : acc1[q];
+        }
+    };
+    strips(PcS, Wl, false, Us, nullptr);             // U = Pc W
+    __syncthreads();
+    DBG_T(22);
+    strips(Us, Al, false, Gs, nullptr);              // G = U A
+    __syncthreads();
+    DBG_T(23);
+    strips(Gs, Ccl, true, Qs, PcS);                  // P1c = Pc - G Pcc^T  (P1[r][24 + c] = P[r][24 + c] - sum_k G[r][k] Pc[24 + c][k])
+    __syncthreads();
+    DBG_T(24);
+    // The closing stage: six 16 x 16 x 60 products — for X(I, J): a = G_I Pc_J^T, b = P1c_I G_J^T, c = G_I U_J^T; for X(J, I) the same with
+    // the strips exchanged — spread over the four waves (products w and w + 4), parked in LDS (W's buffer: W is dead), combined by wave 0 in
+    // the two kernels' order:  x = ((p0 - a) - b) + s2 c,  P+(I, J) = .5 (x_IJ + x_JI^T).   I == J: three products, x_JI = x_IJ.
+    double (*const xt)[16][17] = reinterpret_cast<double (*)[16][17]>(Wl);
+    const int nprod = (I == J) ? 3 : 6;
+    auto product = [&](int pidx) -> d4 {
+        const int sa = pidx / 3, sb = sa ^ 1, kind = pidx - 3 * sa;       // rows of strip sa, columns of strip sb
+        const int i0 = r0[sa], c = r0[sb] + li;
+        const double* Xa = (kind == 1 ? Qs : Gs) + sa * SS;
+        const double* Yb = (kind == 0 ? PcS : (kind == 1 ? Gs : Us)) + sb * SS;
+        const bool rowok = kind == 0 || i0 + li < d;
+        double a1[16], b1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; a1[u] = (k < c6 && rowok) ? Xa[li * LS + k] : 0.0; b1[u] = (k < c6 && c < d) ? Yb[li * LS + k] : 0.0; }
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+        return acc;
+    };
+    {
+        const bool two = wave + 4 < nprod;
+        d4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+        if (wave < nprod) pa = product(wave);
+        if (two) pb = product(wave + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (wave < nprod) xt[wave][lk + 4 * q][li] = pa[q];
+            if (two) xt[wave + 4][lk + 4 * q][li] = pb[q];
+        }
+    }
+    __syncthreads();
+    DBG_T(25);
+    if (wave == 0) {
+        const int o = (I == J) ? 0 : 3;              // tiles of X(J, I) (X(I, I) itself on the diagonal)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = lk + 4 * q, row = I * 16 + rr, col = J * 16 + li;
+            const double p1 = p0[q] - xt[0][rr][li];
+            const double xij = p1 - xt[1][rr][li] + s2 * xt[2][rr][li];
+            const double p1t = p0t[q] - xt[o][li][rr];
+            const double xji = p1t - xt[o + 1][li][rr] + s2 * xt[o + 2][li][rr];      // element (row li of strip J, column rr of strip I) of X(J, I)
+            const double v = .5 * (xij + xji);
+            if (row < d && col < d) {
+                Pout[(size_t)row + (size_t)col * ld] = v;
+                if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+            }
+        }
+    }
+}

@@ -584,6 +584,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)ug_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UGL_LDS_DOUBLES * sizeof(double))));
         HIPCHK(h, hipFuncSetAttribute((const void*)final_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FNL_LDS_DOUBLES * sizeof(double))));
+        HIPCHK(h, hipFuncSetAttribute((const void*)joseph_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(JL_LDS_DOUBLES * sizeof(double))));
     }
     if (batch > 1 && !h->solve5_variant && !h->solve7_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -926,8 +927,11 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     double* Pc = h->P[h->cur];
     const int nt = (dd + 15) / 16, npair = nt * (nt + 1) / 2;
     static const bool no_ugl = ab_env("RVIO_NO_UGL") != nullptr;   // A/B timing
+    static const bool no_jl = ab_env("RVIO_NO_JOSEPH_LDS") != nullptr;   // A/B timing
     if (h->jb_lds && ug && fin) {   // batch handle, 6n <= 60: P -> P+ in one kernel (U, G, P1 never leave the CU)
         hipLaunchKernelGGL(joseph_batch_kernel, dim3(1, 1, B), dim3(JB_THREADS), h->jb_lds, h->stream, d, n, Pc, h->W, Ab, Pn, bs);
+    } else if (B == 1 && c6 <= 60 && ug && fin && !no_jl) {   // one instance, short window: both stages in ONE launch, a workgroup per tile pair of P+
+        hipLaunchKernelGGL(joseph_lds_kernel, dim3(npair), dim3(256), JL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, Pn);
     } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
         if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
         if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
@@ -1864,6 +1868,8 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
                                h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);
         } else if (which == 4 || which == 5) {   // U, G, P1 strips / the Joseph form on the operands of the last update, in the form the handle launches
             launch_ug_final(h, n, h->block, h->P[h->cur ^ 1], which == 4, which == 5);   // (outputs: scratch / the spare covariance buffer, overwritten by the next stage anyway)
+        } else if (which == 7) {   // U, G, P1 + the Joseph form as the handle launches them for a whole update (one instance, 6n <= 60: ONE kernel)
+            launch_ug_final(h, n, h->block, h->P[h->cur ^ 1], true, true);
         } else if (which == 6) {   // cornerSubPix on the corners of the last detector call (reads raw_xy, rewrites xy with the same values)
             if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
             const DetDev q = [&] { DetDev v = h->dets[h->det_set_last]; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();

@@ -31,4 +31,7 @@ print("solve phases (cycles):", " ".join("%d->%d:%d" % (a, b, t[b] - t[a]) for a
 print("wall clock inside the kernel (us): start -> thread 0 done %.2f, -> last thread done %.2f" % ((t[46] - t[45]) / 100.0, (t[47] - t[45]) / 100.0))
 h.set_state(x1, P1); h.update_tracked(); h.sync()
 print("solve kernel live avg us:", h.time_kernel(0, 50))
+idx = [i for i in (20, 21, 22, 23, 24, 25) if t[i] != 0]
+print("joseph_lds phases (cycles): loads %d  U %d  G %d  P1c %d  X %d" % tuple(t[b] - t[a] for a, b in zip(idx[:-1], idx[1:])) if len(idx) == 6 else "joseph_lds: not launched")
+print("ug %.2f us, final %.2f us (two-launch forms); as launched %.2f us" % (h.time_kernel(4, 50), h.time_kernel(5, 50), h.time_kernel(7, 50)))
 h.close()
