@@ -23,17 +23,20 @@ __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
 //  A  lane s <-> IMU sample s: trig, dR, f1..f4 and the two a-dependent vectors (parallel)
 //  B  the serial chain Rk <- dR Rk, dp, dv, pk, vk, gk in reference order (all threads, no broadcast)
 //  C  the ten non-trivial 3x3 blocks of rows 9..17 of Phi = I + dt F (PreIntegrator.cc:123-132), thread <-> (sample, i, j)
-//  D  per sample: rows 9..17 of Phi P and of Phi Psi, then columns 9..17 of (Phi P) Phi^T + Q — using only the
-//     4 / 7 / 13 non-zeros of a theta / p / v row of Phi
-#define PROP3_CH 16
+//  D  (round 4) the chunk's transition composed first — suffix products of the Phi_s, one barrier per sample —, then applied to P once:
+//     P <- Psi_c P Psi_c^T + sum_s S_s Q_s S_s^T  (rounds 1-3: sample by sample, four barriers each)
 struct Prop3Sample { double dR[9], up[3], uv[3], w[3], dt, Rk[9], vk[3], gk[3]; };
 
+template <int PROP3_CH = 16>     // samples composed per chunk: 16 for one stream (one chunk at 200 Hz / 20 Hz), 8 for batch handles (47 instead of 86 KB of LDS: two workgroups per CU)
 __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
     meta = zoff(meta, bs); x = zoff(x, bs); P = zoff(P, bs); imu = zoff(imu, imu_bs);
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
     __shared__ double Phi9[PROP3_CH][9][25];
+    __shared__ double Sx[PROP3_CH][9][25];      // rows 9..17 of the suffix products S_s = Phi_{mc-1} ... Phi_{s+1}
+    __shared__ double PsiC[9][25];              // ... and of the chunk's Psi_c = S_0 Phi_0
+    __shared__ double Nq[PROP3_CH][15][6];      // S_s[9..23, (theta, v)] Qd_s
     __shared__ double vxs[PROP3_CH][9];
     __shared__ Prop3Sample sm[PROP3_CH];
     __shared__ double xs[26];
@@ -46,7 +49,9 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         Psi[i][j] = (i == j) ? 1.0 : 0.0;
     }
     if (tid < 26) xs[tid] = x[tid];
+    DBG_T(10);
     __syncthreads();
+    DBG_T(11);
     const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
     const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
     m33 Rk = q2r(ldq(xs + 10)), RkT = tr33(Rk);
@@ -55,14 +60,11 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     const m33 I = eye33();
     const double nG = cfg.gravity;
     double Dt = 0;
-    // this thread's (row r9 of Phi rows 9..17, column c9) and the non-zero k-segments of that row
-    const int r9 = tid / 24, c9 = tid % 24, br = r9 / 3, ri = r9 % 3;
-    int sA0, sAn, sB0, sBn, sC0, sCn;
-    if (br == 0) { sA0 = 9; sAn = 3; sB0 = 18 + ri; sBn = 1; sC0 = 0; sCn = 0; }
-    else if (br == 1) { sA0 = 9; sAn = 3; sB0 = 12 + ri; sBn = 1; sC0 = 15; sCn = 3; }
-    else { sA0 = 6; sAn = 6; sB0 = 15; sBn = 6; sC0 = 21 + ri; sCn = 1; }
+    // this thread's (row r9 of rows 9..17, column c9)
+    const int r9 = tid / 24, c9 = tid % 24;
     for (int s0 = 0; s0 < m; s0 += PROP3_CH) {
         const int mc = (m - s0 < PROP3_CH) ? (m - s0) : PROP3_CH;
+        for (int e = tid; e < mc * 9 * 25; e += 256) (&Phi9[0][0][0])[e] = 0.0;     // the structural zeros of rows 9..17 of Phi (phase C writes the others)
         // ---- A
         if (tid < mc) {
             const rvio_imu u = imu[s0 + tid];
@@ -93,6 +95,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
             st3(q.w, w); q.dt = dt;
         }
         __syncthreads();
+        DBG_T(12);
         // ---- B
         for (int s = 0; s < mc; ++s) {
             Prop3Sample& q = sm[s];
@@ -112,6 +115,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
             gk = unit3(mv33(Rk, gR));
         }
         __syncthreads();
+        DBG_T(13);
         // ---- C: thread <-> (sample s, i, j)
         for (int e = tid; e < mc * 9; e += 256) {
             const int s = e / 9, i = (e % 9) / 3, j = e % 3;
@@ -128,44 +132,95 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
             vxs[s][3 * i + j] = vxe;
         }
         __syncthreads();
-        // ---- D
-        for (int s = 0; s < mc; ++s) {
-            const double dt = sm[s].dt;
-            const double (*ph)[25] = Phi9[s];
-            double accP = 0, accS = 0;
+        DBG_T(14);
+        // ---- D (round 4): the chunk's samples are COMPOSED first and applied to P once.  Rounds 1-3 applied them one by one — P <- Phi_s P
+        // Phi_s^T + Q_s with four barriers per sample: ten dependent steps, 25 of the kernel's 30 us.  Phi_s = I + (rows 9..17), and such
+        // matrices are closed under multiplication, so with  S_s = Phi_{mc-1} ... Phi_{s+1}  (S_{mc-1} = I) and  Psi_c = S_0 Phi_0:
+        //      P <- Psi_c P Psi_c^T + sum_s S_s Q_s S_s^T            (the same matrix as the sample-by-sample recursion, re-associated)
+        // The suffix products are a chain of 9 x 9 x 24 products with ONE barrier per sample; everything else is parallel over the samples.
+        if (tid < 216) Sx[mc - 1][r9][c9] = (c9 == 9 + r9) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int s = mc - 2; s >= -1; --s) {       // s = -1: Psi_c
+            double acc = 0;
             if (tid < 216) {
-                for (int k = sA0; k < sA0 + sAn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
-                for (int k = sB0; k < sB0 + sBn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
-                for (int k = sC0; k < sC0 + sCn; ++k) { const double f = ph[r9][k]; accP += f * Pl[k][c9]; accS += f * Psi[k][c9]; }
+                const double (*S1)[25] = Sx[s + 1];
+                const double (*ph)[25] = Phi9[s + 1];
+                acc = (c9 >= 9 && c9 < 18) ? 0.0 : S1[r9][c9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += S1[r9][9 + k] * ph[k][c9];
+                if (s >= 0) Sx[s][r9][c9] = acc; else PsiC[r9][c9] = acc;
             }
-            __syncthreads();
-            if (tid < 216) { Pl[9 + r9][c9] = accP; Psi[9 + r9][c9] = accS; }
-            __syncthreads();
-            double accC = 0;
-            if (tid < 216) {
-                for (int k = sA0; k < sA0 + sAn; ++k) accC += Pl[c9][k] * ph[r9][k];
-                for (int k = sB0; k < sB0 + sBn; ++k) accC += Pl[c9][k] * ph[r9][k];
-                for (int k = sC0; k < sC0 + sCn; ++k) accC += Pl[c9][k] * ph[r9][k];
-                // Q = dt G Sigma G^T (PreIntegrator.cc:135-140), non-zero blocks only
-                const int i = c9, j = 9 + r9;
-                const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
-                const double* vx = vxs[s];
-                if (bi == 3 && bj == 3) accC += (ii == jj) ? dt * cfg.sg2 : 0.0;
-                else if (bi == 3 && bj == 5) accC += dt * cfg.sg2 * vx[3 * jj + ii];
-                else if (bi == 5 && bj == 3) accC += dt * cfg.sg2 * vx[3 * ii + jj];
-                else if (bi == 5 && bj == 5) {
-                    double q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] +
-                               ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
-                    if (ii == jj) q += dt * cfg.sa2;
-                    accC += q;
-                }
-            }
-            __syncthreads();
-            if (tid < 216) Pl[c9][9 + r9] = accC;
-            if (tid >= 216 && tid < 219) Pl[18 + tid - 216][18 + tid - 216] += dt * cfg.swg2;
-            if (tid >= 219 && tid < 222) Pl[21 + tid - 219][21 + tid - 219] += dt * cfg.swa2;
             __syncthreads();
         }
+        DBG_T(15);
+        // Psi <- Psi_c Psi (rows 9..17; the other rows of both are identity rows) and X = rows 9..17 of Psi_c P
+        double accS = 0, accP = 0;
+        if (tid < 216) {
+            accS = (c9 >= 9 && c9 < 18) ? 0.0 : PsiC[r9][c9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) accS += PsiC[r9][9 + k] * Psi[9 + k][c9];
+#pragma unroll
+            for (int k = 6; k < 24; ++k) accP += PsiC[r9][k] * Pl[k][c9];      // (columns 0..5 of rows 9..17 are structurally zero)
+        }
+        // N_s = S_s[9..23, A6] Qd_s  with A6 = (theta, v) = columns 9, 10, 11, 15, 16, 17 and Qd_s the dense 6 x 6 block of Q_s = dt G Sigma G^T
+        // (PreIntegrator.cc:135-140: theta-theta dt sg2 I, theta-v / v-theta dt sg2 [v]x terms, v-v dt sg2 [v]x [v]x^T + dt sa2 I)
+        for (int e = tid; e < mc * 90; e += 256) {
+            const int s = e / 90, rem = e - s * 90, ip = rem / 6, b = rem - ip * 6;       // row i = 9 + ip, column A6[b]
+            const double dt = sm[s].dt;
+            const double* vx = vxs[s];
+            const int bb = b / 3, jj = b % 3;
+            double acc = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int ba = a / 3, ii = a % 3, ca = (ba ? 15 : 9) + ii;
+                const double sv = (ip < 9) ? Sx[s][ip][ca] : 0.0;                             // rows 18..23 of S_s are unit rows: zero in the A6 columns
+                double q;
+                if (ba == 0 && bb == 0) q = (ii == jj) ? dt * cfg.sg2 : 0.0;
+                else if (ba == 0 && bb == 1) q = dt * cfg.sg2 * vx[3 * jj + ii];
+                else if (ba == 1 && bb == 0) q = dt * cfg.sg2 * vx[3 * ii + jj];
+                else {
+                    q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] + ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
+                    if (ii == jj) q += dt * cfg.sa2;
+                }
+                acc += sv * q;
+            }
+            Nq[s][ip][b] = acc;
+        }
+        __syncthreads();
+        if (tid < 216) { Psi[9 + r9][c9] = accS; Pl[9 + r9][c9] = accP; }
+        __syncthreads();
+        double accC = 0;
+        if (tid < 216) {
+#pragma unroll
+            for (int k = 6; k < 24; ++k) accC += Pl[c9][k] * PsiC[r9][k];
+        }
+        // T = sum_s S_s Q_s S_s^T on rows / columns 9..23: thread <-> entry (i, j)
+        double accT = 0;
+        const int ti = tid / 15, tj = tid - ti * 15;
+        if (tid < 225) {
+            for (int s = 0; s < mc; ++s) {
+                const double dt = sm[s].dt;
+                double t = 0;
+                if (tj < 9) {
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) t += Nq[s][ti][b] * Sx[s][tj][(b < 3 ? 9 : 12) + b];
+                }
+                // bias random walks: Q_s[a][a] = dt swg2 (a = 18..20), dt swa2 (21..23)
+                if (ti < 9 && tj < 9) {
+#pragma unroll
+                    for (int a = 18; a < 24; ++a) t += (Sx[s][ti][a] * (dt * (a < 21 ? cfg.swg2 : cfg.swa2))) * Sx[s][tj][a];
+                } else if (ti >= 9 && tj < 9) t += (dt * (ti < 12 ? cfg.swg2 : cfg.swa2)) * Sx[s][tj][9 + ti];
+                else if (ti < 9 && tj >= 9) t += Sx[s][ti][9 + tj] * (dt * (tj < 12 ? cfg.swg2 : cfg.swa2));
+                else if (ti == tj) t += dt * (ti < 12 ? cfg.swg2 : cfg.swa2);
+                accT += t;
+            }
+        }
+        __syncthreads();
+        if (tid < 216) Pl[c9][9 + r9] = accC;
+        __syncthreads();
+        if (tid < 225) Pl[9 + ti][9 + tj] += accT;
+        __syncthreads();
+        DBG_T(16);
     }
     if (tid == 0) {
         stq(x + 10, r2q(Rk));
@@ -193,6 +248,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
             P[(24 + c) + (size_t)(9 + r) * ld] = acc;
         }
     }
+    DBG_T(17);
 }
 
 __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
@@ -202,7 +258,7 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
 // batch handles: two workgroups per CU (256 VGPRs, part of the working set in scratch) — throughput, not latency
 __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                              double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
-    propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+    propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs);
 }
 
 // PreIntegrator::propagate and the per-feature stage of Updater::update in ONE launch (single instance, pipelined whole-frame path):
@@ -211,13 +267,14 @@ __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterM
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
 // pinv != NULL (instrumented build, RVIO_SOLVE8: the solve without a pivot search — measured, not adopted, solve8.hip): one more workgroup
 // inverts the clone block Pcc, the measurement-independent half of that solve (propagation leaves Pcc alone, so it is the Pcc the solve will see).
+template <int CH>      // propagate's chunk size (its LDS: 86 KB at 16, 47 KB at 8 — long windows need the room for the per-feature stage)
 __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
                                                         FilterMeta* meta, const rvio_imu* imu, int m, double* pinv) {
     DBG_R(blockIdx.x == 0, 0);
-    if (blockIdx.x == gridDim.x - 1) { propagate_body(cfg, meta, n, x, P, imu, m, 0, 0); return; }
+    if (blockIdx.x == gridDim.x - 1) { propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0); return; }
 #ifdef RVIO_DBG_CLOCKS
     if (pinv && blockIdx.x == gridDim.x - 2) { extern __shared__ __align__(16) double fp_dyn[]; pinv_role<4>(cfg, n, P, pinv, meta, fp_dyn); return; }
 #endif

@@ -146,6 +146,7 @@ struct rvio_hip {
     const rvio_imu* fuse_imu = nullptr;   // whole-frame path: propagate of this frame rides in the per-feature launch (feat_prop_kernel)
     int fuse_m = -1;                      // >= 0 while such a propagate is pending
     bool fuse_ok = false;
+    int fuse_ch = 0;                      // propagate's chunk size inside the fused launch (16 or 8: what fits beside the per-feature stage's LDS)
     bool one_stream = false;
     bool wide_px = false;            // throughput forms of the image kernels (several pixels per thread): batch handles of >= 8 instances
     bool front_end = true;           // a batch handle may carry the filter only
@@ -521,14 +522,23 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
     // (instrumented build: + the 18 KB of static LDS of solve8's inverse role, which also stages Pcc in the launch's dynamic LDS)
+    // propagate rides in the per-feature launch when both fit one CU's LDS: the dynamic per-feature footprint + the kernel's static LDS
+    // (propagate's composed-chunk buffers: 86 KB at 16 samples per chunk, 47 KB at 8; instrumented build: + solve8's inverse role)
+    h->fprop_lds = h->feat_lds;
 #ifdef RVIO_DBG_CLOCKS
     h->fprop_lds = std::max(h->feat_lds, (size_t)S8_PINV_LDS_DOUBLES * sizeof(double));
-    h->fuse_ok = batch == 1 && h->fprop_lds + 64 * 1024 <= 160 * 1024 && !ab_env("RVIO_NO_FUSED_PROPAGATE");
-#else
-    h->fprop_lds = h->feat_lds;
-    h->fuse_ok = batch == 1 && h->feat_lds + 46 * 1024 <= 160 * 1024;   // (+ propagate's 44 KB of static LDS)
 #endif
-    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
+    h->fuse_ch = 0;
+    if (batch == 1 && !ab_env("RVIO_NO_FUSED_PROPAGATE")) {
+        hipFuncAttributes a16, a8;
+        HIPCHK(h, hipFuncGetAttributes(&a16, (const void*)feat_prop_kernel<16>));
+        HIPCHK(h, hipFuncGetAttributes(&a8, (const void*)feat_prop_kernel<8>));
+        if (h->fprop_lds + a16.sharedSizeBytes <= 160 * 1024) h->fuse_ch = 16;
+        else if (h->fprop_lds + a8.sharedSizeBytes <= 160 * 1024) h->fuse_ch = 8;
+    }
+    h->fuse_ok = h->fuse_ch != 0;
+    if (h->fuse_ch == 16) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
+    if (h->fuse_ch == 8) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
@@ -837,9 +847,14 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const int B = h->batch;
     if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
         const bool pinv = h->solve8 && world == 1 && combine;   // (the unsharded update of this very launch follows: the solve will want Pcc^-1)
-        hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                           h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                           h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
+        if (h->fuse_ch == 16)
+            hipLaunchKernelGGL(feat_prop_kernel<16>, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
+        else
+            hipLaunchKernelGGL(feat_prop_kernel<8>, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
         h->pinv_ready = pinv;
         h->fuse_m = -1;
     } else

@@ -40,8 +40,12 @@ names = ["feat_prop", "gram", "solve", "ug", "final", "augcomp", "augcomp end", 
 r = np.array(rows, dtype=np.float64) / 100.0               # microseconds
 print("frames stamped:", last)
 print("period (feat_prop -> feat_prop): %.1f us" % np.mean(np.diff(r[:, 0])))
-for a in range(6):
-    print("%-12s -> %-12s %.1f us" % (names[a], names[a + 1], np.mean(r[1:, a + 1] - r[1:, a])))
+fused = bool(np.all(r[1:, 4] < r[1:, 3]))     # round 4: U / G / P1 and the Joseph form are ONE launch at 6n <= 60 (joseph_lds_kernel stamps slot 3 only; slot 4 keeps its old value)
+stages = [0, 1, 2, 3, 5, 6] if fused else [0, 1, 2, 3, 4, 5, 6]
+if fused:
+    names[3] = "joseph_lds"
+for a, b in zip(stages[:-1], stages[1:]):
+    print("%-12s -> %-12s %.1f us" % (names[a], names[b], np.mean(r[1:, b] - r[1:, a])))
 print("solve start -> solve end (thread 0): %.1f us; solve end -> ug start: %.1f us" % (np.mean(r[1:, 7] - r[1:, 2]), np.mean(r[1:, 3] - r[1:, 7])))
 print("augcomp end -> next feat_prop: %.1f us" % np.mean(r[1:, 0] - r[:-1, 6]))
 out2 = (C.c_longlong * 512)()

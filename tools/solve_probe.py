@@ -34,4 +34,8 @@ print("solve kernel live avg us:", h.time_kernel(0, 50))
 idx = [i for i in (20, 21, 22, 23, 24, 25) if t[i] != 0]
 print("joseph_lds phases (cycles): loads %d  U %d  G %d  P1c %d  X %d" % tuple(t[b] - t[a] for a, b in zip(idx[:-1], idx[1:])) if len(idx) == 6 else "joseph_lds: not launched")
 print("ug %.2f us, final %.2f us (two-launch forms); as launched %.2f us" % (h.time_kernel(4, 50), h.time_kernel(5, 50), h.time_kernel(7, 50)))
+h.propagate(seq.imu_between(39 + cfg.max_track_len + 9)); h.sync()
+h.L.rvio_hip_debug_clocks(h.h, out); t = np.array(list(out))
+idx = [i for i in range(10, 18) if t[i] != 0]
+print("propagate phases (cycles): " + " ".join("%d->%d:%d" % (a, b, t[b] - t[a]) for a, b in zip(idx[:-1], idx[1:])), "(10 start, 11 loads, 12 A trig, 13 B state chain, 14 C Phi rows, 15 suffix products, 16 apply + Q, 17 P12 + stores)")
 h.close()
