@@ -17,7 +17,6 @@
 #include "frontend_dev.h"
 #include "filter_kernels.hip"
 #include "filter_kernels2.hip"
-#include "solve4.hip"
 #include "solve6.hip"
 #include "solve7.hip"
 #ifdef RVIO_DBG_CLOCKS
@@ -65,9 +64,8 @@ struct rvio_hip {
     int* gvalid = nullptr;     // ... and the validity flag of each triangulation
     size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
     int feat_threads = 64;
-    size_t feat_lds = 0, fprop_lds = 0, solve_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
-    int solve_use_lds = 0, solve_nch = 1;
-    int solve5_variant = 0;      // 0: use solve4; 1: <1,16>  2: <2,24>  3: <2,32>
+    size_t feat_lds = 0, fprop_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
+    int solve5_variant = 0;      // solve6_kernel (the LDS-tableau solve behind gemm_T_kernel: batch handles): 0 none, 1: <1,8,8>  2: <2,12,8>  3: <2,16,8>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
@@ -308,7 +306,7 @@ static void fill_devcfg(const rvio_config* c, DevCfg* d) {
 }
 
 // The per-instance filter buffers (state, update scratch, Tracker -> Updater hand-over, IMU staging): called twice — sizes, then pointers
-static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
+static int alloc_filter_slab(rvio_hip* h, bool need_tm_global) {
     const DevCfg& d = h->dc;
     const size_t dm = d.dmax, PP = dm * dm, ldh = d.ldh;
     TrackerDev& t = h->t;
@@ -331,7 +329,6 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global, bool need_Mg) {
     if (need_tm_global) DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
     static const bool no_geom4 = ab_env("RVIO_NO_GEOM4") != nullptr;   // A/B timing
     if (h->batch > 1 && d.max_len <= GEOM4_ML && !no_geom4) { DALLOC(h, h->gpose, (size_t)d.Fu * (d.max_len - 1) * 24); DALLOC(h, h->gvalid, d.Fu); }
-    if (need_Mg) DALLOC(h, h->Mg, ldh * 2 * ldh);
     return RVIO_OK;
 }
 
@@ -464,11 +461,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         need_tm_global = true;
     }
     if (h->feat_lds > 160 * 1024) { h->err = "per-feature LDS footprint exceeds 160 KiB"; return RVIO_ERR_UNSUPPORTED; }
-    const size_t c6m = ldh - 1, NC = c6m + 1, ldm = NC | 1;
-    h->solve_lds = c6m * ldm * sizeof(double) + 1024;   // + slack: tail lanes of the last row read (never write) past the row
-    h->solve_use_lds = h->solve_lds <= 140 * 1024;
-    h->solve_nch = (NC <= 64) ? 1 : (NC <= 128 ? 2 : 3);
-    if (!h->solve_use_lds) h->solve_lds = 0;
+    const size_t c6m = ldh - 1;
     if (front_end && cfg->enable_equalizer) {   // CLAHE(3.0, 5x5), Tracker.cc:198-202
         h->cl_tx = 5; h->cl_ty = 5;
         int ew = d.W, eh = d.H;
@@ -481,7 +474,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     if (h->det_in_slab) { int rc = detector_check(h); if (rc != RVIO_OK) return rc; }
     // instance slab(s)
     h->slab_mode = true; h->slab = nullptr; h->slab_off = 0;
-    { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    { int rc = alloc_filter_slab(h, need_tm_global); if (rc != RVIO_OK) return rc; }
     if (front_end) { int rc = alloc_frontend_slab(h); if (rc != RVIO_OK) return rc; }
     h->slab_bytes = h->slab_off;
     {
@@ -491,7 +484,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         h->allocs.push_back(q);
         h->slab = (char*)q; h->slab_off = 0;
     }
-    { int rc = alloc_filter_slab(h, need_tm_global, !h->solve_use_lds); if (rc != RVIO_OK) return rc; }
+    { int rc = alloc_filter_slab(h, need_tm_global); if (rc != RVIO_OK) return rc; }
     if (front_end) { int rc = alloc_frontend_slab(h); if (rc != RVIO_OK) return rc; }
     h->slab_mode = false;
     h->bin = {0, h->slab_bytes, h->slab_bytes, h->slab_bytes, h->slab_bytes};
@@ -542,19 +535,13 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
-        if (h->solve_use_lds) {
-            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-            HIPCHK(h, hipFuncSetAttribute((const void*)solve4_kernel_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-        }
         {   // fully unrolled solve kernel: variants <column chunks, rows per wave> for c6 <= 126
             int rpw = 0, nch = 0, nw = 8;
             if (c6m <= 60) { h->solve5_variant = 1; nch = 1; rpw = 8; }
             else if (c6m <= 96) { h->solve5_variant = 2; nch = 2; rpw = 12; }
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
-            if (ab_env("RVIO_SOLVE4")) h->solve5_variant = 0;
             h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
-            if (ab_env("RVIO_SOLVE6") || ab_env("RVIO_SOLVE4")) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernels behind gemm_T_kernel
+            if (ab_env("RVIO_SOLVE6") && h->solve5_variant) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernel behind gemm_T_kernel
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
             // (round 3, measured and NOT adopted: solve7 with T through the L2 scratch instead of LDS — 11 KB of LDS, eight workgroups per CU, no gemm_T
@@ -924,14 +911,6 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         hipLaunchKernelGGL((solve6_kernel<2, 12, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
     else if (h->solve5_variant == 3)
         hipLaunchKernelGGL((solve6_kernel<2, 16, 8>), dim3(1, 1, h->batch), dim3(512), h->solve5_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->slab_bytes);
-    else if (!h->solve_use_lds)
-        hipLaunchKernelGGL(solve4_kernel_glb, dim3(1), dim3(SOLVE4_T), 0, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout, h->Mg);
-    else if (h->solve_nch == 1)
-        hipLaunchKernelGGL(solve4_kernel_lds<1>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
-    else if (h->solve_nch == 2)
-        hipLaunchKernelGGL(solve4_kernel_lds<2>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
-    else
-        hipLaunchKernelGGL(solve4_kernel_lds<3>, dim3(1), dim3(SOLVE4_T), h->solve_lds, h->stream, d, h->meta, n, h->Tbuf, Ab, xin, Pc, h->W, xout);
 }
 
 // U = Pc W, G = U A  (K H = [0 | G]);  Joseph form (Updater.cc:615-619): P1 = (I-KH) P,  P+ = sym(P1 - P1c G^T + s2 G U^T)
@@ -1941,7 +1920,6 @@ int rvio_hip_debug_poison(rvio_hip* h, int what) {
         HIPCHK(h, fill(h->gamma, sizeof(double) * d.Fu)); HIPCHK(h, fill(h->pfinv, sizeof(double) * 3 * d.Fu));
         HIPCHK(h, fill(h->nrows, sizeof(int) * d.Fu)); HIPCHK(h, fill(h->acc, sizeof(int) * d.Fu)); HIPCHK(h, fill(h->ndof, sizeof(int) * d.Fu));
         if (h->tm_global) HIPCHK(h, fill(h->tm_global, sizeof(double) * d.Fu * d.rho_max * ldh));
-        if (h->Mg) HIPCHK(h, fill(h->Mg, sizeof(double) * ldh * 2 * ldh));
         if (h->gpose) { HIPCHK(h, fill(h->gpose, sizeof(double) * d.Fu * (d.max_len - 1) * 24)); HIPCHK(h, fill(h->gvalid, sizeof(int) * d.Fu)); }
         HIPCHK(h, fill(h->x[h->cur ^ 1], sizeof(double) * d.xdmax)); HIPCHK(h, fill(h->P[h->cur ^ 1], sizeof(double) * PP));
     }

@@ -14,8 +14,9 @@
 //     maximum, which leaves the growth bound of partial pivoting unchanged for all practical purposes and is
 //     deterministic (replicas of the multi-GPU path stay bit-identical);
 //   * the candidate's reciprocal is published with its key, so the serial chain of a step contains no division.
-// No row swaps, deferred pivot scaling (see solve4.hip for the algebra):  T^-1[k][p_j] = M[p_k][j] / piv_k.
-// c6 <= 64*NCH - 1 and ceil(c6/NW) <= RPW <= 16; larger windows use solve4_kernel_glb.
+// No row swaps (step k uses the not-yet-used row p_k with the largest |M[i][k]|), deferred pivot scaling — every other row i: f = M[i][k] / piv,
+// M[i][j] -= f M[p][j] (j != k), M[i][k] = -f, then M[p][k] := 1 —:  T^-1[k][p_j] = M[p_k][j] / piv_k,  y[k] = M[p_k][c6] / piv_k.
+// c6 <= 64*NCH - 1 and ceil(c6/NW) <= RPW <= 16; larger windows use solve7_kernel (every window does on a plain handle).
 #pragma once
 #include "rvio_dev.h"
 

@@ -1,7 +1,7 @@
 // solve7.hip — T = s2 I + A Pcc, W = T^-1, y = W b, dx = Pc y, state injection  (Updater.cc:540-613), generation 7.
 //
 // One launch replaces gemm_T_kernel + solve6_kernel.  The in-place Gauss-Jordan inversion (partial pivoting, no row swaps,
-// deferred pivot scaling: the algebra of solve4.hip) runs with the tableau in REGISTERS instead of LDS:
+// deferred pivot scaling: the algebra written out in solve6.hip) runs with the tableau in REGISTERS instead of LDS:
 //   * lane <-> row (RPL rows per lane: i = lane + 64 r), wave <-> every NW-th PAIR of columns (columns 2q, 2q+1 live in wave q % NW,
 //     registers 2 (q / NW), + 1); every wave also carries the right-hand side b as one more column, so nobody owns it;
 //   * DATAFLOW instead of barriers: the wave that owns the next pair of columns brings those two up to date first, takes BOTH pivots
