@@ -13,6 +13,7 @@
 //   joseph_batch_kernel  both stages for a batch handle (>= 128 instances, 6n <= 60): one workgroup per instance from P to P+, U / G / P1c in LDS
 //   ug_lds_kernel, final_lds_kernel
 //                        the same two stages for ONE instance with 6n <= 64: every operand of a workgroup staged in LDS by one batch of loads
+//   joseph_lds_kernel    (round 4) both stages of one instance with 6n <= 60 in ONE launch: a workgroup per tile pair of P+ recomputes the strips it needs
 // (propagate / augmentation + composition: filter_kernels2.hip; T, W = T^-1, dx, state injection: solve7.hip — solve6.hip behind
 //  gemm_T_kernel for batch handles and as A/B forms)
 //
