@@ -36,7 +36,8 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     __shared__ double Phi9[PROP3_CH][9][25];
     __shared__ double Sx[PROP3_CH][9][25];      // rows 9..17 of the suffix products S_s = Phi_{mc-1} ... Phi_{s+1}
     __shared__ double PsiC[9][25];              // ... and of the chunk's Psi_c = S_0 Phi_0
-    __shared__ double Nq[PROP3_CH][15][6];      // S_s[9..23, (theta, v)] Qd_s
+    __shared__ double Nq[PROP3_CH][9][6];       // S_s[9..17, (theta, v)] Qd_s
+    __shared__ double Qd[PROP3_CH][6][6];       // the dense (theta, v) block of Q_s
     __shared__ double vxs[PROP3_CH][9];
     __shared__ Prop3Sample sm[PROP3_CH];
     __shared__ double xs[26];
@@ -162,63 +163,66 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
 #pragma unroll
             for (int k = 6; k < 24; ++k) accP += PsiC[r9][k] * Pl[k][c9];      // (columns 0..5 of rows 9..17 are structurally zero)
         }
-        // N_s = S_s[9..23, A6] Qd_s  with A6 = (theta, v) = columns 9, 10, 11, 15, 16, 17 and Qd_s the dense 6 x 6 block of Q_s = dt G Sigma G^T
-        // (PreIntegrator.cc:135-140: theta-theta dt sg2 I, theta-v / v-theta dt sg2 [v]x terms, v-v dt sg2 [v]x [v]x^T + dt sa2 I)
-        for (int e = tid; e < mc * 90; e += 256) {
-            const int s = e / 90, rem = e - s * 90, ip = rem / 6, b = rem - ip * 6;       // row i = 9 + ip, column A6[b]
+        // Qd_s: the dense 6 x 6 block of Q_s = dt G Sigma G^T on (theta, v) = columns A6 = 9, 10, 11, 15, 16, 17 (PreIntegrator.cc:135-140: theta-theta
+        // dt sg2 I, theta-v / v-theta dt sg2 [v]x terms, v-v dt sg2 [v]x [v]x^T + dt sa2 I), tabulated once per sample
+        for (int e = tid; e < mc * 36; e += 256) {
+            const int s = e / 36, rem = e - s * 36, a = rem / 6, b = rem - a * 6;
+            const int ba = a / 3, ii = a - 3 * ba, bb = b / 3, jj = b - 3 * bb;
             const double dt = sm[s].dt;
             const double* vx = vxs[s];
-            const int bb = b / 3, jj = b % 3;
-            double acc = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const int ba = a / 3, ii = a % 3, ca = (ba ? 15 : 9) + ii;
-                const double sv = (ip < 9) ? Sx[s][ip][ca] : 0.0;                             // rows 18..23 of S_s are unit rows: zero in the A6 columns
-                double q;
-                if (ba == 0 && bb == 0) q = (ii == jj) ? dt * cfg.sg2 : 0.0;
-                else if (ba == 0 && bb == 1) q = dt * cfg.sg2 * vx[3 * jj + ii];
-                else if (ba == 1 && bb == 0) q = dt * cfg.sg2 * vx[3 * ii + jj];
-                else {
-                    q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] + ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
-                    if (ii == jj) q += dt * cfg.sa2;
-                }
-                acc += sv * q;
+            double q;
+            if (ba == 0 && bb == 0) q = (ii == jj) ? dt * cfg.sg2 : 0.0;
+            else if (ba == 0 && bb == 1) q = dt * cfg.sg2 * vx[3 * jj + ii];
+            else if (ba == 1 && bb == 0) q = dt * cfg.sg2 * vx[3 * ii + jj];
+            else {
+                q = ((dt * vx[3 * ii]) * cfg.sg2) * vx[3 * jj] + ((dt * vx[3 * ii + 1]) * cfg.sg2) * vx[3 * jj + 1] + ((dt * vx[3 * ii + 2]) * cfg.sg2) * vx[3 * jj + 2];
+                if (ii == jj) q += dt * cfg.sa2;
             }
-            Nq[s][ip][b] = acc;
+            Qd[s][a][b] = q;
         }
         __syncthreads();
         if (tid < 216) { Psi[9 + r9][c9] = accS; Pl[9 + r9][c9] = accP; }
+        // N_s = S_s[9..17, A6] Qd_s  (rows 18..23 of S_s are unit rows: zero in the A6 columns)
+        for (int e = tid; e < mc * 54; e += 256) {
+            const int s = e / 54, rem = e - s * 54, ip = rem / 6, b = rem - ip * 6;
+            double acc = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc += Sx[s][ip][(a < 3 ? 9 : 12) + a] * Qd[s][a][b];
+            Nq[s][ip][b] = acc;
+        }
         __syncthreads();
         double accC = 0;
         if (tid < 216) {
 #pragma unroll
             for (int k = 6; k < 24; ++k) accC += Pl[c9][k] * PsiC[r9][k];
         }
-        // T = sum_s S_s Q_s S_s^T on rows / columns 9..23: thread <-> entry (i, j)
+        // T = sum_s S_s Q_s S_s^T on rows / columns 9..23 (symmetric).  Threads 0..80: the 9 x 9 block; 81..134: the 9 x 6 block against the bias
+        // random walks (Q_s[a][a] = dt swg2 for a = 18..20, dt swa2 for 21..23) and its mirror image; 135..140: the bias diagonal itself
         double accT = 0;
-        const int ti = tid / 15, tj = tid - ti * 15;
-        if (tid < 225) {
+        if (tid < 81) {
+            const int ti = tid / 9, tj = tid - 9 * ti;
             for (int s = 0; s < mc; ++s) {
-                const double dt = sm[s].dt;
+                const double qg = sm[s].dt * cfg.swg2, qa = sm[s].dt * cfg.swa2;
                 double t = 0;
-                if (tj < 9) {
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) t += Nq[s][ti][b] * Sx[s][tj][(b < 3 ? 9 : 12) + b];
-                }
-                // bias random walks: Q_s[a][a] = dt swg2 (a = 18..20), dt swa2 (21..23)
-                if (ti < 9 && tj < 9) {
+                for (int b = 0; b < 6; ++b) t += Nq[s][ti][b] * Sx[s][tj][(b < 3 ? 9 : 12) + b];
 #pragma unroll
-                    for (int a = 18; a < 24; ++a) t += (Sx[s][ti][a] * (dt * (a < 21 ? cfg.swg2 : cfg.swa2))) * Sx[s][tj][a];
-                } else if (ti >= 9 && tj < 9) t += (dt * (ti < 12 ? cfg.swg2 : cfg.swa2)) * Sx[s][tj][9 + ti];
-                else if (ti < 9 && tj >= 9) t += Sx[s][ti][9 + tj] * (dt * (tj < 12 ? cfg.swg2 : cfg.swa2));
-                else if (ti == tj) t += dt * (ti < 12 ? cfg.swg2 : cfg.swa2);
+                for (int a = 18; a < 24; ++a) t += (Sx[s][ti][a] * (a < 21 ? qg : qa)) * Sx[s][tj][a];
                 accT += t;
             }
+        } else if (tid < 135) {
+            const int e = tid - 81, ti = e / 6, k = e - 6 * ti;
+            for (int s = 0; s < mc; ++s) accT += Sx[s][ti][18 + k] * (sm[s].dt * (k < 3 ? cfg.swg2 : cfg.swa2));
+        } else if (tid < 141) {
+            const int k = tid - 135;
+            for (int s = 0; s < mc; ++s) accT += sm[s].dt * (k < 3 ? cfg.swg2 : cfg.swa2);
         }
         __syncthreads();
         if (tid < 216) Pl[c9][9 + r9] = accC;
         __syncthreads();
-        if (tid < 225) Pl[9 + ti][9 + tj] += accT;
+        if (tid < 81) Pl[9 + tid / 9][9 + tid % 9] += accT;
+        else if (tid < 135) { const int e = tid - 81, ti = e / 6, k = e - 6 * ti; Pl[9 + ti][18 + k] += accT; Pl[18 + k][9 + ti] += accT; }
+        else if (tid < 141) Pl[18 + tid - 135][18 + tid - 135] += accT;
         __syncthreads();
         DBG_T(16);
     }
