@@ -737,6 +737,10 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
 #define SP_MARG 12
 #define SP_RS (SP_PW + 1 + 2 * SP_MARG)
 #define SP_T 256
+// subpix_kernel1's LDS row stride in bytes: 11 dwords, so the 16 window rows of a wave start in 16 different banks (43 bytes = 10.75 dwords
+// put every third row into the same one) and a row is 11 whole dwords for the loads
+#define SP_LS 44
+struct __attribute__((packed)) U32u { unsigned v; };
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
 __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
     DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 2);
@@ -960,6 +964,171 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel1(const uint8_t* __restrict
     } while (++iter < 30 && err > eps);
     if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
     if (lane == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+}
+
+
+// Throughput form, second cut (batched launches): FOUR corners per wave, one 16-lane DPP row per corner, lane i of the row = window
+// row i (lane 15 idles).  A lane evaluates the 15 terms of its window row from a 4 x 18 pixel footprint (every pixel converted once,
+// every bilinear sample formed once — subpix_kernel1 forms the four samples of each of its terms separately), folds them by the
+// canonical column tree (j, j + 8), (.., + 4), (.., + 2), (.., + 1) inside the lane, and the rows combine by four DPP steps inside the
+// row: quad permutes for (R0 + R1) + (R2 + R3), half-row mirror and row mirror for (W0 + W1) + (W2 + W3) — every lane of the row ends
+// with the five sums, so the 2 x 2 solve that follows needs no broadcast.  Same additions as subpix_kernel / the oracle (operands of
+// some swapped; IEEE addition commutes), hence identical results; per corner and iteration about a third of subpix_kernel1's
+// instructions (its reduction, its scalar tail and its per-iteration set-up are shared by four corners here).  The four corners of a
+// wave iterate until the last one has converged (a converged row is masked off).
+#define SP_LD (SP_LS / 4)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ub0(unsigned v) { return (float)(v & 0xffu); }
+__device__ __forceinline__ float ub1(unsigned v) { return (float)((v >> 8) & 0xffu); }
+__device__ __forceinline__ float ub2(unsigned v) { return (float)((v >> 16) & 0xffu); }
+__device__ __forceinline__ float ub3(unsigned v) { return (float)(v >> 24); }
+__device__ __forceinline__ float ubn(unsigned v, int b) { return b == 0 ? ub0(v) : b == 1 ? ub1(v) : b == 2 ? ub2(v) : ub3(v); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void subpix_kernel16(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    __shared__ unsigned regs[4][SP_RS * SP_LD + 1];          // (+ 1: the sixth dword of the last row may be the one behind the slice)
+    const int lane = threadIdx.x, wk = lane >> 4, wi = lane & 15;
+    const int p = blockIdx.x * 4 + wk;
+    const int n = *d.n_out;
+    const bool act = p < n;
+    const int W = d.W, H = d.H;
+    unsigned* regw = regs[wk];
+    unsigned char* reg = (unsigned char*)regw;
+    float tx = 0.f, ty = 0.f;
+    int rx0 = 0, ry0 = 0;
+    if (act) {
+        tx = d.raw_xy[2 * p]; ty = d.raw_xy[2 * p + 1];
+        rx0 = (int)tx - (SP_PW - 1) / 2 - SP_MARG; ry0 = (int)ty - (SP_PW - 1) / 2 - SP_MARG;
+        if (rx0 >= 0 && ry0 >= 0 && rx0 + SP_LS <= W && ry0 + SP_RS <= H) {
+            // the neighbourhood lies inside the image: SP_LD dword loads per row (any byte alignment), dword stores
+            const uint8_t* base = src + (size_t)ry0 * stride + rx0;
+            for (int e = wi; e < SP_RS * SP_LD; e += 16) {
+                const int j = e / SP_LD, i = e % SP_LD;
+                regw[e] = ((const U32u*)(base + (size_t)j * stride))[i].v;
+            }
+        } else
+            for (int e = wi; e < SP_RS * SP_RS; e += 16) {
+                const int j = e / SP_RS, i = e % SP_RS;
+                reg[j * SP_LS + i] = src[(size_t)min(max(ry0 + j, 0), H - 1) * stride + min(max(rx0 + i, 0), W - 1)];
+            }
+    }
+    __syncthreads();
+    auto pix = [&](int x, int y) -> float {
+        const int i = x - rx0, j = y - ry0;
+        if ((unsigned)i < (unsigned)SP_RS && (unsigned)j < (unsigned)SP_RS) return (float)reg[j * SP_LS + i];
+        return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)];
+    };
+    const int wr = wi < SP_WW ? wi : SP_WW - 1;     // (lane 15 reads row 14's pixels; its terms are zeroed below)
+    double wm[SP_WW];
+#pragma unroll
+    for (int wj = 0; wj < SP_WW; ++wj) wm[wj] = (double)d.spmask[wr * SP_WW + wj];
+    const double py = wr - SP_WIN;
+    float cx = tx, cy = ty;
+    const double eps = 1e-2 * 1e-2;
+    int iter = 0;
+    bool run = act;
+    while (__builtin_amdgcn_ballot_w64(run)) {
+        if (run) {
+            const float ox = cx - (float)(SP_PW - 1) * 0.5f, oy = cy - (float)(SP_PW - 1) * 0.5f;
+            const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+            float fa = ox - (float)ix;
+            const float fb = oy - (float)iy;
+            fa = fmaxf(fa, 0.0001f);
+            const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
+            // the lane's footprint: pixel (c, r) = image (ix + c, iy + wr + r), c = 0..17, r = 0..3, held as the operand pairs of the packed
+            // bilinear forms:  PP[c] = (row 2, row 0), QQ[c] = (row 3, row 1)  ->  samples (S2[c], S0[c]);
+            //                  TT[c] = row 1 at (c, c + 8), UU[c] = row 2 at (c, c + 8)  ->  samples (S1[c], S1[c + 8])
+            f2v PP[18], QQ[18], TT[10], UU[10];
+            const int ux = ix - rx0, uy = iy - ry0;
+            if (ux >= 0 && uy >= 0 && ux <= SP_RS - 4 - (SP_WW - 1) && uy <= SP_RS - 4 - (SP_WW - 1)) {
+                // inside the cached neighbourhood: 6 dwords per row, shifted to the footprint's first byte, bytes converted in place
+                const int sh = ux & 3;
+                const unsigned* rowp = regw + (uy + wr) * SP_LD + (ux >> 2);
+                unsigned A[4][5];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    unsigned dw[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) dw[j] = rowp[r * SP_LD + j];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) A[r][j] = __builtin_amdgcn_alignbyte(dw[j + 1], dw[j], sh);
+                }
+#pragma unroll
+                for (int c = 0; c < 18; ++c) {
+                    PP[c] = f2v{ubn(A[2][c >> 2], c & 3), ubn(A[0][c >> 2], c & 3)};
+                    QQ[c] = f2v{ubn(A[3][c >> 2], c & 3), ubn(A[1][c >> 2], c & 3)};
+                }
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {
+                    TT[c] = f2v{ubn(A[1][c >> 2], c & 3), ubn(A[1][(c + 8) >> 2], (c + 8) & 3)};
+                    UU[c] = f2v{ubn(A[2][c >> 2], c & 3), ubn(A[2][(c + 8) >> 2], (c + 8) & 3)};
+                }
+            } else {
+                // the estimate has wandered off the cached neighbourhood (or sits at the image border): pixel by pixel
+#pragma unroll 1
+                for (int c = 0; c < 18; ++c) {
+                    const float r0 = pix(ix + c, iy + wr), r1 = pix(ix + c, iy + wr + 1), r2 = pix(ix + c, iy + wr + 2), r3 = pix(ix + c, iy + wr + 3);
+                    // (dynamic index into register arrays would spill: a switch over the unrolled copies)
+#pragma unroll
+                    for (int cc = 0; cc < 18; ++cc)
+                        if (cc == c) {
+                            PP[cc] = f2v{r2, r0}; QQ[cc] = f2v{r3, r1};
+                            if (cc < 10) { TT[cc].x = r1; UU[cc].x = r2; }
+                            if (cc >= 8) { TT[cc - 8].y = r1; UU[cc - 8].y = r2; }
+                        }
+                }
+            }
+            // bilinear samples (getRectSubPix), two per packed operation: same IEEE operations as the scalar form, contraction off
+            f2v S20[SP_WW + 1], S1p[9];
+#pragma unroll
+            for (int c = 1; c <= SP_WW; ++c) S20[c] = ((PP[c] * a11 + PP[c + 1] * a12) + QQ[c] * a21) + QQ[c + 1] * a22;     // (S2[c], S0[c])
+#pragma unroll
+            for (int c = 0; c < 9; ++c) S1p[c] = ((TT[c] * a11 + TT[c + 1] * a12) + UU[c] * a21) + UU[c + 1] * a22;          // (S1[c], S1[c + 8])
+            auto S1 = [&](int c) -> float { return c < 8 ? S1p[c].x : S1p[c - 8].y; };
+            // term wj of the window row: the five products; the canonical column tree (j, j + 8), (.., + 4), (.., + 2), (.., + 1) is
+            // walked depth first — j, j + 8 -> u_j;  u_j + u_(j+4) -> v_j;  v_j + v_(j+2) -> w_j;  w_0 + w_1 — so few partial sums are alive
+            auto term = [&](int wj, double* o) {
+                if (wj >= SP_WW) { o[0] = o[1] = o[2] = o[3] = o[4] = 0.0; return; }       // the padding column
+                const double tgx = S1(wj + 2) - S1(wj);
+                const double tgy = S20[wj + 1].x - S20[wj + 1].y;
+                const double px = wj - SP_WIN;
+                const double gxx = tgx * tgx * wm[wj], gxy = tgx * tgy * wm[wj], gyy = tgy * tgy * wm[wj];
+                o[0] = gxx; o[1] = gxy; o[2] = gyy;
+                o[3] = gxx * px + gxy * py;
+                o[4] = gxy * px + gyy * py;
+            };
+            auto uj = [&](int j, double* o) { double x[5], y[5]; term(j, x); term(j + 8, y); for (int c = 0; c < 5; ++c) o[c] = x[c] + y[c]; };
+            auto vj = [&](int j, double* o) { double x[5], y[5]; uj(j, x); uj(j + 4, y); for (int c = 0; c < 5; ++c) o[c] = x[c] + y[c]; };
+            auto wj_ = [&](int j, double* o) { double x[5], y[5]; vj(j, x); vj(j + 2, y); for (int c = 0; c < 5; ++c) o[c] = x[c] + y[c]; };
+            double w0[5], w1[5], sm[5];
+            wj_(0, w0); wj_(1, w1);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                double v = w0[c] + w1[c];
+                if (wi >= SP_WW) v = 0.0;               // the padding row
+                // rows: lane i of the DPP row = window row i
+                v += dpp_f64<0xb1>(v);      // quad_perm [1,0,3,2]: R0 + R1 | R2 + R3
+                v += dpp_f64<0x4e>(v);      // quad_perm [2,3,0,1]: (R0 + R1) + (R2 + R3) = W, in all four lanes
+                v += dpp_f64<0x141>(v);     // row_half_mirror: W0 + W1 | W2 + W3
+                v += dpp_f64<0x140>(v);     // row_mirror: (W0 + W1) + (W2 + W3), in all sixteen lanes
+                sm[c] = v;
+            }
+            const double a = sm[0], b = sm[1], c = sm[2], bb1 = sm[3], bb2 = sm[4];
+            const double det = a * c - b * b;
+            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) run = false;
+            else {
+                const double scale = 1.0 / det;
+                const float nx = (float)(cx + c * scale * bb1 - b * scale * bb2);
+                const float ny = (float)(cy - b * scale * bb1 + a * scale * bb2);
+                const float ex = nx - cx, ey = ny - cy;
+                const double err = (double)(ex * ex + ey * ey);
+                cx = nx; cy = ny;
+                if (cx < 0 || cx >= W || cy < 0 || cy >= H) run = false;
+                else run = ++iter < 30 && err > eps;
+            }
+        }
+    }
+    if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
+    if (act && wi == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }
 
 

@@ -14,7 +14,7 @@
 #include "frontend_dev.h"
 
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 // exact sum over the wave of values whose 16-lane partial sums fit in int32
 __device__ __forceinline__ long long wave_sum_i32rows(int v) {
     v += dpp_i32<0x128>(v);

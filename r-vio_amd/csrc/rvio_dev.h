@@ -197,8 +197,8 @@ __device__ __forceinline__ q4 small_q(double ex, double ey, double ez) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -222,8 +222,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 template <int CTRL>
 __device__ __forceinline__ long long dpp_i64(long long v) {
     int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 __device__ __forceinline__ long long readlane_i64(long long v, int l) {

@@ -1123,7 +1123,8 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     const hipStream_t ds = image_stream(h);
     h->det_set_last = h->runahead ? h->ic : 0;
     static const bool two_pass = ab_env("RVIO_DET_TWO_PASS") != nullptr;   // A/B timing
-    if (h->wide_px || two_pass) {   // batch handles of >= 8 instances: the two-pass throughput form (the map through HBM)
+    static const bool fused_wide = ab_env("RVIO_DET_FUSED_WIDE") != nullptr;
+    if ((h->wide_px && !fused_wide) || two_pass) {   // batch handles of >= 8 instances: the two-pass throughput form (the map through HBM)
         const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
         if (h->wide_px) hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
         else hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
@@ -1140,8 +1141,11 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
     if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
         hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, B), dim3(SPG_T), 0, ds, img, stride, q, src_bs, bs);
-    else if (h->wide_px)
-        hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
+    else if (h->wide_px) {
+        static const bool sp1 = ab_env("RVIO_SUBPIX1") != nullptr;   // A/B timing
+        if (sp1) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
+        else hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
+    }
     else
         hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
     HIPCHK(h, hipGetLastError());

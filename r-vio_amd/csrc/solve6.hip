@@ -22,7 +22,7 @@
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ unsigned umax32(unsigned a, unsigned b) { return a > b ? a : b; }
 

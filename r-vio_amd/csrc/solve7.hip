@@ -23,7 +23,7 @@
 #include "rvio_dev.h"
 
 template <int CTRL>
-__device__ __forceinline__ unsigned s7_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned s7_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned s7_max(unsigned a, unsigned b) { return a > b ? a : b; }
 typedef double s7_d4 __attribute__((ext_vector_type(4)));
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (register arrays must be indexed by constants)
