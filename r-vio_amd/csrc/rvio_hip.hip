@@ -25,6 +25,7 @@
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
 #include "klt3.hip"
+#include "klt16.hip"
 #include "clahe.hip"
 #include "detector.hip"
 #pragma clang fp contract(fast)
@@ -1318,8 +1319,13 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     const int nb = (h->pyr_cur + 1) % 4;   // pyramid of the new image; pyr_cur holds mLastImage's (slot nb was last read by KLT(k-3))
     rc = build_pyramid_dev(h, d_img, stride, nb);
     if (rc != RVIO_OK) return rc;
-    hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
-                       h->t.tracked, h->t.status, h->slab_bytes);
+    static const bool klt3 = ab_env("RVIO_KLT3") != nullptr;   // A/B timing
+    if (h->wide_px && !klt3)    // batch handles of >= 8 instances: the throughput form, four features per wave
+        hipLaunchKernelGGL(klt_kernel16, dim3((h->dc.F + 3) / 4, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+                           h->t.tracked, h->t.status, h->slab_bytes);
+    else
+        hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
+                           h->t.tracked, h->t.status, h->slab_bytes);
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
     return rc;
