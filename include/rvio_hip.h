@@ -322,6 +322,10 @@ int rvio_hip_debug_stall(rvio_hip* h, int which, int usec);
 /* Test hook against timing dependence inside kernels: `wgs` workgroups on a stream of their own load HBM, L2 and LDS for `usec`
  * microseconds beside whatever the handle has in flight (a box under load); results must not move by a bit. */
 int rvio_hip_debug_noise(rvio_hip* h, int wgs, int usec);
+/* Test hook: selects the throughput forms of the image kernels (the ones a batch handle of >= 8 instances launches: several pixels per
+ * thread, four corners / features per wave) on any handle, or the latency forms (0) on a batch handle.  The two families compute the same
+ * bits by construction; the tests run the KLT early-out cases and the detector's image set through both. */
+int rvio_hip_debug_kernel_forms(rvio_hip* h, int throughput);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@
 //                     runs the rounds on those lists with the candidate states in LDS, then ranks
 //   subpix_kernel     one workgroup of 4 waves per corner: the neighbourhood cached in LDS, 17x17 bilinear patch, one
 //                     window term per thread, double sums in the oracle's canonical tree order, 2x2 solve, <= 30 iterations
-//   subpix_kernel1    the throughput form (one wave per corner: batch handles); subpix_generic_kernel: any half-window 1..15 other than the stock 7
+//   subpix_kernel16   the throughput form (four corners per wave, one 16-lane DPP row each: batch handles); subpix_generic_kernel: any half-window 1..15 other than the stock 7
 //   (mineig_kernel4, nms_kernel4: several pixels per thread, batch handles)
 #pragma once
 
@@ -737,8 +737,8 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
 #define SP_MARG 12
 #define SP_RS (SP_PW + 1 + 2 * SP_MARG)
 #define SP_T 256
-// subpix_kernel1's LDS row stride in bytes: 11 dwords, so the 16 window rows of a wave start in 16 different banks (43 bytes = 10.75 dwords
-// put every third row into the same one) and a row is 11 whole dwords for the loads
+// subpix_kernel16's LDS row stride in bytes: 11 dwords, so the 16 window rows of a DPP row of lanes start in 16 different banks (43 bytes =
+// 10.75 dwords put every third row into the same one) and a row is 11 whole dwords for the loads
 #define SP_LS 44
 struct __attribute__((packed)) U32u { unsigned v; };
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
@@ -853,128 +853,15 @@ __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict_
     DBG_I(p == n - 1 && blockIdx.z == 0, dbg_tag, 3);
 }
 
-// Throughput form (batched launches): ONE wave per corner, four corners per workgroup, no workgroup barrier inside the iteration.
-// Lane (i, q) = (lane / 4, lane % 4) evaluates the four window terms (i, q), (i, q + 4), (i, q + 8), (i, q + 12) of window row i, so
-// the first two levels of the canonical column tree — (j, j + 8), then (.., + 4) — are additions inside the lane, the last two
-// — (.., + 2), (.., + 1) — two quad permutes; rows combine as (R0 + R1) + (R2 + R3) per row quartet (row rotations by 4 and 8
-// lanes inside a 16-lane DPP row = one quartet), quartets as (W0 + W1) + (W2 + W3).  The same tree as subpix_kernel and the
-// oracle, hence identical results, at about half the instructions and a quarter of the wave slots per corner.
-__global__ __launch_bounds__(SP_T) void subpix_kernel1(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
-    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
-    __shared__ unsigned char regs[4][SP_RS * SP_RS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = blockIdx.x * 4 + wv;
-    const int n = *d.n_out;
-    const bool act = p < n;
-    const int W = d.W, H = d.H;
-    unsigned char* reg = regs[wv];
-    float tx = 0.f, ty = 0.f;
-    int rx0 = 0, ry0 = 0;
-    if (act) {
-        tx = d.raw_xy[2 * p]; ty = d.raw_xy[2 * p + 1];
-        rx0 = (int)tx - (SP_PW - 1) / 2 - SP_MARG; ry0 = (int)ty - (SP_PW - 1) / 2 - SP_MARG;
-        for (int e = lane; e < SP_RS * SP_RS; e += 64) {
-            const int j = e / SP_RS, i = e % SP_RS;
-            reg[e] = src[(size_t)min(max(ry0 + j, 0), H - 1) * stride + min(max(rx0 + i, 0), W - 1)];
-        }
-    }
-    __syncthreads();
-    if (!act) return;
-    auto pix = [&](int x, int y) -> float {
-        const int i = x - rx0, j = y - ry0;
-        if ((unsigned)i < (unsigned)SP_RS && (unsigned)j < (unsigned)SP_RS) return (float)reg[j * SP_RS + i];
-        return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)];
-    };
-    const int wi = lane >> 2, q4 = lane & 3;
-    double wm[4], px[4];
-    bool live[4];
-    const double py = wi - SP_WIN;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int wj = q4 + 4 * k;
-        live[k] = wi < SP_WW && wj < SP_WW;
-        wm[k] = live[k] ? (double)d.spmask[wi * SP_WW + wj] : 0.0;
-        px[k] = wj - SP_WIN;
-    }
-    float cx = tx, cy = ty;
-    const double eps = 1e-2 * 1e-2;
-    int iter = 0;
-    double err = 0;
-    do {
-        const float ox = cx - (float)(SP_PW - 1) * 0.5f, oy = cy - (float)(SP_PW - 1) * 0.5f;
-        const int ix = (int)floorf(ox), iy = (int)floorf(oy);
-        float fa = ox - (float)ix;
-        const float fb = oy - (float)iy;
-        fa = fmaxf(fa, 0.0001f);
-        const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
-        auto samp = [&](int pi, int pj) -> float {
-            const int x = ix + pj, y = iy + pi;
-            return ((pix(x, y) * a11 + pix(x + 1, y) * a12) + pix(x, y + 1) * a21) + pix(x + 1, y + 1) * a22;
-        };
-        double t[4][5];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int wj = q4 + 4 * k;
-            double ra = 0, rb = 0, rc = 0, r1s = 0, r2s = 0;
-            if (live[k]) {
-                float sE, sW, sS, sN;
-                const int bx = ix + wj - rx0, by = iy + wi - ry0;
-                if ((unsigned)bx <= (unsigned)(SP_RS - 4) && (unsigned)by <= (unsigned)(SP_RS - 4)) {
-                    const unsigned char* g = reg + by * SP_RS + bx;
-                    const float p01 = g[1], p02 = g[2];
-                    const float p10 = g[SP_RS], p11 = g[SP_RS + 1], p12 = g[SP_RS + 2], p13 = g[SP_RS + 3];
-                    const float p20 = g[2 * SP_RS], p21 = g[2 * SP_RS + 1], p22 = g[2 * SP_RS + 2], p23 = g[2 * SP_RS + 3];
-                    const float p31 = g[3 * SP_RS + 1], p32 = g[3 * SP_RS + 2];
-                    sE = ((p12 * a11 + p13 * a12) + p22 * a21) + p23 * a22;
-                    sW = ((p10 * a11 + p11 * a12) + p20 * a21) + p21 * a22;
-                    sS = ((p21 * a11 + p22 * a12) + p31 * a21) + p32 * a22;
-                    sN = ((p01 * a11 + p02 * a12) + p11 * a21) + p12 * a22;
-                } else { sE = samp(wi + 1, wj + 2); sW = samp(wi + 1, wj); sS = samp(wi + 2, wj + 1); sN = samp(wi, wj + 1); }
-                const double tgx = sE - sW;
-                const double tgy = sS - sN;
-                const double gxx = tgx * tgx * wm[k], gxy = tgx * tgy * wm[k], gyy = tgy * tgy * wm[k];
-                ra = gxx; rb = gxy; rc = gyy;
-                r1s = gxx * px[k] + gxy * py;
-                r2s = gxy * px[k] + gyy * py;
-            }
-            t[k][0] = ra; t[k][1] = rb; t[k][2] = rc; t[k][3] = r1s; t[k][4] = r2s;
-        }
-        double sm[5];
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            // columns: (j, j+8) and (.., +4) inside the lane; (.., +2), (.., +1) across the quad
-            double v = (t[0][c] + t[2][c]) + (t[1][c] + t[3][c]);
-            v += dpp_f64<0x4e>(v);      // quad_perm [2,3,0,1]
-            v += dpp_f64<0xb1>(v);      // quad_perm [1,0,3,2]
-            // rows of a quartet sit 4 lanes apart inside one 16-lane DPP row: (R0 + R1) + (R2 + R3)
-            v += dpp_f64<0x12c>(v);     // row_ror:12 (lane i <- lane i + 4): lane 0: R0 + R1, lane 8: R2 + R3
-            v += dpp_f64<0x128>(v);     // row_ror:8   lane 0 of the row: (R0 + R1) + (R2 + R3)
-            sm[c] = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-        }
-        const double a = sm[0], b = sm[1], c = sm[2], bb1 = sm[3], bb2 = sm[4];
-        const double det = a * c - b * b;
-        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
-        const double scale = 1.0 / det;
-        const float nx = (float)(cx + c * scale * bb1 - b * scale * bb2);
-        const float ny = (float)(cy - b * scale * bb1 + a * scale * bb2);
-        const float ex = nx - cx, ey = ny - cy;
-        err = (double)(ex * ex + ey * ey);
-        cx = nx; cy = ny;
-        if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
-    } while (++iter < 30 && err > eps);
-    if (fabsf(cx - tx) > SP_WIN || fabsf(cy - ty) > SP_WIN) { cx = tx; cy = ty; }
-    if (lane == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
-}
-
-
-// Throughput form, second cut (batched launches): FOUR corners per wave, one 16-lane DPP row per corner, lane i of the row = window
+// Throughput form (batched launches): FOUR corners per wave, one 16-lane DPP row per corner, lane i of the row = window
 // row i (lane 15 idles).  A lane evaluates the 15 terms of its window row from a 4 x 18 pixel footprint (every pixel converted once,
-// every bilinear sample formed once — subpix_kernel1 forms the four samples of each of its terms separately), folds them by the
+// every bilinear sample formed once), folds them by the
 // canonical column tree (j, j + 8), (.., + 4), (.., + 2), (.., + 1) inside the lane, and the rows combine by four DPP steps inside the
 // row: quad permutes for (R0 + R1) + (R2 + R3), half-row mirror and row mirror for (W0 + W1) + (W2 + W3) — every lane of the row ends
 // with the five sums, so the 2 x 2 solve that follows needs no broadcast.  Same additions as subpix_kernel / the oracle (operands of
-// some swapped; IEEE addition commutes), hence identical results; per corner and iteration about a third of subpix_kernel1's
-// instructions (its reduction, its scalar tail and its per-iteration set-up are shared by four corners here).  The four corners of a
+// some swapped; IEEE addition commutes), hence identical results; per corner and iteration about a third of the instructions of
+// round 2's one-wave-per-corner form (the reduction, the 2 x 2 solve and the per-iteration set-up are shared by four corners;
+// measured at 128 streams: 81 k -> 97 k frames/s).  The four corners of a
 // wave iterate until the last one has converged (a converged row is masked off).
 #define SP_LD (SP_LS / 4)
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -1136,7 +1023,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void su
 // One workgroup per corner; the (2 win + 1)^2 window terms go to a zero-padded G x G grid in LDS (G = 16 / 32) and are summed in the
 // canonical order of oracle/detector.cpp — per row a balanced tree over the columns, rows in groups of four, the groups by a balanced tree —
 // by 5 G threads (one per quantity and row), then one thread per quantity.  Correct for every window, tuned for none: the stock window
-// runs subpix_kernel / subpix_kernel1.
+// runs subpix_kernel / subpix_kernel16.
 #define SPG_T 256
 #define SPG_G 32
 __global__ __launch_bounds__(SPG_T) void subpix_generic_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {

@@ -1142,11 +1142,8 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
     if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
         hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, B), dim3(SPG_T), 0, ds, img, stride, q, src_bs, bs);
-    else if (h->wide_px) {
-        static const bool sp1 = ab_env("RVIO_SUBPIX1") != nullptr;   // A/B timing
-        if (sp1) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs);
-        else hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
-    }
+    else if (h->wide_px)
+        hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
     else
         hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, B), dim3(SP_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
     HIPCHK(h, hipGetLastError());
@@ -1879,7 +1876,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             const DetDev q = [&] { DetDev v = h->dets[h->det_set_last]; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
             const uint8_t* im = h->pyr[h->pyr_cur].img[0];   // level 0 of the current pyramid = the image the detector saw
             if (q.sp_win != SP_WIN) hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, 1), dim3(SPG_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
-            else if (h->wide_px) hipLaunchKernelGGL(subpix_kernel1, dim3((d.F + 3) / 4, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            else if (h->wide_px) hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, 1), dim3(64), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
             else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes, 0);
         } else return RVIO_ERR_INVALID;
     }
@@ -1999,6 +1996,11 @@ __global__ __launch_bounds__(256) void noise_kernel(unsigned long long ticks, do
         ++it;
     }
     if (acc == 1.2345e300) g[0] = acc;
+}
+int rvio_hip_debug_kernel_forms(rvio_hip* h, int throughput) {
+    if (!h) return RVIO_ERR_INVALID;
+    h->wide_px = throughput != 0;
+    return RVIO_OK;
 }
 int rvio_hip_debug_noise(rvio_hip* h, int wgs, int usec) {
     if (!h || wgs < 1 || wgs > 4096 || usec < 0 || usec > 1000000) return RVIO_ERR_INVALID;

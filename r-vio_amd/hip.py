@@ -23,7 +23,7 @@ SYMBOLS = [
     "rvio_hip_debug_pyramid", "rvio_hip_debug_tracked", "rvio_hip_frame_plan", "rvio_hip_propagate_dev",
     "rvio_hip_debug_time_kernel", "rvio_hip_get_corners", "rvio_hip_frame_begin_dev", "rvio_hip_frame_end",
     "rvio_hip_create_batch", "rvio_hip_batch_size", "rvio_hip_set_state_at", "rvio_hip_get_state_at", "rvio_hip_frame_tracks_dev",
-    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at", "rvio_hip_frame_sharded_dev", "rvio_hip_debug_poison", "rvio_hip_debug_stall", "rvio_hip_debug_noise",
+    "rvio_hip_frame_batch_dev", "rvio_hip_get_tracker_points_at", "rvio_hip_frame_sharded_dev", "rvio_hip_debug_poison", "rvio_hip_debug_stall", "rvio_hip_debug_noise", "rvio_hip_debug_kernel_forms",
 ]
 
 _LIB = None
@@ -370,6 +370,10 @@ class RvioHip:
     def noise(self, wgs, usec):
         """`wgs` workgroups of HBM / L2 / LDS traffic on a stream of their own for usec microseconds (a box under load)"""
         self._ck(self.L.rvio_hip_debug_noise(self.h, int(wgs), int(usec)), "debug_noise")
+
+    def kernel_forms(self, throughput):
+        """select the throughput (batch) or latency (one stream) forms of the image kernels on this handle: same bits either way"""
+        self._ck(self.L.rvio_hip_debug_kernel_forms(self.h, int(throughput)), "debug_kernel_forms")
 
     def frame_info(self):
         info = abi.rvio_frame_info()

@@ -23,13 +23,16 @@ def _imgs():
             "flat": (np.full((480, 752), 77, np.uint8), np.full((480, 752), 78, np.uint8))}
 
 
+@pytest.mark.parametrize("throughput", [0, 1], ids=["latency-forms", "throughput-forms"])
 @pytest.mark.parametrize("name", ["synth", "noise", "checker", "flat"])
 @pytest.mark.parametrize("eq", [0, 1])
-def test_detector_bit_exact(gpu_required, name, eq):
+def test_detector_bit_exact(gpu_required, name, eq, throughput):
+    """(throughput = 1: the forms a batch handle launches — 4 pixels per thread, the map through HBM, four corners per wave — on this one stream)"""
     from rvio_amd import hip
     cfg = abi.config_named("B", enable_equalizer=eq)
     im0, im1 = _imgs()[name]
     h = hip.RvioHip(cfg)
+    h.kernel_forms(throughput)
     imu = np.zeros(2, abi.IMU_DTYPE)
     imu["dt"] = 0.005
     for s, im in ((1, im0), (2, im1)):       # first image: s = 1; afterwards the refill factor 2 (unless nothing was found)
@@ -67,11 +70,13 @@ def test_detector_bit_exact_1080p(gpu_required):
     h.close()
 
 
-def test_tracker_sequence_with_device_detector_bit_exact(gpu_required):
+@pytest.mark.parametrize("throughput", [0, 1], ids=["latency-forms", "throughput-forms"])
+def test_tracker_sequence_with_device_detector_bit_exact(gpu_required, throughput):
     from rvio_amd import hip
     cfg = abi.config_named("B", enable_equalizer=1)
     seq = rv.synth.SynthSequence(cfg, duration=8.0)
     h = hip.RvioHip(cfg)
+    h.kernel_forms(throughput)
     t = O.Tracker(cfg)
     n_upd = 0
     for k in range(60, 72):

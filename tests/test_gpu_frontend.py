@@ -35,10 +35,16 @@ def test_pyramid_and_scharr_bit_exact(gpu_required, frames):
     h.close()
 
 
-def test_klt_bit_exact(gpu_required, frames):
+FORMS = pytest.mark.parametrize("throughput", [0, 1], ids=["latency-forms", "throughput-forms"])
+
+
+@FORMS
+def test_klt_bit_exact(gpu_required, frames, throughput):
+    """(throughput = 1: klt_kernel16, the four-features-per-wave form a batch handle launches, on this one stream)"""
     from rvio_amd import hip
     cfg, seq, ks, imgs = frames
     h = hip.RvioHip(cfg)
+    h.kernel_forms(throughput)
     xy, vis = seq.project(ks[0], noise=False)
     cand, _ = seq.candidates(ks[0], xy, vis)
     h.track(imgs[0], seq.imu_between(ks[0]), cand)
@@ -52,7 +58,8 @@ def test_klt_bit_exact(gpu_required, frames):
     h.close()
 
 
-def test_klt_early_outs(gpu_required, frames):
+@FORMS
+def test_klt_early_outs(gpu_required, frames, throughput):
     """The early-outs of cv::calcOpticalFlowPyrLK (SURVEY.md appendix B.2), each with its own point and an explicit status:
     a window that starts outside the image at the coarsest level / a start position outside the image (status 0), a textureless
     patch (min eigenvalue below minEigThreshold: status 0), a window that leaves the image mid-iteration (status 0), and ordinary
@@ -86,6 +93,7 @@ def test_klt_early_outs(gpu_required, frames):
     assert st[8] == 0 and st[9] == 0, "start positions outside the image"
     assert st[3] == 0 or st[4] == 0, "a window that leaves the image"
     h = hip.RvioHip(cfg)
+    h.kernel_forms(throughput)
     imu = np.zeros(0, abi.IMU_DTYPE)
     h.track(a, imu, pts)                                 # first image: the list is taken as it is
     assert np.array_equal(h.get_points()[0], pts)
