@@ -14,7 +14,7 @@
 //   subpix_kernel     one workgroup of 4 waves per corner: the neighbourhood cached in LDS, 17x17 bilinear patch, one
 //                     window term per thread, double sums in the oracle's canonical tree order, 2x2 solve, <= 30 iterations
 //   subpix_kernel16   the throughput form (four corners per wave, one 16-lane DPP row each: batch handles); subpix_generic_kernel: any half-window 1..15 other than the stock 7
-//   (mineig_kernel4, nms_kernel4: several pixels per thread, batch handles)
+//   mineig_nms_strip_kernel: the fused pass of batch handles (one wave per strip of 60 x 32 pixels, rows walked with the state in registers)
 #pragma once
 
 #define DET_NBCAP 64          // stronger-neighbour list capacity per candidate (global memory)
@@ -57,6 +57,7 @@ __device__ __forceinline__ void det_shift(DetDev& d, size_t off) {
 __device__ __forceinline__ int f2ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : (b ^ 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
 
+struct __attribute__((packed)) U32u { unsigned v; };   // a dword at any byte address
 #define DET_TW 64
 #define DET_TH 8
 #define DET_T (DET_TW * DET_TH)
@@ -130,98 +131,6 @@ __global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict
     }
 }
 
-// Throughput form (batched launches): a 64 x 16 tile per workgroup, the raw pixels staged once in LDS (one byte load per pixel
-// instead of eight per gradient) and the 3x3 box sums made separable: the vertical three-sums (p(i) + p(i+1)) + p(i+2) of the three
-// product planes are formed once per column (in double, from the float products — exactly the canonical inner sums) and shared through
-// LDS by the three pixels that need them; a pixel then adds three of them left to right.  Same additions in the same order as
-// mineig_kernel, hence the same bits, with 6 instead of 27 float->double conversions per pixel (measured at 128 images per launch:
-// 344 us for the 1-pixel form, 297 with the staged pixels, 268 with the separable sums).
-#define DET_R4 2
-__global__ __launch_bounds__(DET_T) void mineig_kernel4(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
-    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
-    constexpr int TH = DET_TH * DET_R4, RW = DET_TW + 4, RH = TH + 4, CW = DET_TW + 2;
-    __shared__ unsigned char raw[RH][RW];
-    __shared__ float sdx[TH + 2][CW], sdy[TH + 2][CW];
-    __shared__ double cs[3][TH][CW];          // cs[k][i][c] = (p_k(i, c) + p_k(i+1, c)) + p_k(i+2, c), p_0 = gx*gx, p_1 = gx*gy, p_2 = gy*gy
-    __shared__ int s_max[DET_TH];
-    const int W = d.W, H = d.H;
-    const int tid = threadIdx.x, x0 = blockIdx.x * DET_TW, y0 = blockIdx.y * TH;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int i = tid; i < d.max_cells; i += DET_T) d.cell_cnt[i] = 0;
-        if (tid < 3) d.counters[tid] = 0;
-    }
-    // raw[tr][tc] = pixel (y0 - 2 + tr, x0 - 2 + tc) wherever that lies in the image (other cells are never addressed)
-    for (int e = tid; e < RH * RW; e += DET_T) {
-        const int tr = e / RW, tc = e % RW;
-        const int yy = min(max(y0 - 2 + tr, 0), H - 1), xx = min(max(x0 - 2 + tc, 0), W - 1);
-        raw[tr][tc] = src[(size_t)yy * stride + xx];
-    }
-    __syncthreads();
-    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
-    const float k1 = (float)scale, k0 = (float)(2.0 * scale);
-    for (int e = tid; e < CW * (TH + 2); e += DET_T) {
-        const int ly = e / CW, lx = e % CW;
-        float dxv = 0.f, dyv = 0.f;
-        if (y0 + ly - 1 < H + 1 && x0 + lx - 1 < W + 1) {
-            const int gy = reflect1(y0 + ly - 1, H), gx = reflect1(x0 + lx - 1, W);
-            const unsigned char* r0 = raw[reflect1(gy - 1, H) - y0 + 2];
-            const unsigned char* r1 = raw[gy - y0 + 2];
-            const unsigned char* r2 = raw[reflect1(gy + 1, H) - y0 + 2];
-            const int xl = reflect1(gx - 1, W) - x0 + 2, xc = gx - x0 + 2, xr = reflect1(gx + 1, W) - x0 + 2;
-            const float a00 = r0[xl], a01 = r0[xc], a02 = r0[xr], a10 = r1[xl], a12 = r1[xr], a20 = r2[xl], a21 = r2[xc], a22 = r2[xr];
-            const float rr0 = a02 - a00, rr1 = a12 - a10, rr2 = a22 - a20;
-            dxv = k0 * rr1 + k1 * (rr0 + rr2);
-            const float q0 = k0 * a01 + k1 * (a00 + a02);
-            const float q2 = k0 * a21 + k1 * (a20 + a22);
-            dyv = q2 - q0;
-        }
-        sdx[ly][lx] = dxv; sdy[ly][lx] = dyv;
-    }
-    __syncthreads();
-    // vertical three-sums: item = (column c, pair of tile rows 2g, 2g+1); consecutive threads take consecutive columns
-    for (int it = tid; it < CW * (TH / 2); it += DET_T) {
-        const int c = it % CW, r0 = 2 * (it / CW);
-        double p[3][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float gx = sdx[r0 + r][c], gy = sdy[r0 + r][c];
-            const float pxx = gx * gx, pxy = gx * gy, pyy = gy * gy;
-            p[0][r] = (double)pxx; p[1][r] = (double)pxy; p[2][r] = (double)pyy;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cs[k][r0][c] = (p[k][0] + p[k][1]) + p[k][2];
-            cs[k][r0 + 1][c] = (p[k][1] + p[k][2]) + p[k][3];
-        }
-    }
-    __syncthreads();
-    const int lx = tid & 63, x = x0 + lx;
-    int key = (int)0x80000000;
-#pragma unroll
-    for (int rr = 0; rr < DET_R4; ++rr) {
-        const int ly = (tid >> 6) + DET_TH * rr, y = y0 + ly;
-        if (x < W && y < H) {
-            float cov[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) cov[k] = (float)((cs[k][ly][lx] + cs[k][ly][lx + 1]) + cs[k][ly][lx + 2]);
-            const float a = cov[0] * 0.5f, b = cov[1], c = cov[2] * 0.5f;
-            const float ev = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-            d.eig[(size_t)y * W + x] = ev;
-            const int k2 = f2ord(ev);
-            key = k2 > key ? k2 : key;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
-    if ((tid & 63) == 0) s_max[tid >> 6] = key;
-    __syncthreads();
-    if (tid == 0) {
-        int m = s_max[0];
-        for (int k = 1; k < DET_TH; ++k) m = s_max[k] > m ? s_max[k] : m;
-        atomicMax(d.maxkey, m);
-    }
-}
-
 // ---------------------------------------------------------------- round 4: min-eigenvalue map + 3x3 local maxima in ONE pass
 // goodFeaturesToTrack thresholds the map at quality x its MAXIMUM and keeps the strict 3x3 local maxima (cv::dilate + compare).  The two
 // kernels of rounds 1-3 wrote the whole float map (1.44 MB at 752 x 480) for the second one to read back (1.07 MB after the threshold test):
@@ -230,7 +139,7 @@ __global__ __launch_bounds__(DET_T) void mineig_kernel4(const uint8_t* __restric
 // the same arithmetic, hence the same bits), keeps it in LDS, appends every local maximum (value != 0) to a provisional list and folds the
 // tile's maximum into the image maximum; nms_threshold_kernel then applies  value > quality x maximum  to that list (a few thousand
 // entries instead of the 361 k-pixel map) and fills the candidate list and the cell buckets exactly as nms_kernel did.  The map itself
-// is no longer stored (one stream; batch handles of >= 8 instances keep the two-pass throughput form, see nms_kernel4);
+// is no longer stored (batch handles of >= 8 instances run the same pass in its strip form, mineig_nms_strip_kernel);
 // rvio_hip_get_corners(eig) recomputes it on demand with mineig_kernel.
 // Arithmetic = mineig_kernel's, in the separable form of round 2's throughput kernel: raw pixels staged once (one byte load per pixel),
 // Scharr-scaled Sobel gradients in float, the three product planes' vertical three-sums (p(i) + p(i+1)) + p(i+2) formed once per column in
@@ -357,6 +266,158 @@ __global__ __launch_bounds__(DET_T) void mineig_nms_kernel(const uint8_t* __rest
     for (int i = tid; i < cnt; i += DET_T) d.prov[s_base + i] = s_list[i];
 }
 
+// ---------------------------------------------------------------- round 4, throughput form of the fused pass (batched launches)
+// One WAVE per strip of DET_SW columns x DET_SH rows, lane = image column, rows walked top to bottom with everything a row needs from the
+// rows above it kept in registers:
+//   raw row r      -> per column  rr = right - left,  q = k0 * centre + k1 * (left + right)            (3 byte reads from the staged tile)
+//   gradient row g = r - 1:   dx = k0 * rr(g) + k1 * (rr(g-1) + rr(g+1)),  dy = q(g+1) - q(g-1)  ->  the three products, in double
+//   column sums  c = g - 1:   cs_k = (p_k(c-1) + p_k(c)) + p_k(c+1)                                     (the canonical vertical three-sums)
+//   map row c:                cov_k = (cs_k[x-1] + cs_k[x]) + cs_k[x+1]  — the neighbours' sums through LDS (one ds_read2 per plane) — eigenvalue
+//   local maxima  n = c - 1:  the 3 x 3 test on map rows n-1, n, n+1 (left / right through LDS), appended to the wave's list by ballot
+// i.e. mineig_kernel's additions in mineig_kernel's order (hence the same bits) at about half the instructions of the tiled form:
+// no gradient, product or sum is computed twice (the tiled kernels recompute the vertical sums' inputs for every pair of rows and re-read
+// nine column sums per pixel), nothing but the raw tile, one row of column sums and one row of the map goes through LDS, and the map never
+// goes to HBM (mineig_kernel4 wrote 183 MB per 128 images, nms_kernel4 read 107 MB back).  Borders as cornerMinEigenVal does them
+// (BORDER_REFLECT_101 on the pixels for the Sobel rows / columns, and on the GRADIENT products for the box sums): row -1 of anything is
+// row 1, row H is row H - 2, column -1 is column 1, column W is column W - 2 — two virtual steps behind the last image row flush the
+// pipeline.  A wave keeps two columns of halo on either side (its lanes 0, 1, 62, 63 only feed their neighbours).
+#define DET_SH 32
+#define DET_SW 60
+#define DET_SL 256                       // the wave's list of local maxima in LDS: flushed to the provisional list when a row might not fit
+__global__ __launch_bounds__(64) void mineig_nms_strip_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    constexpr int TR = DET_SH + 6, TWB = 68;                          // raw tile: rows ys-3 .. ys+SH+2, columns X0-3 .. X0+64 (17 dwords)
+    __shared__ __align__(16) unsigned char raw[TR * TWB];
+    __shared__ double xcs[2][3][66];                                  // lane L's column sums at [L + 1], by row parity
+    __shared__ float xe[2][66];                                       // ... and its map value
+    __shared__ unsigned long long s_list[DET_SL];
+    const int W = d.W, H = d.H;
+    const int lane = threadIdx.x;
+    const int X0 = blockIdx.x * DET_SW, ys = blockIdx.y * DET_SH, ye = min(ys + DET_SH, H);
+    const int x = X0 - 2 + lane;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {        // per-frame reset of the detector's counters (nothing in this kernel reads them; [3] is the provisional count)
+        for (int i = lane; i < d.max_cells; i += 64) d.cell_cnt[i] = 0;
+        if (lane < 3) d.counters[lane] = 0;
+    }
+    // ---- the raw tile (clamped coordinates: positions the reflections below never address hold a copy of an edge pixel)
+    const int ty0 = ys - 3, tx0 = X0 - 3;
+    if (tx0 >= 0 && tx0 + TWB <= W) {
+        for (int e = lane; e < TR * (TWB / 4); e += 64) {
+            const int tr = e / (TWB / 4), q = e % (TWB / 4);
+            const int yy = min(max(ty0 + tr, 0), H - 1);
+            ((unsigned*)raw)[e] = ((const U32u*)(src + (size_t)yy * stride + tx0))[q].v;
+        }
+    } else {
+        for (int e = lane; e < TR * TWB; e += 64) {
+            const int tr = e / TWB, tc = e % TWB;
+            const int yy = min(max(ty0 + tr, 0), H - 1), xx = min(max(tx0 + tc, 0), W - 1);
+            raw[e] = src[(size_t)yy * stride + xx];
+        }
+    }
+    __syncthreads();
+    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+    const float k1 = (float)scale, k0 = (float)(2.0 * scale);
+    const bool edge = X0 - 2 <= 0 || X0 - 2 + 63 >= W - 1;           // the wave holds image column 0 or W - 1 (wave-uniform)
+    const bool isL = x == 0, isR = x == W - 1;
+    const bool own = lane >= 2 && lane < 2 + DET_SW && x < W;        // (x >= 0 for these lanes)
+    const bool nmsx = own && x >= 1 && x < W - 1;
+    // sliding state: rr / q of raw rows (r-2, r-1, r); products of gradient rows (g-2, g-1, g); map rows (c-2, c-1, c) with their row maxima
+    float rrA = 0, rrB = 0, rrC = 0, qA = 0, qB = 0, qC = 0;
+    double pA[3] = {0, 0, 0}, pB[3] = {0, 0, 0}, pC[3] = {0, 0, 0};
+    float eA = 0, eB = 0, eC = 0, lB = 0, rB = 0, mA = 0, mB = 0, mC = 0;    // l / r: the row's left / right neighbours; m: max of the row's three
+    int key = (int)0x80000000;
+    int n_list = 0;
+    auto flush = [&]() {                   // ONE global atomic reserves the range (wave-uniform control flow)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&d.counters[3], n_list);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int i = lane; i < n_list; i += 64) d.prov[base + i] = s_list[i];
+        n_list = 0;
+    };
+    const int r_lo = max(ys - 3, 0), r_hi = min(ye + 2, H + 1);
+    const int g_min = (ys - 3 <= 0) ? 0 : r_lo + 1;                    // first gradient row this strip forms
+    const int c_min = (g_min == 0) ? 0 : g_min + 1;                    // first row of column sums / of the map
+#pragma unroll 1
+    for (int r = r_lo; r <= r_hi; ++r) {
+        // ---- stage A: raw row r -> rr, q; gradient row g = r - 1 -> products
+        bool have_p = false;
+        if (r < H) {
+            const unsigned char* t = raw + (r - ty0) * TWB + lane;     // tile column lane <-> image column x - 1
+            float a0 = (float)t[0], a1 = (float)t[1], a2 = (float)t[2];
+            if (edge) { const float l0 = a0; if (isL) a0 = a2; if (isR) a2 = l0; }
+            rrA = rrB; rrB = rrC; qA = qB; qB = qC;
+            rrC = a2 - a0;
+            qC = k0 * a1 + k1 * (a0 + a2);
+        }
+        const int g = r - 1;
+        if (g >= g_min && g <= H - 1) {
+            float rrU, rrM, rrD, qU, qD;
+            if (r < H) { rrU = (g == 0) ? rrC : rrA; rrM = rrB; rrD = rrC; qU = (g == 0) ? qC : qA; qD = qC; }
+            else { rrU = rrB; rrM = rrC; rrD = rrB; qU = qB; qD = qB; }      // g = H - 1: the row below is row H - 2
+            const float gx = k0 * rrM + k1 * (rrU + rrD);
+            const float gy = qD - qU;
+            const float pxx = gx * gx, pxy = gx * gy, pyy = gy * gy;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pA[k] = pB[k]; pB[k] = pC[k]; }
+            pC[0] = (double)pxx; pC[1] = (double)pxy; pC[2] = (double)pyy;
+            have_p = true;
+        }
+        // ---- stage B: column sums of row c = g - 1 (c = H - 1: one step behind the last gradient row, nothing new above)
+        const int c = g - 1;
+        if (!(c >= c_min && c <= H - 1 && (have_p || c == H - 1))) continue;
+        double cs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (have_p) cs[k] = (((c == 0) ? pC[k] : pA[k]) + pB[k]) + pC[k];
+            else cs[k] = (pB[k] + pC[k]) + pB[k];                      // c = H - 1: the row below is row H - 2
+        }
+        // ---- stage C: the neighbours' sums through LDS, covariation, eigenvalue
+        // (a lane's own slot and its neighbours' are different addresses: without the barrier the compiler moves the loads above the stores.
+        //  One wave per workgroup: the barrier costs a wait for the LDS queue.  Two buffers: the next row's stores cannot overtake these loads.)
+        double (*xc)[66] = xcs[c & 1];
+        float* xr = xe[c & 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xc[k][lane + 1] = cs[k];
+        __syncthreads();
+        float cov[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double cl = xc[k][lane], cr = xc[k][lane + 2];
+            if (edge) { const double l0 = cl; if (isL) cl = cr; if (isR) cr = l0; }
+            cov[k] = (float)((cl + cs[k]) + cr);
+        }
+        const float a = cov[0] * 0.5f, b = cov[1], cc = cov[2] * 0.5f;
+        const float ev = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
+        if (own && c >= ys && c < ye) { const int k2 = f2ord(ev); key = k2 > key ? k2 : key; }     // the strip's own pixels feed the image maximum
+        // ---- stage D: the 3 x 3 test on map row n = c - 1
+        xr[lane + 1] = ev;
+        __syncthreads();
+        const float el = xr[lane], er = xr[lane + 2];
+        eA = eB; eB = eC; eC = ev;
+        const float lOld = lB, rOld = rB;
+        mA = mB; mB = mC;
+        lB = el; rB = er;                                              // (row c's neighbours: row n's next step)
+        mC = fmaxf(fmaxf(el, ev), er);
+        const int n = c - 1;
+        if (n >= max(ys, 1) && n <= min(ye - 1, H - 2)) {
+            // row n = the middle row: eB is its value, lOld / rOld its neighbours (saved one step ago), mA / mC the rows above / below
+            const float v = eB;
+            float m = fmaxf(v, mA);
+            m = fmaxf(m, lOld); m = fmaxf(m, rOld);
+            m = fmaxf(m, mC);
+            const bool hit = nmsx && v != 0.f && v == m;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) s_list[n_list + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(n * W + x);
+            n_list += __popcll(bal);
+            if (n_list + 64 > DET_SL) flush();                        // (a map of equal values makes every pixel a "maximum")
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
+    if (lane == 0) atomicMax(d.maxkey, key);
+    if (n_list > 0) flush();
+}
+
 __device__ __forceinline__ void det_geometry(const DetDev& d, float* md, int* cell, int* gw, int* gh) {
     const float s = (*d.first) ? 1.f : 2.f;
     *md = s * d.min_dist;                                    // s*mnMinDistance (int * float)
@@ -389,8 +450,7 @@ __global__ __launch_bounds__(NMS_T) void nms_threshold_kernel(DetDev d, size_t b
     }
 }
 
-// The two-pass form (the map through HBM): batch handles of >= 8 instances keep it — throughput, not latency: the fused pass recomputes the
-// ring (+27 % gradient / eigenvalue work) and holds 55 KB of LDS per workgroup (measured at 128 streams: 1.70 ms per batched frame fused, 1.59 two-pass)
+// The two-pass form of rounds 1-3 (the map through HBM), kept for A/B timing in the instrumented build and for rvio_hip_get_corners(eig)
 __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     det_shift(d, (size_t)blockIdx.z * bs);
     const int W = d.W, H = d.H;
@@ -416,43 +476,6 @@ __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     const size_t slot = (size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1);
     d.cell_ent[slot] = key;
     d.cell_ci[slot] = ci;
-}
-
-// Throughput form (batched launches): one thread = 4 adjacent pixels read as one float4; nearly all of them fail the threshold,
-// so what is left per pixel is a quarter of a load.  Same test, same candidate records (their order in `cand` is as unordered
-// as before: it is an atomic append).  Requires W % 4 == 0.
-__global__ __launch_bounds__(DET_T) void nms_kernel4(DetDev d, size_t bs) {
-    det_shift(d, (size_t)blockIdx.z * bs);
-    const int W = d.W, H = d.H;
-    const int x4 = (blockIdx.x * DET_TW + (threadIdx.x & 63)) * 4, y = blockIdx.y * DET_TH + (threadIdx.x >> 6);
-    if (x4 >= W || y < 1 || y >= H - 1) return;
-    const float mx = ord2f(*d.maxkey);
-    const float thr = (float)((double)mx * d.quality);
-    const float4 q = *(const float4*)(d.eig + (size_t)y * W + x4);
-    const float vv[4] = {q.x, q.y, q.z, q.w};
-    float md = 0.f; int cell = 0, gw = 0, gh = 0;
-    bool geo = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x4 + k;
-        const float v = vv[k];
-        if (x < 1 || x >= W - 1 || !(v > thr) || v == 0.f) continue;
-        const float* e = d.eig + (size_t)y * W + x;
-        float m = v;
-        m = fmaxf(m, e[-W - 1]); m = fmaxf(m, e[-W]); m = fmaxf(m, e[-W + 1]);
-        m = fmaxf(m, e[-1]);     m = fmaxf(m, e[1]);
-        m = fmaxf(m, e[W - 1]);  m = fmaxf(m, e[W]);  m = fmaxf(m, e[W + 1]);
-        if (v != m) continue;
-        if (!geo) { det_geometry(d, &md, &cell, &gw, &gh); geo = true; }
-        const int idx = y * W + x;
-        const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)idx;
-        const int ci = atomicAdd(&d.counters[0], 1);
-        d.cand[ci] = key;
-        const int c = (y / cell) * gw + (x / cell);
-        const size_t slot = (size_t)c * cell * cell + atomicAdd(&d.cell_cnt[c], 1);
-        d.cell_ent[slot] = key;
-        d.cell_ci[slot] = ci;
-    }
 }
 
 #define NEIGH_T 1024
@@ -740,7 +763,6 @@ __global__ __launch_bounds__(GREEDY_T) void greedy_kernel(DetDev d, size_t bs) {
 // subpix_kernel16's LDS row stride in bytes: 11 dwords, so the 16 window rows of a DPP row of lanes start in 16 different banks (43 bytes =
 // 10.75 dwords put every third row into the same one) and a row is 11 whole dwords for the loads
 #define SP_LS 44
-struct __attribute__((packed)) U32u { unsigned v; };
 // one workgroup of 4 waves per corner; thread t <-> window term (i, j) = (t / 16, t % 16) (row / column 15 are padding)
 __global__ __launch_bounds__(SP_T) void subpix_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
     DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 2);

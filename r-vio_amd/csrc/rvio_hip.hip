@@ -1124,14 +1124,16 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     const hipStream_t ds = image_stream(h);
     h->det_set_last = h->runahead ? h->ic : 0;
     static const bool two_pass = ab_env("RVIO_DET_TWO_PASS") != nullptr;   // A/B timing
-    static const bool fused_wide = ab_env("RVIO_DET_FUSED_WIDE") != nullptr;
-    if ((h->wide_px && !fused_wide) || two_pass) {   // batch handles of >= 8 instances: the two-pass throughput form (the map through HBM)
+    if (h->wide_px && !two_pass) {
+        // batch handles of >= 8 instances: the fused pass in its throughput form (one wave per strip, rows walked with the state in registers)
+        hipLaunchKernelGGL(mineig_nms_strip_kernel, dim3((d.W + DET_SW - 1) / DET_SW, (d.H + DET_SH - 1) / DET_SH, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
+        if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));
+        hipLaunchKernelGGL(nms_threshold_kernel, dim3(16, 1, B), dim3(NMS_T), 0, ds, q, bs);
+    } else if (two_pass) {   // rounds 1-3: the map through HBM
         const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
-        if (h->wide_px) hipLaunchKernelGGL(mineig_kernel4, dim3(g.x, (d.H + DET_TH * DET_R4 - 1) / (DET_TH * DET_R4), B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs);
-        else hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
+        hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
-        if (h->wide_px && d.W % 4 == 0) hipLaunchKernelGGL(nms_kernel4, dim3((d.W / 4 + DET_TW - 1) / DET_TW, g.y, B), dim3(DET_T), 0, ds, q, bs);
-        else hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
+        hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
     } else {
         // one stream: min-eigenvalue map + strict 3x3 local maxima in one pass (the map stays in LDS), then the image-wide threshold on the provisional list
         hipLaunchKernelGGL(mineig_nms_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_FH - 1) / DET_FH, B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
