@@ -102,9 +102,12 @@ __global__ __launch_bounds__(64) void klt_kernel16(PyrDev prev, PyrDev next, int
 #pragma unroll 1
     for (int level = 3; level >= 0; --level) {
         if (level >= levels) continue;
-        const uint8_t* I = prev.img[level];
-        const uint8_t* J = next.img[level];
-        const int w = prev.w[level], h = prev.h[level];
+        // (a run-time index into the by-value pyramid descriptors would put both of them into scratch: 200 bytes per lane written and read back
+        //  by every wave — 96 MB per launch of 128 images by the write counter; constant indices + selects stay in scalar registers)
+        const uint8_t* I = level == 0 ? prev.img[0] : level == 1 ? prev.img[1] : level == 2 ? prev.img[2] : prev.img[3];
+        const uint8_t* J = level == 0 ? next.img[0] : level == 1 ? next.img[1] : level == 2 ? next.img[2] : next.img[3];
+        const int w = level == 0 ? prev.w[0] : level == 1 ? prev.w[1] : level == 2 ? prev.w[2] : prev.w[3];
+        const int h = level == 0 ? prev.h[0] : level == 1 ? prev.h[1] : level == 2 ? prev.h[2] : prev.h[3];
         const float sc = (float)(1. / (1 << level));
         float ppx = px * sc, ppy = py * sc;
         if (level == levels - 1) { nx = ppx; ny = ppy; } else { nx = nx * 2.f; ny = ny * 2.f; }
