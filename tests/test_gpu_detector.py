@@ -206,3 +206,44 @@ def test_detector_refuses_what_it_cannot_do(gpu_required):
     with pytest.raises(hip.RvioHipError, match="half-windows"):
         h.track(np.zeros((480, 752), np.uint8), imu, None)
     h.close()
+
+
+@pytest.mark.parametrize("throughput", [0, 1], ids=["latency-forms", "throughput-forms"])
+@pytest.mark.parametrize("W,H,eq", [(200, 136, 0), (757, 483, 1), (1000, 562, 0)], ids=["200x136", "757x483-clahe", "1000x562"])
+def test_image_sizes_that_fit_no_tile(gpu_required, W, H, eq, throughput):
+    """widths / heights that are no multiple of anything the kernels tile by (the strip detector's 60 x 32 strips, 4-pixel words, the 64-lane
+    tiles) on noise images — candidates up against every border: corners,
+    refined corners and the KLT result (features near the borders: reflected staging, early-outs) bit-exact, both kernel families"""
+    from rvio_amd import hip
+    cfg = abi.config_named("B", width=W, height=H, enable_equalizer=eq)
+    rng = np.random.default_rng(W * 1000 + H)
+    base = rng.integers(0, 256, (H + 8, W + 8), dtype=np.uint8)
+    k = np.ones(3) / 3.0                                     # a little smoothing: corners that KLT can hold on to
+    sm = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, base.astype(np.float64))
+    sm = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, sm)
+    sm = np.clip((sm - sm.mean()) * 3.0 + 128.0, 0, 255).astype(np.uint8)
+    im0 = np.ascontiguousarray(sm[4:4 + H, 4:4 + W])
+    im1 = np.ascontiguousarray(sm[3:3 + H, 2:2 + W])         # the scene moved by (+2, +1) px
+    h = hip.RvioHip(cfg)
+    h.kernel_forms(throughput)
+    imu = np.zeros(2, abi.IMU_DTYPE)
+    imu["dt"] = 0.005
+    seen = []
+    for s, im in ((1, im0), (2, im1)):
+        h.track(im, imu, None)
+        if s == 2:
+            got, _ = h.debug_tracked(len(pts0))
+        sn = O.clahe(im) if eq else im
+        seen.append(sn)
+        xy, raw = h.get_corners()
+        want_raw = O.gftt(sn, cfg.n_features, float(f32(cfg.qual_lvl)), float(f32(s) * f32(cfg.min_dist)))
+        assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw), (s, len(raw), len(want_raw))
+        assert np.array_equal(xy, O.detect(cfg, sn, s)), s
+        if s == 1:
+            pts0, _ = h.get_points()
+            assert len(pts0) >= min(20, cfg.n_features) and np.array_equal(pts0, xy)
+    want, st = O.klt(seen[0], seen[1], pts0)
+    assert st.sum() >= len(pts0) // 2, (int(st.sum()), len(pts0))
+    assert np.array_equal(got, want)
+    assert h.frame_info()["n_klt_ok"] == int(st.sum())
+    h.close()
