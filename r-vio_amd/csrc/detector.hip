@@ -480,6 +480,7 @@ __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
 
 #define NEIGH_T 1024
 #define NEIGH_BLOCKS 8
+#define NEIGH_BLOCKS_WIDE 2     // batch handles (measured at 128 streams: 8 -> 134.5 k frames/s, 4 -> 135.3, 2 -> 136.0, 1 -> 135.9)
 // LDS of neigh_kernel's bucket build: keys 8 B, packed xy 4, cell 2, slot 2, order 2 per candidate + cell starts
 #define NEIGH_LDS (DET_FAST_N * (8 + 4 + 2 + 2 + 2) + (DET_FAST_CELLS + 2) * 4)
 

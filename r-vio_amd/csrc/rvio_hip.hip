@@ -1140,7 +1140,11 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // the threshold pass reads mbIsTheFirstImage (cell size) as book-keeping(k-1) left it
         hipLaunchKernelGGL(nms_threshold_kernel, dim3(16, 1, B), dim3(NMS_T), 0, ds, q, bs);
     }
-    hipLaunchKernelGGL(neigh_kernel, dim3(NEIGH_BLOCKS, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
+    // (every workgroup rebuilds the candidate buckets in its LDS before it walks its share of the candidates: 8 of them for the latency of one
+    //  stream, fewer for batch handles, whose width comes from the streams)
+    static const int nb_env = ab_env("RVIO_NEIGH_BLOCKS") ? atoi(ab_env("RVIO_NEIGH_BLOCKS")) : 0;   // A/B timing
+    const unsigned neigh_blocks = nb_env > 0 ? (unsigned)nb_env : (h->wide_px ? NEIGH_BLOCKS_WIDE : NEIGH_BLOCKS);
+    hipLaunchKernelGGL(neigh_kernel, dim3(neigh_blocks, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
     if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
         hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, B), dim3(SPG_T), 0, ds, img, stride, q, src_bs, bs);
