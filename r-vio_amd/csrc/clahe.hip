@@ -73,7 +73,7 @@ __global__ __launch_bounds__(CLAHE_LUT_T) void clahe_lut_kernel(const uint8_t* _
 // 64 different counters (two lanes share a word: a two-way conflict at worst), and the four waves of the workgroup meet only by coincidence.
 // The counts are integers: the same histogram, hence the same LUT bit for bit.  256 threads: wave <-> every fourth row of the tile.
 // T threads: 256 for batch handles (five workgroups per CU), 1024 for one stream (the tile's latency: 16 waves share the rows).
-template <int T>
+template <int T, int RIF = 4>      // RIF: rows of byte loads in flight per thread before the LDS additions
 __global__ __launch_bounds__(T) void clahe_lut_kernel2(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tw, int th,
                                                        int clip_limit, float lut_scale, uint8_t* __restrict__ lut, size_t src_bs, size_t bs, int dbg_tag) {
     DBG_I(blockIdx.x == 0 && blockIdx.z == 0, dbg_tag, 0);
@@ -88,20 +88,20 @@ __global__ __launch_bounds__(T) void clahe_lut_kernel2(const uint8_t* __restrict
     __syncthreads();
     const unsigned one = 1u << (16 * (lane & 1));
     unsigned* const mine = hist2 + (lane >> 1);
-    // four rows x 64 columns of byte loads in flight before the LDS additions; wave <-> every NWV-th row
+    // RIF rows x 64 columns of byte loads in flight before the LDS additions; wave <-> every NWV-th row
     for (int c0 = 0; c0 < tw; c0 += 64) {
         const int c = c0 + lane;
         const bool cok = c < tw;
         const int xs = reflect1(tx * tw + (cok ? c : 0), w);
-        for (int r0 = wv; r0 < th; r0 += 4 * NWV) {
-            int v[4];
+        for (int r0 = wv; r0 < th; r0 += RIF * NWV) {
+            int v[RIF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RIF; ++j) {
                 const int r = r0 + NWV * j;
                 v[j] = (cok && r < th) ? (int)src[(size_t)reflect1(ty * th + r, h) * stride + xs] : -1;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (v[j] >= 0) atomicAdd(&mine[v[j] * 32], one);
+            for (int j = 0; j < RIF; ++j) if (v[j] >= 0) atomicAdd(&mine[v[j] * 32], one);
         }
     }
     __syncthreads();
