@@ -1,6 +1,6 @@
 // rvio_hip.hip — the C-ABI of include/rvio_hip.h: handle, HBM allocation, kernel sequencing.
-// Single translation unit: the two kernel files are included so that one hipcc call
-// builds the whole library (frontend_kernels.hip switches FP contraction off for itself).
+// Single translation unit: the kernel files are included so that one hipcc call builds the whole library
+// (the front end — frontend_kernels / klt3 / klt16 / clahe / detector — sits inside an FP-contraction-off region).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <chrono>
