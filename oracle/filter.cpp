@@ -5,7 +5,7 @@
 //   P1  PreIntegrator.cc:51-194         propagate
 //   U1..U10 Updater.cc:72-628           update
 //   S1/S2 System.cc:279-365             augmentation, window slide, composition
-// Parity unpinned (see rvio_oracle.h).
+// Pinned against the reference's own sources through oracle/_ref (see rvio_oracle.h, tests/test_ref_pins.py).
 #include "rvio_oracle.h"
 #include "mat.hpp"
 #include <cstdio>

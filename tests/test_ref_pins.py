@@ -1,0 +1,336 @@
+"""The CPU oracle held against the reference's OWN sources (oracle/_ref/libref.so).
+
+libref.so is built by `make -C oracle ref` from /root/reference/src/rvio/{Updater,PreIntegrator,Ransac,InputBuffer,FeatureDetector,
+Tracker,System}.cc + util/Numerics.h, unmodified, against the header shim oracle/refshim/ (mini Eigen written from Eigen 3.3's
+documented semantics, OpenCV containers, inert ROS types; the OpenCV IMAGE algorithms forward to the oracle's restatements after
+checking the parameters the reference passes).  These tests therefore pin every line the reference itself wrote — Numerics.h,
+propagate, RANSAC, the whole Updater, the tracker's book-keeping and grid selection, MonoVIO's sequencing, augmentation and
+composition — against oracle/filter.cpp + oracle/frontend.cpp, stage by stage on the golden scenarios and over free-running
+sequences.  They run where /root/reference exists (this container); elsewhere they skip.
+
+Tolerances: per stage 1e-12 (observed <= 1e-16: the two are the same arithmetic up to the order of a few sums); discrete decisions
+(accept set size, reject counts, RANSAC pairs / votes / flags, track tables) must be identical.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+abi = O.abi
+
+try:
+    import ref as R
+
+    HAVE_REF = R.available()
+except Exception as e:  # a broken build must fail loudly where the sources exist
+    if "failed to build" in str(e):
+        raise
+    HAVE_REF = False
+
+pytestmark = pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/libref.so needs the reference's sources (/root/reference)")
+
+STAGE_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def recs_b():
+    cfg = abi.config_named("B")
+    return cfg, S.record_sequence(cfg, n_frames=40)[1]
+
+
+def test_numerics_helpers_bit_exact():
+    """Numerics.h:30-167 + the chi-square table :173-224"""
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        q1, q2 = rng.normal(size=4), rng.normal(size=4)
+        q1 /= np.linalg.norm(q1)
+        q2 /= np.linalg.norm(q2)
+        assert np.array_equal(R.quat_mul(q1, q2), O.quat_mul(q1, q2))
+        assert np.array_equal(R.quat_to_rot(q1), O.quat_to_rot(q1))
+        Rm = O.quat_to_rot(q1)
+        assert np.array_equal(R.rot_to_quat(Rm), O.rot_to_quat(Rm))
+    # every Breckenridge branch (Numerics.h:132-159)
+    for ax in range(3):
+        q = np.zeros(4)
+        q[ax], q[3] = np.cos(0.05), np.sin(0.05)
+        Rm = O.quat_to_rot(q)
+        assert np.array_equal(R.rot_to_quat(Rm), O.rot_to_quat(Rm))
+    for dof in range(1, 501):
+        assert R.chi2_95(dof) == O.chi2_95(dof)
+
+
+@pytest.mark.parametrize("align", [1, 0])
+def test_initialize(align):
+    """System::initialize, System.cc:115-170"""
+    cfg = abi.config_named("B", ini_enable_alignment=align)
+    rng = np.random.default_rng(1)
+    for n in (1, 7, 40):
+        w, a = rng.normal(size=3) * 1e-2, np.array([0.3, -0.2, 9.7]) + rng.normal(size=3) * 0.05
+        xr, Pr = R.initialize(cfg, w, a, n)
+        xo, Po = O.initialize(cfg, w, a, n)
+        assert np.max(np.abs(xr - xo)) <= 1e-15 and np.array_equal(Pr, Po)
+
+
+def test_propagate_stagewise(recs_b):
+    """PreIntegrator::propagate on every recorded frame (window filling and sliding), incl. the in-place mutation of Pkk"""
+    cfg, recs = recs_b
+    worst = 0.0
+    for r in recs:
+        x1, P1 = R.propagate(cfg, r["x0"], r["P0"], r["inp"]["imu"])
+        worst = max(worst, S.state_delta(x1, r["x1"]), np.max(np.abs(P1 - r["P1"])) / max(1e-300, np.max(np.abs(r["P1"]))))
+    assert worst <= STAGE_TOL, worst
+
+
+def test_propagate_small_angle_branch():
+    """PreIntegrator.cc:111-113,148-156: |w| < nSmallAngle"""
+    cfg = abi.config_named("B")
+    rng = np.random.default_rng(2)
+    x = np.zeros(26 + 7 * 3)
+    x[3] = x[13] = 1
+    x[7:10] = [0, 0, 1]
+    x[17:20] = [0.2, -0.1, 0.05]
+    for c in range(3):
+        x[26 + 7 * c + 3] = 1
+    A = rng.normal(size=(42, 42))
+    P = A @ A.T * 1e-4
+    imu = np.zeros(6, dtype=abi.IMU_DTYPE)
+    for i in range(6):
+        imu[i]["w"] = rng.normal(size=3) * (1e-6 if i % 2 else 0.3)
+        imu[i]["a"] = [0.1, 0.2, 9.8]
+        imu[i]["t"] = 0.005 * (i + 1)
+        imu[i]["dt"] = 0.005
+    xr, Pr = R.propagate(cfg, x, P, imu)
+    xo, Po = O.propagate(cfg, x, P, imu)
+    assert S.state_delta(xr, xo) <= STAGE_TOL and np.max(np.abs(Pr - Po)) <= STAGE_TOL * np.max(np.abs(Po))
+
+
+def test_update_stagewise(recs_b):
+    """Updater::update on every recorded update: state, covariance, accepted-feature count (the published landmark cloud,
+    Updater.cc:430-448), gate rejects and invalid-estimate rejects (the ROS_DEBUG lines of :156,267,452)"""
+    cfg, recs = recs_b
+    n_upd, worst = 0, 0.0
+    for r in recs:
+        if not r["did_update"]:
+            continue
+        x2, P2, d = R.update(cfg, r["x1"], r["P1"], r["types"], r["lens"], r["meas"])
+        dg = r["diag"]
+        worst = max(worst, S.state_delta(x2, r["x2"]), np.max(np.abs(P2 - r["P2"])) / np.max(np.abs(r["P2"])))
+        assert d["updated"] == dg["updated"]
+        assert d["n_cloud"] == dg["n_good"], r["k"]
+        # rejected = invalid triangulations + gate failures
+        assert d["gate_rejects"] + d["invalid"] == len(r["types"]) - dg["n_good"], r["k"]
+        n_upd += 1
+    assert n_upd >= 30 and worst <= STAGE_TOL, (n_upd, worst)
+
+
+def test_update_landmarks_match_the_oracle_triangulation(recs_b):
+    """the point cloud the reference publishes (pf in {Rk}, Updater.cc:432-447) equals the one rebuilt from the oracle's
+    (phi, psi, rho): pins U1 (pose chain) and U2 (LM) per feature, not only through the fused state"""
+    cfg, recs = recs_b
+    T = np.array(list(cfg.T_bc)).reshape(4, 4)
+    Ric, tic = T[:3, :3], T[:3, 3]
+    checked = 0
+    for r in recs[8::6]:
+        if not r["did_update"]:
+            continue
+        x1 = r["x1"]
+        _, _, d = R.update(cfg, x1, r["P1"], r["types"], r["lens"], r["meas"])
+        ci = 0
+        for f in range(len(r["types"])):
+            if not r["diag"]["accepted"][f]:
+                continue
+            nph = r["lens"][f] - 1
+            rel = x1[-7 * nph:] if r["types"][f] == ord("1") else x1[26:26 + 7 * nph]
+            qI, tI = rel[0:4].copy(), -O.quat_to_rot(rel[0:4]) @ rel[4:7]
+            for i in range(1, nph):
+                qi, ti = rel[7 * i:7 * i + 4], rel[7 * i + 4:7 * i + 7]
+                tI = O.quat_to_rot(qi) @ (tI - ti)
+                qI = O.quat_mul(qi, qI)
+            phi, psi, rho = r["diag"]["pfinv"][f]
+            ep = np.array([np.cos(phi) * np.sin(psi), np.sin(phi), np.cos(phi) * np.cos(psi)])
+            pfk = O.quat_to_rot(qI) @ (Ric @ (ep / rho) + tic) + tI
+            assert np.max(np.abs(pfk - d["cloud"][ci])) <= 1e-12 * max(1.0, np.linalg.norm(pfk)), (r["k"], f)
+            ci += 1
+            checked += 1
+        assert ci == d["n_cloud"]
+    assert checked > 40
+
+
+@pytest.mark.parametrize("name,mix", [("A", "half"), ("B", "all2"), ("C", "half"), ("E", "half")])
+def test_update_at_full_load(name, mix):
+    """the worst-case load of SURVEY.md 8(d) (ceil(F/2) features, tall stack: the Givens compression Updater.cc:469-536 and
+    its rank scan run) at the stock window, the headline window, and the 20- and 30-clone windows"""
+    cfg = abi.config_named(name)
+    seq, recs = S.record_sequence(cfg, n_frames=cfg.max_track_len + 4, duration=(38 + cfg.max_track_len + 8) / 20.0)
+    r = recs[-1]
+    n_feat = None if name != "E" else 160  # keep the mini-Eigen run to seconds
+    types, lens, meas = S.worst_case_tracks(cfg, r, seq, n_feat=n_feat, mix=mix)
+    xo, Po, dg = O.update(cfg, r["x1"], r["P1"], types, lens, meas)
+    xr, Pr, d = R.update(cfg, r["x1"], r["P1"], types, lens, meas)
+    assert dg["updated"] and d["updated"] and dg["n_rows"] > 6 * (cfg.max_track_len - 1)
+    assert d["n_cloud"] == dg["n_good"]
+    assert S.state_delta(xr, xo) <= 1e-11 and np.max(np.abs(Pr - Po)) <= 1e-11 * np.max(np.abs(Po))
+
+
+def test_update_passthrough_when_too_few(recs_b):
+    """Updater.cc:460,621-627"""
+    cfg, recs = recs_b
+    r = next(r for r in recs if r["did_update"] and len(r["types"]) >= 2)
+    x2, P2, d = R.update(cfg, r["x1"], r["P1"], r["types"][:2], r["lens"][:2], r["meas"][:2])
+    assert d["updated"] == 0 and np.array_equal(x2, r["x1"]) and np.array_equal(P2, r["P1"])
+    xo, Po, dg = O.update(cfg, r["x1"], r["P1"], r["types"][:2], r["lens"][:2], r["meas"][:2])
+    assert dg["updated"] == 0 and np.array_equal(xo, x2)
+
+
+def test_augment_compose_stagewise(recs_b):
+    """System.cc:279-365 (the block lifted verbatim at build time): window filling, sliding, composition; the returned pose"""
+    cfg, recs = recs_b
+    worst, slid = 0.0, 0
+    for r in recs:
+        x3, P3, pp, pq = R.augment_compose(cfg, r["x2"], r["P2"], r["do_augment"])
+        assert len(x3) == len(r["x3"])
+        slid += int(len(r["x2"]) == len(r["x3"]) and r["do_augment"])
+        worst = max(worst, S.state_delta(x3, r["x3"]), np.max(np.abs(P3 - r["P3"])) / np.max(np.abs(r["P3"])),
+                    np.max(np.abs(pp - r["pose_p"])), np.max(np.abs(pq - r["pose_q"])))
+    assert slid > 5 and worst <= STAGE_TOL, (slid, worst)
+
+
+@pytest.mark.parametrize("use_sampson", [1, 0])
+def test_ransac_pairs_votes_flags(use_sampson):
+    """Ransac::FindInliers with the glibc rand() stream the reference draws (never seeded = seed 1): the 16 index pairs, the 16
+    vote counts, the returned inlier count and the output flags are identical; also with status-0 points and < 17 candidates"""
+    cfg = abi.config_named("B", use_sampson=use_sampson)
+    seq = O.rv.synth.SynthSequence(cfg, duration=4.0, seed=3)
+    rng = np.random.default_rng(5)
+    # candidate counts 17..31 are excluded: the reference's SetPointPair never returns there
+    for trial, n in enumerate((40, 200, 64, 16)):
+        k = 45 + trial
+        imu = seq.imu_between(k)
+        p1 = np.c_[rng.uniform(-0.5, 0.5, (n, 2)), np.ones(n)]
+        # a small rotation + translation flow with outliers
+        p2 = p1.copy()
+        p2[:, :2] += 0.01 * rng.normal(size=(n, 2)) * (rng.uniform(size=(n, 1)) < 0.3) + 0.002
+        flags = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+        if n == 16:
+            flags[:] = 1
+        nr, fr, pairs, votes = R.ransac(cfg, p1, p2, imu, flags, seed=1)
+        st = np.zeros(35, np.int32)
+        O.lib().orc_srand(O._p(st, O.ip), 1)
+        no, fo, winner, pairs_o, _ = O.ransac(cfg, p1, p2, imu, flags, st)
+        assert nr == no and np.array_equal(fr, fo), n
+        if flags.sum() > 16:
+            assert np.array_equal(pairs, np.asarray(pairs_o).reshape(16, 2))
+            assert int(np.argmax(votes)) == winner  # first maximum wins (Ransac.cc:218-222)
+
+
+def _tracks_equal(a, b):
+    ta, la, ma = a
+    tb, lb, mb = b
+    if not (np.array_equal(ta, tb) and np.array_equal(la, lb)):
+        return False
+    return all(np.array_equal(ma[f, : la[f]], mb[f, : la[f]]) for f in range(len(ta)))
+
+
+def test_tracker_bookkeeping_direct_sequence():
+    """Tracker::track (Tracker.cc:179-396) + FeatureDetector::FindNewer / ChessGrid (FeatureDetector.cc:78-150) over 120 frames
+    in direct-track mode: the feature table, every history length and every emitted track (types, lengths, float coordinates)
+    are bit-identical to the oracle's tracker"""
+    cfg = abi.config_named("B")
+    seq = O.rv.synth.SynthSequence(cfg, duration=(38 + 124) / 20.0, seed=0)
+    to, tr = O.Tracker(cfg), R.Tracker(cfg)
+    drv = O.rv.synth.DirectTrackDriver(seq)
+    emitted = 0
+    for k in range(39, 39 + 120):
+        inp = drv.inputs(k)
+        to.track_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        tr.track_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        po, ho = to.get_points()
+        pr, hr = tr.get_points()
+        assert np.array_equal(po, pr) and np.array_equal(ho, hr), k
+        a, b = to.get_tracks(), tr.get_tracks()
+        assert _tracks_equal(a, b), k
+        emitted += len(a[0])
+        drv.after(po)
+    assert emitted > 500
+
+
+def test_tracker_on_images_small():
+    """the image path (CLAHE -> detector -> LK -> undistort -> RANSAC -> book-keeping -> refill) through the reference's Tracker with
+    the OpenCV calls forwarded to the oracle's restatements: same feature table and tracks, 25 frames of the half-size camera"""
+    cfg = S.small_image_config()
+    seq = O.rv.synth.SynthSequence(cfg, duration=(38 + 30) / 20.0, seed=0)
+    to, tr = O.Tracker(cfg), R.Tracker(cfg)
+    for k in range(39, 39 + 25):
+        imu, img = seq.imu_between(k), seq.render(k)
+        to.track(img, imu, None)
+        tr.track(img, imu, None)
+        po, ho = to.get_points()
+        pr, hr = tr.get_points()
+        assert np.array_equal(po, pr) and np.array_equal(ho, hr), k
+        assert _tracks_equal(to.get_tracks(), tr.get_tracks()), k
+
+
+def _free_run(cfg, n, image, seed=0, **kw):
+    seq = O.rv.synth.SynthSequence(cfg, duration=(38 + n + 4) / 20.0, seed=seed, **kw)
+    w, a, ni = seq.init_from_static(38)
+    x0, P0 = O.initialize(cfg, w, a, ni)
+    so, sr = O.System(cfg), R.System(cfg)
+    so.set_state(x0, P0)
+    sr.set_state(x0, P0)
+    drv = None if image else O.rv.synth.DirectTrackDriver(seq)
+    worst, worst_x, n_upd, ranks = 0.0, 0.0, 0, []
+    for k in range(39, 39 + n):
+        if image:
+            imu = seq.imu_between(k)
+            io, _, ppo, pqo = so.frame(imu, None, img=seq.render(k))
+            ir, ppr, pqr = sr.frame(imu, None, img=seq.render(k))
+        else:
+            inp = drv.inputs(k)
+            io, _, ppo, pqo = so.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])
+            ir, ppr, pqr = sr.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])
+            drv.after(so.tracker().get_points()[0])
+        xo, Po = so.get_state()
+        xr, Pr = sr.get_state()
+        assert len(xo) == len(xr), k
+        worst = max(worst, S.state_delta(xo, xr), np.max(np.abs(Po - Pr)) / np.max(np.abs(Po)), np.max(np.abs(ppo - ppr)))
+        worst_x = max(worst_x, S.state_delta(xo, xr))
+        assert io["n_tracked_out"] == ir["n_tracked_out"], k
+        if io["updated"]:
+            n_upd += 1
+            assert ir["updated"] == 1 and ir["n_cloud"] == io["n_feat_accepted"], (k, ir, io)
+            ranks.append(so.last_rank())
+        assert _tracks_equal(so.tracker().get_tracks(), sr.get_tracks()), k
+    return worst, n_upd, (ranks, worst_x)
+
+
+def test_monovio_free_running_direct_241_frames():
+    """System::MonoVIO itself (PushImuData / PushImageData / GetMeasurements / track / propagate / update / augment / compose),
+    241 free-running frames in direct-track mode, against the oracle's orc_system_frame: every frame's state, covariance, pose,
+    accepted-feature count and track table.  The sequence includes the frames where the reference's rank scan cuts rows off."""
+    cfg = abi.config_named("B")
+    worst, n_upd, ranks = _free_run(cfg, 241, image=False)
+    assert n_upd > 200
+    assert worst <= 1e-10, worst
+
+
+def test_monovio_free_running_images_small():
+    """the same through rendered images (CLAHE + detector + LK forwarded to the restatements), half-size camera, 60 frames"""
+    cfg = S.small_image_config()
+    worst, n_upd, _ = _free_run(cfg, 60, image=True)
+    assert n_upd >= 40
+    assert worst <= 1e-10, worst
+
+
+def test_monovio_at_rest_direct():
+    """the stationary sequence — the hardest case of tests/test_gpu_truncation.py.  With zero parallax the window has unobservable
+    directions and the filter amplifies rounding noise: the reference's sources and their restatement, which differ only in the
+    order of a few sums (S = (Hn P) Hn^T vs Hn (P Hn^T), Eigen's aliased in-place symmetrisation), start 1e-16 apart at the first
+    update, grow about 3x per frame for 20 frames and saturate near 3e-7 in the state (1e-5 relative in P).  That is the
+    reference's OWN noise floor on this sequence; every discrete decision (accept sets, track tables) still agrees.  The bar
+    below is that floor, not a parity tolerance: DESIGN.md section 3 quotes it beside the device's at-rest figure."""
+    cfg = abi.config_named("B")
+    worst, n_upd, (_, worst_x) = _free_run(cfg, 100, image=False, motion="stationary")
+    assert n_upd > 60
+    assert 1e-9 < worst_x < 5e-6, worst_x   # measured 3.4e-7; > 1e-9 documents that the amplification is real
+    assert worst < 1e-4, worst             # measured 2.0e-5 (covariance, relative)
