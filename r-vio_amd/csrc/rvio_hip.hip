@@ -19,6 +19,7 @@
 #include "filter_kernels2.hip"
 #include "solve6.hip"
 #include "solve7.hip"
+#include "solve9.hip"   // round 5: the solve as blocked SPD factorisations on the matrix cores (one instance; every window up to 6n = 192)
 #ifdef RVIO_DBG_CLOCKS
 #include "solve8.hip"   // the solve without a pivot search: measured, NOT adopted (its header says why); instrumented build only, RVIO_SOLVE8=1
 #endif
@@ -70,6 +71,8 @@ struct rvio_hip {
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
+    int solve9_nt = 0;           // solve9_kernel (solve9.hip): tiles per side of the padded clone block (4, 6, 8, 12), 0: not used (batch handles, RVIO_SOLVE7=1)
+    double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles
     bool solve8 = false;         // one instance, 6n <= 64: the solve without a pivot search (solve8.hip) — Pcc^-1 beside the per-feature stage, B^-1 on the chain
     bool pinv_ready = false;     // Pinv holds the inverse of the clone block the next solve will see (written by the fused per-feature launch)
     double* Pinv = nullptr;      // 64 x 64
@@ -543,6 +546,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
             h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
             if (ab_env("RVIO_SOLVE6") && h->solve5_variant) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernel behind gemm_T_kernel
+            // one instance, 6n > 64: the blocked SPD solve (solve9.hip).  Measured on full-load updates (tools/solve9_probe.py, profiles/r05_solve9_probe.txt):
+            // 6n = 84: 94.0 us against solve7's 102.6; 120: 173 against 212; 180: 511 against 797.  At 6n <= 64 the register-tableau elimination
+            // stays (36.6 us against 47.8: there the 16 x 16 in-wave factor, eight of them in sequence, is the chain).  RVIO_SOLVE7=1 (instrumented build)
+            // keeps solve7 everywhere, RVIO_SOLVE9=1 takes solve9 at 6n <= 64 too: A/B timing.
+            if (batch == 1 && c6m <= 192 && (c6m > 64 || ab_env("RVIO_SOLVE9")) && !ab_env("RVIO_SOLVE7")) {
+                h->solve9_nt = (c6m <= 64) ? 4 : (c6m <= 96) ? 6 : (c6m <= 128) ? 8 : 12;
+                DALLOC(h, h->S9scr, (size_t)5 * h->solve9_nt * h->solve9_nt * S9_TILE);
+            }
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
             // (round 3, measured and NOT adopted: solve7 with T through the L2 scratch instead of LDS — 11 KB of LDS, eight workgroups per CU, no gemm_T
@@ -885,6 +896,14 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         return;
     }
 #endif
+    if (h->solve9_nt) {   // blocked SPD factorisations on the matrix cores (solve9.hip): one workgroup, one launch
+        switch (h->solve9_nt) {
+        case 4: hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        case 6: hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        case 8: hipLaunchKernelGGL((solve9_kernel<2, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        default: hipLaunchKernelGGL((solve9_kernel<3, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        }
+    }
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
     case 1: {
         static const int nw = ab_env("RVIO_S7_NW") ? atoi(ab_env("RVIO_S7_NW")) : 4;

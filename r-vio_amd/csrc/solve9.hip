@@ -1,0 +1,473 @@
+// solve9.hip — W = (s2 I + A Pcc)^-1, y = W b, dx = Pc y, state injection (Updater.cc:540-613), generation 9 (round 5):
+// the solve as blocked factorisations of SYMMETRIC POSITIVE DEFINITE matrices on the FP64 matrix cores.
+//
+// solve7 eliminates the non-symmetric T = s2 I + A Pcc column by column (Gauss-Jordan, partial pivoting): ~980 cycles per column on
+// ONE CU, every column a pivot search + a cross-wave hand-over + a rank-1 update on the vector ALU (35.7 us at 6n = 60, 796 us at 180).
+// Here the same W comes from pieces that never need a pivot search (tools/solve9_model.py is the NumPy model of this file):
+//
+//     Pcc = L L^T                     blocked Cholesky (positive-SEMI-definite safe: a clone with zero covariance — an IMU stream
+//                                     that ended — gives a zero column of L, exactly as the reference's pivoted LU tolerates it)
+//     M   = s2 I + L^T A L            symmetric, every eigenvalue >= s2: elimination in natural order is unconditionally stable
+//     Mi  = M^-1                      blocked symmetric sweep in its Cholesky form (per step: Z = F old, S -= Z^T Z, new = F^T Z)
+//     W   = (I - (A L) Mi L^T) / s2   Woodbury; no inverse of L or Pcc is ever formed, cond(Pcc) does not enter
+//
+// cond(M) = cond(T) <= 5e3 on every sequence of the test suite (median 1.5): against numpy.linalg.inv(T) the model sits at
+// 1e-15 .. 8e-14 (5e-12 in U = Pc W at rest), and at LAPACK's own residual on a synthetic cond(T) = 7e8 case.
+//
+// Layout.  Everything is 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64: lane (li = lane & 15, lk = lane >> 4),
+// register r <-> element (4 r + lk, li).  A tile in that layout IS the B operand of four consecutive MFMAs, and it is the A operand
+// of its TRANSPOSE — so every product is written as X^T Y of stored tiles (the matrices involved are symmetric, or kept in both
+// orientations: G = L^T beside L, Q^T beside Q) and operands never go through a layout conversion.  NW = WGR^2 waves; wave (a, b)
+// owns the BS x BS tiles of block row a, block column b (NT = WGR BS tiles per side, 16 NT >= 6n).
+//   * one in-wave primitive on the 16 x 16 diagonal tile: forward elimination of [Mkk | I] without pivoting (16 steps; the pivot
+//     row travels through the wave's LDS scratch) -> F = Lkk^-1 and F^T.  Every wave runs it redundantly on the published tile:
+//     no second barrier, no hand-over of the result.
+//   * Cholesky step k: row panel G(k, j) = F S(k, j), L(j, k) = S(k, j)^T F^T, trailing S(i, j) -= G(k, i)^T G(k, j)  (i <= j).
+//   * sweep step k:    Z_j = F S(k, j);  S(i, j) -= Z_i^T Z_j;  S(k, j) = F^T Z_j;  S(i, k) = Z_i^T F;  S(k, k) = -F^T F.
+//   * the GEMM phases (Q = A L, M, X = Mi G, W) read tiles from a scratch slab in L2 (written by the phase before, one barrier).
+// One workgroup per instance, one launch; the row panel of a step crosses waves through LDS (double-buffered: one barrier per step).
+#pragma once
+#include "rvio_dev.h"
+
+typedef double s9_d4 __attribute__((ext_vector_type(4)));
+#define S9_TILE 256                                  // doubles of a stored tile: [r][lane]
+
+__device__ __forceinline__ bool lane_is(int li, int lk, int a, int b) { return li == a && lk == b; }
+struct S9Wave {                                      // per-wave LDS scratch of the in-wave primitive
+    double rowb[2][128];                              // pivot row of [M | E], by step parity
+    double tb[16 * 17 + 64 + 192];                   // transposition of a tile (272), then 3 x 64 slots for stores that are not meant to be read
+};
+typedef __attribute__((address_space(3))) double s9_lds_t;      // LDS-qualified: ds_read / ds_write instead of flat accesses
+typedef volatile s9_lds_t* s9_vlp;
+
+// acc += X^T Y for tiles in the accumulator layout
+__device__ __forceinline__ s9_d4 s9_tn(const s9_d4& x, const s9_d4& y, s9_d4 acc) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ s9_d4 s9_zero() { s9_d4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
+// Scratch tiles are written and read by waves of ONE workgroup, i.e. of one CU: __syncthreads() (a workgroup-scope release / acquire
+// + s_barrier) between the phase that writes and the phase that reads is all the ordering they need, and the loads are served by the
+// CU's own L1 / the XCD's L2.  (Agent-scope loads — what a slab shared between CUs would need — leave the XCD: measured 4x slower.)
+__device__ __forceinline__ s9_d4 s9_ldg(const double* t, int lane) {
+    s9_d4 v = {t[lane], t[64 + lane], t[128 + lane], t[192 + lane]};
+    return v;
+}
+__device__ __forceinline__ void s9_stg(double* t, int lane, const s9_d4& v) {
+    t[lane] = v[0]; t[64 + lane] = v[1]; t[128 + lane] = v[2]; t[192 + lane] = v[3];
+}
+// a tile of the row panel in LDS (written before a workgroup barrier, read after it)
+__device__ __forceinline__ s9_d4 s9_lds(const double* t_, int lane) {
+    const s9_lds_t* t = (const s9_lds_t*)t_;
+    s9_d4 v = {t[lane], t[64 + lane], t[128 + lane], t[192 + lane]};
+    return v;
+}
+__device__ __forceinline__ void s9_sts(double* t_, int lane, const s9_d4& v) {
+    s9_lds_t* t = (s9_lds_t*)t_;
+    t[lane] = v[0]; t[64 + lane] = v[1]; t[128 + lane] = v[2]; t[192 + lane] = v[3];
+}
+// The wave-private LDS scratch is only ever touched through VOLATILE LDS pointers: the compiler keeps those accesses in program
+// order, and the LDS operations of one wave complete in order — a store followed by loads of other lanes' slots needs nothing else.
+// the transpose of a tile, through the wave's scratch
+__device__ __forceinline__ s9_d4 s9_transpose_tb(const s9_d4& v, double* tb_, int li, int lk) {
+    s9_vlp tb = (s9_vlp)tb_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tb[(4 * r + lk) * 17 + li] = v[r];
+    s9_d4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = tb[li * 17 + 4 * r + lk];
+    return t;
+}
+
+// The in-wave primitive (run by ONE wave per step; the others wait for its result at a barrier — run redundantly by all 16 waves it is
+// bound by instruction issue, four waves to a SIMD).  m: a symmetric positive (semi-)definite 16 x 16 tile.  Blocked forward
+// elimination of [m | I] in natural order, FOUR rows per step (rows 4 b .. 4 b + 3 are register b of every lane):
+//     a    = the 4 x 4 diagonal block of the current tile,   F4 = chol(a)^-1 (lower triangular, formed in registers by every lane)
+//     Z    = F4 m[blk, :]   (= the block row of the tile's Cholesky factor),   Ze = F4 E[blk, :]   (= rows blk of F, final)
+//     m   -= Z^T Z,  E -= Z^T Ze  on the rows below the block:  ONE v_mfma_f64_16x16x4 each — the A operand of lane (li, lk) is
+//            -Z(lk, li) (zero for the rows up to the block), the B operand is Z(lk, li) resp. Ze(lk, li): what the lane holds anyway.
+// E ends as F = (chol m)^-1.  A pivot <= tol * ref[p] (ref: the ORIGINAL diagonal of the matrix the tile belongs to; nullptr: plain
+// positivity) is a zero direction: no elimination with it, row p of F is zero (the convention of a semi-definite Cholesky).
+// returns F and F^T; bad |= 1 when a pivot is not positive (or NaN) where it has to be.
+// Serial chain per block step: one LDS round trip (block rows of m and E out, 10 + 8 doubles back), four inverse square roots
+// (v_rsq_f64 + two Newton steps) with a handful of FMAs between them, two MFMAs.  Four block steps per tile.
+__device__ __forceinline__ double s9_rsqrt(double t) {
+    double y = __builtin_amdgcn_rsq(t);
+    const double h = 0.5 * t;
+    y = fma(y, fma(-(h * y), y, 0.5), y);
+    y = fma(y, fma(-(h * y), y, 0.5), y);
+    return y;
+}
+__device__ __forceinline__ void s9_factor(s9_d4 m, const double* ref_, double tol, S9Wave* ws, int li, int lk, s9_d4& F, s9_d4& Ft, int& bad) {
+    const s9_lds_t* ref = (const s9_lds_t*)ref_;
+    const int lane = li + 16 * lk;
+    s9_d4 e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = (4 * r + lk == li) ? 1.0 : 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        s9_vlp rb = (s9_vlp)ws->rowb[b & 1];
+        rb[lane] = m[b];                                // R(lk, li)  = m(4 b + lk, li)
+        rb[64 + lane] = e[b];                           // Re(lk, li) = E(4 b + lk, li)
+        const double a00 = rb[0 * 16 + 4 * b + 0];
+        const double a10 = rb[1 * 16 + 4 * b + 0], a11 = rb[1 * 16 + 4 * b + 1];
+        const double a20 = rb[2 * 16 + 4 * b + 0], a21 = rb[2 * 16 + 4 * b + 1], a22 = rb[2 * 16 + 4 * b + 2];
+        const double a30 = rb[3 * 16 + 4 * b + 0], a31 = rb[3 * 16 + 4 * b + 1], a32 = rb[3 * 16 + 4 * b + 2], a33 = rb[3 * 16 + 4 * b + 3];
+        double Rv[4], Ev[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { Rv[v] = rb[v * 16 + li]; Ev[v] = rb[64 + v * 16 + li]; }
+        double lim[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lim[k] = ref_ ? tol * ref[4 * b + k] : 0.0;
+        auto pivot = [&](double t, int k) {             // 1 / sqrt(t), or 0 for a zero direction
+            const bool ok = t > lim[k] && t > 0.0;      // false for NaN too
+            if (!ok && (ref_ == nullptr || !(t >= -lim[k]))) bad |= 1;
+            return ok ? s9_rsqrt(t) : 0.0;
+        };
+        // chol(a) through its inverse diagonal i_k = 1 / l_kk
+        const double i0 = pivot(a00, 0);
+        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+        const double i1 = pivot(fma(-l10, l10, a11), 1);
+        const double l21 = fma(-l20, l10, a21) * i1, l31 = fma(-l30, l10, a31) * i1;
+        const double i2 = pivot(fma(-l21, l21, fma(-l20, l20, a22)), 2);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * i2;
+        const double i3 = pivot(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33))), 3);
+        // F4 = chol(a)^-1
+        const double f00 = i0, f11 = i1, f22 = i2, f33 = i3;
+        const double f10 = -(l10 * f00) * i1;
+        const double f21 = -(l21 * f11) * i2;
+        const double f32 = -(l32 * f22) * i3;
+        const double f20 = -fma(l21, f10, l20 * f00) * i2;
+        const double f31 = -fma(l32, f21, l31 * f11) * i3;
+        const double f30 = -fma(l32, f20, fma(l31, f10, l30 * f00)) * i3;
+        // row lk of F4
+        const double g0 = lk == 0 ? f00 : lk == 1 ? f10 : lk == 2 ? f20 : f30;
+        const double g1 = lk == 0 ? 0.0 : lk == 1 ? f11 : lk == 2 ? f21 : f31;
+        const double g2 = lk <= 1 ? 0.0 : lk == 2 ? f22 : f32;
+        const double g3 = lk == 3 ? f33 : 0.0;
+        const double z = fma(g3, Rv[3], fma(g2, Rv[2], fma(g1, Rv[1], g0 * Rv[0])));
+        const double ze = fma(g3, Ev[3], fma(g2, Ev[2], fma(g1, Ev[1], g0 * Ev[0])));
+        const double za = (li > 4 * b + 3) ? -z : 0.0;
+        m = __builtin_amdgcn_mfma_f64_16x16x4f64(za, z, m, 0, 0, 0);
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(za, ze, e, 0, 0, 0);
+        e[b] = ze;
+    }
+    F = e;
+    Ft = s9_transpose_tb(F, ws->tb, li, lk);
+}
+
+// sum_{k0 <= k < k1} X_k^T Y_k with the operands of step k + 1 in flight while step k multiplies
+template <class FX, class FY>
+__device__ __forceinline__ s9_d4 s9_gemm(int k0, int k1, FX fx, FY fy) {
+    s9_d4 acc = s9_zero();
+    if (k0 >= k1) return acc;
+    s9_d4 xa = fx(k0), xb = fy(k0);
+#pragma unroll 2
+    for (int k = k0; k < k1; ++k) {
+        s9_d4 na = xa, nb = xb;
+        if (k + 1 < k1) { na = fx(k + 1); nb = fy(k + 1); }
+        acc = s9_tn(xa, xb, acc);
+        xa = na; xb = nb;
+    }
+    return acc;
+}
+
+// A wave's BS x BS block of a product: per k the BS y-tiles are loaded once and each x-tile once (2 BS tile loads for BS^2 products —
+// a single CU takes 64 B per clock from its L1: at 12 tiles per side the tile-at-a-time loop above is bound by exactly that)
+template <int BS, class FX, class FY, class FOK>
+__device__ __forceinline__ void s9_gemm_block(int k0, int k1, s9_d4 (&acc)[BS * BS], FX fx, FY fy, FOK ok) {
+#pragma unroll 1
+    for (int k = k0; k < k1; ++k) {
+        s9_d4 y[BS];
+#pragma unroll
+        for (int qj = 0; qj < BS; ++qj) y[qj] = fy(k, qj);
+#pragma unroll
+        for (int qi = 0; qi < BS; ++qi) {
+            const s9_d4 xq = fx(k, qi);
+#pragma unroll
+            for (int qj = 0; qj < BS; ++qj)
+                if (ok(k, qi, qj)) acc[qi * BS + qj] = s9_tn(xq, y[qj], acc[qi * BS + qj]);
+        }
+    }
+}
+
+// BS x BS tiles per wave, WGR x WGR waves: NT = WGR * BS tiles per side.  scr: 5 * NT^2 * 256 doubles per instance.
+template <int BS, int WGR>
+__global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
+                                                                const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ scr,
+                                                                double* __restrict__ Wout, double* __restrict__ x_out, size_t bs, size_t scr_bs) {
+    meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
+    scr = (double*)((char*)scr + (size_t)blockIdx.z * scr_bs);
+    constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
+    __shared__ double s_rowp[2][NT][S9_TILE];          // the row panel of a step, by step parity
+    __shared__ S9Wave s_ws[1];                         // the in-wave primitive runs in wave 0
+    __shared__ double s_F[2][S9_TILE];                 // its result: F and F^T of the step's diagonal tile
+    __shared__ double s_tb[NW][16 * 17];               // per-wave transposition scratch (Q^T, L from G)
+    __shared__ double s_ref[NP];                        // the original diagonal of Pcc (the scale of "zero" for its Cholesky)
+    __shared__ double s_b[NP], s_y[NP], s_yp[NT][NP];
+    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    __shared__ double s_part[4 * (24 + 6 * RVIO_MAX_LEN)];
+    __shared__ int s_bad;
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int wa = wv / WGR, wb = wv % WGR;             // this wave's block row / block column
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    DBG_R(true, 2);
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; s_bad = 0; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        return;
+    }
+    DBG_T(30);
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    S9Wave* ws = &s_ws[0];
+    double* bL = scr;                                   // L(i, k), i >= k
+    double* bG = scr + (size_t)NT * NT * S9_TILE;       // G = L^T: G(k, j), j >= k
+    double* bQ = scr + (size_t)2 * NT * NT * S9_TILE;   // Q = A L;   later X = Mi G
+    double* bQt = scr + (size_t)3 * NT * NT * S9_TILE;  // Q^T
+    double* bMi = scr + (size_t)4 * NT * NT * S9_TILE;  // M^-1
+    auto tile = [&](double* b, int i, int j) { return b + (size_t)(i * NT + j) * S9_TILE; };
+    // A(i, j) as a tile, straight from the information block (read-only input: ordinary loads); zero beyond 6n
+    auto ld_A = [&](int i, int j) {
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+            v[r] = (row < c6 && col < c6) ? Ab[(size_t)row * ldh + col] : 0.0;
+        }
+        return v;
+    };
+
+    // ---- P0: the clone block of P into the tableau (symmetric: element (row, col) is read as P[col + row ld], coalesced along li); identity beyond 6n
+    s9_d4 S[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+            S[s][r] = (row < c6 && col < c6) ? P[(size_t)(24 + col) + (size_t)(24 + row) * ld] : (row == col ? 1.0 : 0.0);
+        }
+    }
+    for (int i = tid; i < NP; i += NTH) {
+        s_ref[i] = (i < c6) ? P[(size_t)(24 + i) * (ld + 1)] : 1.0;
+        s_b[i] = (i < c6) ? Ab[(size_t)i * ldh + c6] : 0.0;
+    }
+    int bad = 0;
+    __syncthreads();
+    DBG_T(31);
+
+    // ---- P1: Pcc = L L^T.  Only tiles i <= j are live (the row panel of step k is S(k, j >= k)).
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {
+        double (*rowp)[S9_TILE] = s_rowp[k & 1];
+        if (wa == k / BS) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+                if (i == k && j >= k) s9_sts(rowp[j], lane, S[s]);
+            }
+        }
+        __syncthreads();
+        if (k == 0) DBG_T(40);
+        s9_d4 F, Ft;
+        if (wv == 0) {
+            s9_factor(s9_lds(rowp[k], lane), s_ref + 16 * k, 1e-12, ws, li, lk, F, Ft, bad);
+            s9_sts(s_F[1], lane, Ft);
+        }
+        __syncthreads();
+        Ft = s9_lds(s_F[1], lane);
+        if (k == 0) DBG_T(41);
+        // G(k, c) = F S(k, c) for the block columns / block rows this wave touches
+        s9_d4 Zr[BS], Zc[BS];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) {
+            const int ir = wa * BS + q, jc = wb * BS + q;
+            Zr[q] = (ir > k) ? s9_tn(Ft, s9_lds(rowp[ir], lane), s9_zero()) : s9_zero();
+            Zc[q] = (jc >= k) ? s9_tn(Ft, s9_lds(rowp[jc], lane), s9_zero()) : s9_zero();
+        }
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+            if (i == k && j >= k) {
+                s9_d4 g = Zc[s % BS];
+                if (j == k) {                          // the diagonal tile of G = Lkk^T: exact zeros below the diagonal
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (4 * r + lk > li) g[r] = 0.0;
+                }
+                s9_stg(tile(bG, k, j), lane, g);
+                s9_stg(tile(bL, j, k), lane, s9_transpose_tb(g, s_tb[wv], li, lk));
+            } else if (i > k && j >= i) {
+                s9_d4 nz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nz[r] = -Zr[s / BS][r];
+                S[s] = s9_tn(nz, Zc[s % BS], S[s]);
+            }
+        }
+        if (k == 0) DBG_T(42);
+    }
+    __syncthreads();
+
+    DBG_T(32);
+    // ---- P2: Q = A L  (Q(i, j) = sum_{k >= j} A(k, i)^T L(k, j)); Q and Q^T to the slab
+    {
+        s9_d4 acc[TS];
+#pragma unroll
+        for (int s = 0; s < TS; ++s) acc[s] = s9_zero();
+        s9_gemm_block<BS>(wb * BS, NT, acc, [&](int k, int qi) { return ld_A(k, wa * BS + qi); },
+                          [&](int k, int qj) { return s9_ldg(tile(bL, k, wb * BS + qj), lane); }, [&](int k, int, int qj) { return k >= wb * BS + qj; });
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+            s9_stg(tile(bQ, i, j), lane, acc[s]);
+            s9_stg(tile(bQt, j, i), lane, s9_transpose_tb(acc[s], s_tb[wv], li, lk));
+        }
+    }
+    __syncthreads();
+
+    DBG_T(33);
+    // ---- P3: M = s2 I + L^T Q  (M(i, j) = sum_{k >= i} L(k, i)^T Q(k, j)) into the tableau
+#pragma unroll
+    for (int s = 0; s < TS; ++s) S[s] = s9_zero();
+    s9_gemm_block<BS>(wa * BS, NT, S, [&](int k, int qi) { return s9_ldg(tile(bL, k, wa * BS + qi), lane); },
+                      [&](int k, int qj) { return s9_ldg(tile(bQ, k, wb * BS + qj), lane); }, [&](int k, int qi, int) { return k >= wa * BS + qi; });
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+        if (i == j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * r + lk == li) S[s][r] += s2;
+        }
+    }
+    __syncthreads();                                   // (the row-panel buffers of P1 are idle again)
+
+    DBG_T(34);
+    // ---- P4: the symmetric sweep; the tableau ends as -M^-1
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {
+        double (*rowp)[S9_TILE] = s_rowp[k & 1];
+        if (wa == k / BS) {
+#pragma unroll
+            for (int s = 0; s < TS; ++s) {
+                const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+                if (i == k) s9_sts(rowp[j], lane, S[s]);
+            }
+        }
+        __syncthreads();
+        s9_d4 F, Ft;
+        if (wv == 0) {
+            s9_factor(s9_lds(rowp[k], lane), nullptr, 0.0, ws, li, lk, F, Ft, bad);
+            s9_sts(s_F[0], lane, F);
+            s9_sts(s_F[1], lane, Ft);
+        }
+        __syncthreads();
+        F = s9_lds(s_F[0], lane);
+        Ft = s9_lds(s_F[1], lane);
+        s9_d4 Zr[BS], Zc[BS];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) {
+            Zr[q] = s9_tn(Ft, s9_lds(rowp[wa * BS + q], lane), s9_zero());
+            Zc[q] = s9_tn(Ft, s9_lds(rowp[wb * BS + q], lane), s9_zero());
+        }
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+            if (i == k && j == k) {
+                const s9_d4 dd = s9_tn(F, F, s9_zero());
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[s][r] = -dd[r];
+            } else if (i == k) S[s] = s9_tn(F, Zc[s % BS], s9_zero());          // F^T Z_j
+            else if (j == k) S[s] = s9_tn(Zr[s / BS], F, s9_zero());            // Z_i^T F
+            else {
+                s9_d4 nz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nz[r] = -Zr[s / BS][r];
+                S[s] = s9_tn(nz, Zc[s % BS], S[s]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = -S[s][r];
+        s9_stg(tile(bMi, i, j), lane, v);
+    }
+    __syncthreads();
+
+    DBG_T(35);
+    // ---- P5: X = Mi G  (X(i, j) = sum_{k <= j} Mi(k, i)^T G(k, j)) over Q's buffer (Q itself is dead: W reads Q^T)
+#pragma unroll
+    for (int s = 0; s < TS; ++s) S[s] = s9_zero();
+    s9_gemm_block<BS>(0, wb * BS + BS, S, [&](int k, int qi) { return s9_ldg(tile(bMi, k, wa * BS + qi), lane); },
+                      [&](int k, int qj) { return s9_ldg(tile(bG, k, wb * BS + qj), lane); }, [&](int k, int, int qj) { return k <= wb * BS + qj; });
+#pragma unroll
+    for (int s = 0; s < TS; ++s) s9_stg(tile(bQ, wa * BS + s / BS, wb * BS + s % BS), lane, S[s]);
+    __syncthreads();
+
+    DBG_T(36);
+    // ---- P6: W = (I - Q X) / s2  (W(i, j) = (delta - sum_k Qt(k, i)^T X(k, j)) / s2), stored row-major like solve7's; y = W b by tile
+    const double is2 = 1.0 / s2;
+#pragma unroll
+    for (int s = 0; s < TS; ++s) S[s] = s9_zero();
+    s9_gemm_block<BS>(0, NT, S, [&](int k, int qi) { return s9_ldg(tile(bQt, k, wa * BS + qi), lane); },
+                      [&](int k, int qj) { return s9_ldg(tile(bQ, k, wb * BS + qj), lane); }, [&](int, int, int) { return true; });
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+        const double bj = s_b[16 * j + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+            const double w = (((row == col) ? 1.0 : 0.0) - S[s][r]) * is2;
+            if (row < c6 && col < c6) Wout[(size_t)row * ldh + col] = w;
+            // this tile's share of y[row]: the 16 columns summed over the 16 lanes of a DPP row (fixed order)
+            double t = w * bj;
+            t += __shfl_xor(t, 1, 16); t += __shfl_xor(t, 2, 16); t += __shfl_xor(t, 4, 16); t += __shfl_xor(t, 8, 16);
+            if (li == 0) s_yp[j][16 * i + 4 * r + lk] = t;
+        }
+    }
+    if (bad) atomicOr(&s_bad, 1);
+    __syncthreads();
+    if (tid == 0 && s_bad) atomicOr(&meta->err, 1);
+    for (int i = tid; i < NP; i += NTH) { double acc = s_yp[0][i]; for (int j = 1; j < NT; ++j) acc += s_yp[j][i]; s_y[i] = acc; }
+    __syncthreads();
+
+    DBG_T(37);
+    // ---- dx = K r = Pc y (Updater.cc:544): NTH / d threads per row, each a contiguous share of the columns; partial sums added in a fixed order
+    {
+        const int np = max(1, min(4, NTH / d)), share = (c6 + np - 1) / np;
+        const int pt = tid / d, i = tid - pt * d;
+        if (pt < np) {
+            double acc = 0;
+            const int k1 = min(c6, (pt + 1) * share);
+#pragma unroll 8
+            for (int k = pt * share; k < k1; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
+            s_part[pt * d + i] = acc;
+        }
+        __syncthreads();
+        if (tid < d) { double acc = s_part[tid]; for (int q = 1; q < np; ++q) acc += s_part[q * d + tid]; s_dx[tid] = acc; }
+    }
+    __syncthreads();
+    // ---- state injection (Updater.cc:546-613)
+    const double* dx = s_dx;
+    if (tid == 0) {
+        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
+        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
+        st3(x_out + 7, unit3(ld3(x_out + 7)));
+        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
+        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
+    }
+    for (int p = tid - 64; p >= 0 && p < n; p += NTH - 64) {
+        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
+        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
+    }
+    DBG_T(38);
+    DBG_R(true, 7);
+}
