@@ -331,6 +331,10 @@ __global__ __launch_bounds__(64) void mineig_nms_strip_kernel(const uint8_t* __r
         int base = 0;
         if (lane == 0) base = atomicAdd(&d.counters[3], n_list);
         base = __builtin_amdgcn_readfirstlane(base);
+        // s_list was filled through ballot slots by other lanes of this wave: in-order LDS of one wave + these fences (no reliance on alias analysis)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int i = lane; i < n_list; i += 64) d.prov[base + i] = s_list[i];
         n_list = 0;
     };

@@ -259,6 +259,13 @@ __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta*
                                                          double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
     propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
 }
+// the same with 8-sample chunks: the standalone propagate of a handle whose FUSED per-feature + propagate launch runs with CH = 8 (long
+// windows: the per-feature stage needs the LDS) — one chunk size per handle, so frame_dev (fused) and frame_begin_dev / the sharded path
+// (unfused) give the same last bits (the composed-chunk form re-associates PreIntegrator.cc's per-sample recursion: DESIGN.md section 3 item 5)
+__global__ __launch_bounds__(256) void propagate_kernel3c(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                                          double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+    propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+}
 // batch handles: two workgroups per CU (256 VGPRs, part of the working set in scratch) — throughput, not latency
 __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                              double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {

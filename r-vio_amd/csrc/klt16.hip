@@ -185,6 +185,11 @@ __global__ __launch_bounds__(64) void klt_kernel16(PyrDev prev, PyrDev next, int
                     if (ox < 0 || ox > 32 - 17 || oy < 0 || oy > 32 - 17) {   // window left the staged region: restage around it
                         jxl = inx - 8; jyl = iny - 8; ox = 8; oy = 8;
                         k16_stage_j(Jw, J, w, h, jxl, jyl, r);
+                        // the lanes of this feature's 16-lane row now read region rows staged by OTHER lanes of the same wave: the LDS
+                        // operations of a wave complete in order; the fences keep the compiler from moving those loads above the stores
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                     const float a = npx - inx, b = npy - iny;
                     const int iw00 = (int)rintf((1.f - a) * (1.f - b) * (1 << 14));

@@ -266,6 +266,9 @@ __device__ __forceinline__ bool stage_wait(const unsigned long long* c, unsigned
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(4);
+                // once a wait of this handle has timed out (sticky bit 4) the frame sequence is broken: every later poll gives up at once instead of
+                // spinning its own 30 s — a caller that keeps enqueueing frames without a sync must not queue N x 30 s of dead GPU time
+                if (__hip_atomic_load(&meta->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) { ok = 0; break; }
                 if (wall_clock64() - t0 > STAGE_WAIT_TICKS) { atomicOr(&meta->err, 4); ok = 0; break; }
             }
         }

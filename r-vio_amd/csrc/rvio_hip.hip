@@ -75,7 +75,8 @@ struct rvio_hip {
     double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles
     bool solve8 = false;         // one instance, 6n <= 64: the solve without a pivot search (solve8.hip) — Pcc^-1 beside the per-feature stage, B^-1 on the chain
     bool pinv_ready = false;     // Pinv holds the inverse of the clone block the next solve will see (written by the fused per-feature launch)
-    double* Pinv = nullptr;      // 64 x 64
+    double* Pinv = nullptr;      // 64 x 64 (instrumented build only)
+    float* eig_map = nullptr;    // W x H min-eigenvalue map of rvio_hip_get_corners(eig): allocated on first use
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
     rvio_imu* d_imu = nullptr;
@@ -322,7 +323,9 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global) {
     DALLOC(h, h->gram_cnt, 8);
     DALLOC(h, h->stage_sync, 1);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
-    DALLOC(h, h->Pinv, 64 * 64);
+#ifdef RVIO_DBG_CLOCKS
+    DALLOC(h, h->Pinv, 64 * 64);   // solve8's Pcc^-1: the shipping pipeline never touches it
+#endif
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
     DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
@@ -795,6 +798,9 @@ static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_b
     if (h->batch > 8 && prop_b)
         hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                            h->slab_bytes, imu_bs);
+    else if (h->fuse_ch == 8)   // one chunk size per handle: the fused launch of this handle composes 8 samples at a time
+        hipLaunchKernelGGL(propagate_kernel3c, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
+                           h->slab_bytes, imu_bs);
     else
     hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                        h->slab_bytes, imu_bs);
@@ -1072,7 +1078,12 @@ static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE 
     q.W = d.W; q.H = d.H; q.F = d.F; q.min_dist = h->cfg.min_dist; q.quality = (double)h->cfg.qual_lvl;
     q.max_cells = ((d.W + cell1 - 1) / cell1) * ((d.H + cell1 - 1) / cell1);
     q.first = h->t.first;
-    DALLOC(h, q.eig, npx); DALLOC(h, q.maxkey, 1); DALLOC(h, q.counters, 4); DALLOC(h, q.cell_cnt, (size_t)q.max_cells);
+#ifdef RVIO_DBG_CLOCKS
+    DALLOC(h, q.eig, npx);   // the two-pass A/B form (RVIO_DET_TWO_PASS) sends the map through HBM
+#else
+    q.eig = nullptr;   // (the pipeline keeps the min-eigenvalue map in LDS; rvio_hip_get_corners(eig) allocates ONE map per handle on first use)
+#endif
+    DALLOC(h, q.maxkey, 1); DALLOC(h, q.counters, 4); DALLOC(h, q.cell_cnt, (size_t)q.max_cells);
     DALLOC(h, q.cell_ent, (size_t)(d.W + cell2) * (d.H + cell2)); DALLOC(h, q.cell_ci, (size_t)(d.W + cell2) * (d.H + cell2));
     q.n_cap = (int)std::min(npx, (size_t)16384);
     DALLOC(h, q.nb, (size_t)q.n_cap * DET_NBCAP); DALLOC(h, q.nb_cnt, (size_t)q.n_cap);
@@ -1815,11 +1826,14 @@ int rvio_hip_get_corners(rvio_hip* h, int32_t* n, float* xy, float* raw_xy, floa
         // detector saw — level 0 of the current pyramid — by the map-only kernel (same arithmetic); its side effects on the detector's
         // per-frame scratch are undone (the image maximum returns to its rest value)
         const DevCfg& d = h->dc;
-        hipLaunchKernelGGL(mineig_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, 1), dim3(DET_T), 0, h->stream, h->pyr[h->pyr_cur].img[0], d.W, ds_, (size_t)0,
-                           h->slab_bytes, 0);
+        if (!h->eig_map) { const bool sm = h->slab_mode; h->slab_mode = false; const int rc = dalloc(h, &h->eig_map, (size_t)d.W * d.H); h->slab_mode = sm; if (rc != RVIO_OK) return rc; }
+        DetDev dm = ds_;
+        dm.eig = h->eig_map;
+        hipLaunchKernelGGL(mineig_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, 1), dim3(DET_T), 0, h->stream, h->pyr[h->pyr_cur].img[0], d.W, dm, (size_t)0,
+                           (size_t)0, 0);
         const int rest = (int)0x80000000;
         HIPCHK(h, hipMemcpyAsync(ds_.maxkey, &rest, sizeof rest, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(eig, ds_.eig, sizeof(float) * d.W * d.H, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(eig, h->eig_map, sizeof(float) * d.W * d.H, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RVIO_OK;
@@ -1950,6 +1964,7 @@ int rvio_hip_debug_poison(rvio_hip* h, int what) {
         HIPCHK(h, fill(h->partial, sizeof(double) * d.Fu * ldh * ldh));
         HIPCHK(h, fill(h->block, sizeof(double) * 2 * ldh * ldh)); HIPCHK(h, fill(h->Ab, sizeof(double) * 2 * ldh * ldh));
         HIPCHK(h, fill(h->Tbuf, sizeof(double) * ldh * ldh)); HIPCHK(h, fill(h->W, sizeof(double) * ldh * ldh));
+        if (h->S9scr) HIPCHK(h, hipMemsetAsync(h->S9scr, 0xff, sizeof(double) * 5 * h->solve9_nt * h->solve9_nt * S9_TILE, h->stream));   // (solve9 reads only tiles it wrote in the same launch)
         HIPCHK(h, fill(h->U, sizeof(double) * dm * ldh)); HIPCHK(h, fill(h->G, sizeof(double) * dm * ldh));
         HIPCHK(h, fill(h->Pt1, sizeof(double) * PP));
         HIPCHK(h, fill(h->gamma, sizeof(double) * d.Fu)); HIPCHK(h, fill(h->pfinv, sizeof(double) * 3 * d.Fu));

@@ -46,6 +46,11 @@ def load():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
+        # the version first: a library built from an older header must fail HERE, with a sentence, not at the first missing symbol
+        L.rvio_hip_abi_version.restype = C.c_int
+        if L.rvio_hip_abi_version() != abi.ABI_VERSION:
+            raise RvioHipError("%s speaks ABI %d, this binding expects %d (include/rvio_hip.h): rebuild it — python -c 'import __graft_entry__ as g; g.build()'"
+                               % (LIB_PATH, L.rvio_hip_abi_version(), abi.ABI_VERSION))
         L.rvio_hip_last_error.restype = C.c_char_p
         L.rvio_hip_last_error.argtypes = [C.c_void_p]
         L.rvio_hip_stream.restype = C.c_void_p

@@ -12,14 +12,18 @@ import scenarios as S
 abi, rv = O.abi, O.rv
 pytestmark = pytest.mark.gpu
 
-# Free-running bar: 1e-6 per state (north star).  The platform AT REST is the exception and gets 2e-5: there position and velocity are
+# Free-running bar: 1e-6 per state (north star).  The platform AT REST is the exception and gets 1.5e-5 (2 x the largest device figure
+# measured, 7.1e-6 on images / 2.9e-6 on direct tracks): there position and velocity are
 # unobservable, the sequence itself amplifies any difference ~1e7..1e9-fold within 80-100 frames (the LITERAL oracle started ONE ULP away
 # from itself ends 1e-9 .. 2e-7 away; 8e-14 on the stock motion: tests/test_truncation.py::test_the_reference_itself_is_ill_conditioned_at_rest),
 # and the device's per-update difference of ~1e-14 grows to a few 1e-6 in the integrated position.  What the device owes — and what the
 # structural truncation rule owes — is agreement PER UPDATE: both tests below run a second handle that is re-seeded with the literal
 # state before every frame and hold it to 1e-9 (1e-8 at rest; measured: 3e-14 typical, 1.5e-9 worst at rest).
+# Round 5 (tests/test_ref_pins.py::test_monovio_at_rest_direct): the reference's OWN sources, compiled, against their restatement — two
+# programs that differ only in the order of a few sums — end 3.4e-7 (state) / 2e-5 (P, relative) apart on the stationary sequence, growing
+# ~3x per frame from 3e-16.  A 1e-6 free-running bar at rest is not a property of any implementation of this filter.
 def bar(kw):
-    return 2e-5 if kw.get("motion") == "stationary" else 1e-6
+    return 1.5e-5 if kw.get("motion") == "stationary" else 1e-6
 
 
 def bar1(kw):

@@ -21,9 +21,13 @@ imu_arr = imu_arr.reshape(len(imgs), -1)
 s = O.System(cfg)
 x0, P0 = O.initialize(cfg, d["wi"], d["ai"], int(d["ni"]))
 s.set_state(x0, P0)
-t0 = time.perf_counter()
+warm = int(d["warm"]) if "warm" in d.files else 0
+per = []
 for i in range(len(imgs)):
+    t0 = time.perf_counter()
     s.frame(imu_arr[i, : imu_cnt[i]], None, img=imgs[i])
-el = time.perf_counter() - t0
+    per.append(time.perf_counter() - t0)
+per = np.array(per)[warm:]
 pts, hl = s.tracker().get_points()
-print(json.dumps({"value": len(imgs) / el, "x": s.get_state()[0].tolist(), "pts": pts.tolist(), "hist_len": hl.tolist()}))
+print(json.dumps({"value": len(per) / float(per.sum()), "frame_ms_p50": float(1e3 * np.median(per)), "frame_ms_p95": float(1e3 * np.percentile(per, 95)),
+                  "x": s.get_state()[0].tolist(), "pts": pts.tolist(), "hist_len": hl.tolist()}))
