@@ -7,6 +7,7 @@
 // limiter), no loops over dependent global loads.
 #pragma once
 #include "rvio_dev.h"
+#include "solve9.hip"   // the Cholesky role of the solve rides in the per-feature / propagate launches
 #ifdef RVIO_DBG_CLOCKS
 #include "solve8.hip"   // (measured, not adopted: instrumented build only — see its header)
 #endif
@@ -266,6 +267,18 @@ __global__ __launch_bounds__(256) void propagate_kernel3c(DevCfg cfg, FilterMeta
                                                           double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
     propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs);
 }
+// propagate with the Cholesky role of solve9 as a second workgroup (plain handle, 6n <= 96; staged entry points: rvio_hip_propagate[_dev],
+// rvio_hip_frame_begin_dev): propagation rewrites the IMU block and the cross terms of P, the role reads the clone block only
+template <int CH, int BS>
+__global__ __launch_bounds__(256) void propagate_chol_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
+                                                             double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, double* __restrict__ chol_scr) {
+    if (blockIdx.x == 1) {
+        __shared__ S9CholLds<2 * BS, 4> sh;
+        s9_chol_role<BS>(cfg, n, P, chol_scr, sh);
+        return;
+    }
+    propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0);
+}
 // batch handles: two workgroups per CU (256 VGPRs, part of the working set in scratch) — throughput, not latency
 __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                              double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
@@ -278,14 +291,22 @@ __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterM
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
 // pinv != NULL (instrumented build, RVIO_SOLVE8: the solve without a pivot search — measured, not adopted, solve8.hip): one more workgroup
 // inverts the clone block Pcc, the measurement-independent half of that solve (propagation leaves Pcc alone, so it is the Pcc the solve will see).
+// chol_scr != NULL (round 5, solve9.hip at 6n <= 96): one more workgroup factors the clone block Pcc = L L^T into the solve's tile slab —
+// the measurement-independent part of the solve, off the filter chain (its LDS: the launch's dynamic LDS, idle in that workgroup).
 template <int CH>      // propagate's chunk size (its LDS: 86 KB at 16, 47 KB at 8 — long windows need the room for the per-feature stage)
 __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
-                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* pinv) {
+                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* pinv, double* chol_scr, int chol_nt) {
     DBG_R(blockIdx.x == 0, 0);
     if (blockIdx.x == gridDim.x - 1) { propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0); return; }
+    if (chol_scr && blockIdx.x == gridDim.x - 2) {
+        extern __shared__ __align__(16) double fp_dyn[];
+        if (chol_nt == 4) s9_chol_role<2>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<4, 4>*>(fp_dyn));
+        else s9_chol_role<3>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<6, 4>*>(fp_dyn));
+        return;
+    }
 #ifdef RVIO_DBG_CLOCKS
     if (pinv && blockIdx.x == gridDim.x - 2) { extern __shared__ __align__(16) double fp_dyn[]; pinv_role<4>(cfg, n, P, pinv, meta, fp_dyn); return; }
 #endif

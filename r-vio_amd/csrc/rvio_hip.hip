@@ -72,7 +72,8 @@ struct rvio_hip {
     StageSync stage_tgt = {};
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     int solve9_nt = 0;           // solve9_kernel (solve9.hip): tiles per side of the padded clone block (4, 6, 8, 12), 0: not used (batch handles, RVIO_SOLVE7=1)
-    double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles
+    double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles (+ the verdict of the Cholesky role)
+    bool chol_ready = false;     // the slab holds L, G of the clone block the next solve will see (written by the role workgroup of the per-feature / propagate launch)
     bool solve8 = false;         // one instance, 6n <= 64: the solve without a pivot search (solve8.hip) — Pcc^-1 beside the per-feature stage, B^-1 on the chain
     bool pinv_ready = false;     // Pinv holds the inverse of the clone block the next solve will see (written by the fused per-feature launch)
     double* Pinv = nullptr;      // 64 x 64 (instrumented build only)
@@ -525,6 +526,8 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     // propagate rides in the per-feature launch when both fit one CU's LDS: the dynamic per-feature footprint + the kernel's static LDS
     // (propagate's composed-chunk buffers: 86 KB at 16 samples per chunk, 47 KB at 8; instrumented build: + solve8's inverse role)
     h->fprop_lds = h->feat_lds;
+    // (round 5: + the Cholesky role of solve9 at 6n <= 96 — one more workgroup whose buffers live in the launch's dynamic LDS)
+    if (batch == 1 && c6m <= 96) h->fprop_lds = std::max(h->fprop_lds, c6m <= 64 ? sizeof(S9CholLds<4, 4>) : sizeof(S9CholLds<6, 4>));
 #ifdef RVIO_DBG_CLOCKS
     h->fprop_lds = std::max(h->feat_lds, (size_t)S8_PINV_LDS_DOUBLES * sizeof(double));
 #endif
@@ -549,13 +552,13 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             else if (c6m <= 126) { h->solve5_variant = 3; nch = 2; rpw = 16; }
             h->solve7_variant = (c6m <= 64) ? 1 : (c6m <= 96) ? 2 : (c6m <= 128) ? 3 : (c6m <= 192) ? 4 : 0;
             if (ab_env("RVIO_SOLVE6") && h->solve5_variant) h->solve7_variant = 0;   // A/B timing: the LDS-tableau kernel behind gemm_T_kernel
-            // one instance, 6n > 64: the blocked SPD solve (solve9.hip).  Measured on full-load updates (tools/solve9_probe.py, profiles/r05_solve9_probe.txt):
-            // 6n = 84: 94.0 us against solve7's 102.6; 120: 173 against 212; 180: 511 against 797.  At 6n <= 64 the register-tableau elimination
-            // stays (36.6 us against 47.8: there the 16 x 16 in-wave factor, eight of them in sequence, is the chain).  RVIO_SOLVE7=1 (instrumented build)
-            // keeps solve7 everywhere, RVIO_SOLVE9=1 takes solve9 at 6n <= 64 too: A/B timing.
-            if (batch == 1 && c6m <= 192 && (c6m > 64 || ab_env("RVIO_SOLVE9")) && !ab_env("RVIO_SOLVE7")) {
+            // one instance: the blocked SPD solve (solve9.hip).  Measured on full-load updates (tools/solve9_probe.py, profiles/r05_solve9_probe.txt), solve kernel alone:
+            // 6n = 84: 94.0 us against solve7's 102.6; 120: 173 against 212; 180: 511 against 797.  At 6n <= 96 the Cholesky of the clone block — the part that does
+            // not depend on the measurements — rides as one more workgroup in the per-feature launch (pipelined frame) or in propagate's launch (staged entry
+            // points), off the chain; the solve kernel then starts at Q = A L.  RVIO_SOLVE7=1 (instrumented build) keeps the register-tableau elimination: A/B timing.
+            if (batch == 1 && c6m <= 192 && !ab_env("RVIO_SOLVE7")) {
                 h->solve9_nt = (c6m <= 64) ? 4 : (c6m <= 96) ? 6 : (c6m <= 128) ? 8 : 12;
-                DALLOC(h, h->S9scr, (size_t)5 * h->solve9_nt * h->solve9_nt * S9_TILE);
+                DALLOC(h, h->S9scr, S9_SLAB_DOUBLES(h->solve9_nt));
             }
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
@@ -678,6 +681,7 @@ static int set_state_range(rvio_hip* h, int lo, int hi, const double* x, int xdi
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_clones_host = n;
+    h->chol_ready = false;   // (the slab's factor belongs to the covariance that was just replaced)
     return RVIO_OK;
 }
 // (a batch handle: every instance receives the same state)
@@ -798,6 +802,19 @@ static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_b
     if (h->batch > 8 && prop_b)
         hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                            h->slab_bytes, imu_bs);
+    else if (h->batch == 1 && h->solve9_nt && h->solve9_nt <= 6 && h->n_clones_host >= 1 && !imu_bs) {
+        // plain handle, 6n <= 96: the Cholesky role of the solve (solve9.hip) as a second workgroup — the clone block it factors is the one the update
+        // behind this propagate will see (propagation does not touch it); one chunk size per handle (the fused launch's)
+        const int nc = h->n_clones_host;
+        if (h->solve9_nt == 4) {
+            if (h->fuse_ch == 8) hipLaunchKernelGGL((propagate_chol_kernel<8, 2>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
+            else hipLaunchKernelGGL((propagate_chol_kernel<16, 2>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
+        } else {
+            if (h->fuse_ch == 8) hipLaunchKernelGGL((propagate_chol_kernel<8, 3>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
+            else hipLaunchKernelGGL((propagate_chol_kernel<16, 3>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
+        }
+        h->chol_ready = true;
+    }
     else if (h->fuse_ch == 8)   // one chunk size per handle: the fused launch of this handle composes 8 samples at a time
         hipLaunchKernelGGL(propagate_kernel3c, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                            h->slab_bytes, imu_bs);
@@ -852,14 +869,19 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const int B = h->batch;
     if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
         const bool pinv = h->solve8 && world == 1 && combine;   // (the unsharded update of this very launch follows: the solve will want Pcc^-1)
+        // solve9 at 6n <= 96: the Cholesky of the clone block as one more workgroup of this launch (the solve of this very update follows on the stream)
+        const bool chol = !pinv && h->solve9_nt && h->solve9_nt <= 6 && n >= 1;
+        double* cs = chol ? h->S9scr : (double*)nullptr;
+        const int extra = 1 + (pinv ? 1 : 0) + (chol ? 1 : 0);
         if (h->fuse_ch == 16)
-            hipLaunchKernelGGL(feat_prop_kernel<16>, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+            hipLaunchKernelGGL(feat_prop_kernel<16>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
+                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr, cs, h->solve9_nt);
         else
-            hipLaunchKernelGGL(feat_prop_kernel<8>, dim3(d.Fu + (pinv ? 2 : 1)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+            hipLaunchKernelGGL(feat_prop_kernel<8>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr);
+                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr, cs, h->solve9_nt);
+        h->chol_ready = chol;
         h->pinv_ready = pinv;
         h->fuse_m = -1;
     } else
@@ -903,9 +925,17 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     }
 #endif
     if (h->solve9_nt) {   // blocked SPD factorisations on the matrix cores (solve9.hip): one workgroup, one launch
+        const bool pre = h->chol_ready;   // L, G of the clone block are in the slab already (the role workgroup of this update's per-feature / propagate launch)
+        h->chol_ready = false;
         switch (h->solve9_nt) {
-        case 4: hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
-        case 6: hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        case 4:
+            if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            return;
+        case 6:
+            if (pre) hipLaunchKernelGGL((solve9_kernel<2, 3, true>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            else hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            return;
         case 8: hipLaunchKernelGGL((solve9_kernel<2, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
         default: hipLaunchKernelGGL((solve9_kernel<3, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
         }
@@ -1054,6 +1084,7 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
                        h->slab_bytes, done);
     HIPCHK(h, hipGetLastError());
     h->cur = o;
+    h->chol_ready = false;   // the clone block has changed (window slide / new clone)
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
     return RVIO_OK;
 }
@@ -1887,6 +1918,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
             h->pinv_ready = h->solve8;   // (time what the chain sees: the solve kernel alone; Pcc^-1 rides in the per-feature launch)
+            h->chol_ready = h->solve9_nt && h->solve9_nt <= 6 && !ab_env("RVIO_S9_FULL");   // (likewise the Cholesky role of solve9: the slab holds a factor from the last update)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT
@@ -1964,7 +1996,7 @@ int rvio_hip_debug_poison(rvio_hip* h, int what) {
         HIPCHK(h, fill(h->partial, sizeof(double) * d.Fu * ldh * ldh));
         HIPCHK(h, fill(h->block, sizeof(double) * 2 * ldh * ldh)); HIPCHK(h, fill(h->Ab, sizeof(double) * 2 * ldh * ldh));
         HIPCHK(h, fill(h->Tbuf, sizeof(double) * ldh * ldh)); HIPCHK(h, fill(h->W, sizeof(double) * ldh * ldh));
-        if (h->S9scr) HIPCHK(h, hipMemsetAsync(h->S9scr, 0xff, sizeof(double) * 5 * h->solve9_nt * h->solve9_nt * S9_TILE, h->stream));   // (solve9 reads only tiles it wrote in the same launch)
+        if (h->S9scr) HIPCHK(h, hipMemsetAsync(h->S9scr, 0xff, sizeof(double) * S9_SLAB_DOUBLES(h->solve9_nt), h->stream));   // (solve9 reads only tiles it wrote in the same launch)
         HIPCHK(h, fill(h->U, sizeof(double) * dm * ldh)); HIPCHK(h, fill(h->G, sizeof(double) * dm * ldh));
         HIPCHK(h, fill(h->Pt1, sizeof(double) * PP));
         HIPCHK(h, fill(h->gamma, sizeof(double) * d.Fu)); HIPCHK(h, fill(h->pfinv, sizeof(double) * 3 * d.Fu));

@@ -194,55 +194,30 @@ __device__ __forceinline__ void s9_gemm_block(int k0, int k1, s9_d4 (&acc)[BS * 
     }
 }
 
-// BS x BS tiles per wave, WGR x WGR waves: NT = WGR * BS tiles per side.  scr: 5 * NT^2 * 256 doubles per instance.
-template <int BS, int WGR>
-__global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
-                                                                const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ scr,
-                                                                double* __restrict__ Wout, double* __restrict__ x_out, size_t bs, size_t scr_bs) {
-    meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
-    scr = (double*)((char*)scr + (size_t)blockIdx.z * scr_bs);
-    constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
-    __shared__ double s_rowp[2][NT][S9_TILE];          // the row panel of a step, by step parity
-    __shared__ S9Wave s_ws[1];                         // the in-wave primitive runs in wave 0
-    __shared__ double s_F[2][S9_TILE];                 // its result: F and F^T of the step's diagonal tile
-    __shared__ double s_tb[NW][16 * 17];               // per-wave transposition scratch (Q^T, L from G)
-    __shared__ double s_ref[NP];                        // the original diagonal of Pcc (the scale of "zero" for its Cholesky)
-    __shared__ double s_b[NP], s_y[NP], s_yp[NT][NP];
-    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
-    __shared__ double s_part[4 * (24 + 6 * RVIO_MAX_LEN)];
-    __shared__ int s_bad;
-    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
-    const int wa = wv / WGR, wb = wv % WGR;             // this wave's block row / block column
-    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
-    const bool upd = n_good > 2;                       // Updater.cc:460
-    DBG_R(true, 2);
-    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; s_bad = 0; }
-    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
-        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
-        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
-        return;
-    }
-    DBG_T(30);
-    const double s2 = cfg.sigma_im * cfg.sigma_im;
-    S9Wave* ws = &s_ws[0];
-    double* bL = scr;                                   // L(i, k), i >= k
-    double* bG = scr + (size_t)NT * NT * S9_TILE;       // G = L^T: G(k, j), j >= k
-    double* bQ = scr + (size_t)2 * NT * NT * S9_TILE;   // Q = A L;   later X = Mi G
-    double* bQt = scr + (size_t)3 * NT * NT * S9_TILE;  // Q^T
-    double* bMi = scr + (size_t)4 * NT * NT * S9_TILE;  // M^-1
-    auto tile = [&](double* b, int i, int j) { return b + (size_t)(i * NT + j) * S9_TILE; };
-    // A(i, j) as a tile, straight from the information block (read-only input: ordinary loads); zero beyond 6n
-    auto ld_A = [&](int i, int j) {
-        s9_d4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
-            v[r] = (row < c6 && col < c6) ? Ab[(size_t)row * ldh + col] : 0.0;
-        }
-        return v;
-    };
+// LDS of the Cholesky phase (P0 + P1): static in solve9_kernel, carved out of the launch's dynamic LDS by the role workgroup of feat_prop_kernel
+template <int NT, int NW>
+struct S9CholLds {
+    double rowp[2][NT][S9_TILE];                       // the row panel of a step, by step parity
+    S9Wave ws;                                         // the in-wave primitive runs in wave 0
+    double F[2][S9_TILE];                              // its result: F and F^T of the step's diagonal tile
+    double tb[NW][16 * 17];                            // per-wave transposition scratch (L from G; Q^T in the solve)
+    double ref[16 * NT];                               // the original diagonal of Pcc (the scale of "zero" for its Cholesky)
+    int bad;
+};
 
+// P0 + P1: the clone block of P -> L (bL: tiles (i, k), i >= k) and G = L^T (bG: tiles (k, j), j >= k) in the tile slab.
+// Depends on P only — NOT on the measurements: the pipelined path runs it as one more workgroup of the per-feature launch
+// (feat_prop_kernel: propagation leaves the clone block alone, so it is the Pcc the solve will see), off the filter chain.
+// Every thread of a workgroup of 64 WGR^2 threads calls it; returns (in every thread) whether a pivot was not positive where it had to be.
+template <int BS, int WGR>
+__device__ __forceinline__ int s9_cholesky(const DevCfg& cfg, int n, const double* __restrict__ P, double* __restrict__ scr, S9CholLds<WGR * BS, WGR * WGR>& sh) {
+    constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
+    const int c6 = 6 * n, ld = cfg.dmax;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int wa = wv / WGR, wb = wv % WGR;
+    double* bL = scr;
+    double* bG = scr + (size_t)NT * NT * S9_TILE;
+    auto tile = [&](double* b, int i, int j) { return b + (size_t)(i * NT + j) * S9_TILE; };
     // ---- P0: the clone block of P into the tableau (symmetric: element (row, col) is read as P[col + row ld], coalesced along li); identity beyond 6n
     s9_d4 S[TS];
 #pragma unroll
@@ -254,10 +229,8 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
             S[s][r] = (row < c6 && col < c6) ? P[(size_t)(24 + col) + (size_t)(24 + row) * ld] : (row == col ? 1.0 : 0.0);
         }
     }
-    for (int i = tid; i < NP; i += NTH) {
-        s_ref[i] = (i < c6) ? P[(size_t)(24 + i) * (ld + 1)] : 1.0;
-        s_b[i] = (i < c6) ? Ab[(size_t)i * ldh + c6] : 0.0;
-    }
+    for (int i = tid; i < NP; i += NTH) sh.ref[i] = (i < c6) ? P[(size_t)(24 + i) * (ld + 1)] : 1.0;
+    if (tid == 0) sh.bad = 0;
     int bad = 0;
     __syncthreads();
     DBG_T(31);
@@ -265,7 +238,7 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     // ---- P1: Pcc = L L^T.  Only tiles i <= j are live (the row panel of step k is S(k, j >= k)).
 #pragma unroll 1
     for (int k = 0; k < NT; ++k) {
-        double (*rowp)[S9_TILE] = s_rowp[k & 1];
+        double (*rowp)[S9_TILE] = sh.rowp[k & 1];
         if (wa == k / BS) {
 #pragma unroll
             for (int s = 0; s < TS; ++s) {
@@ -277,11 +250,11 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
         if (k == 0) DBG_T(40);
         s9_d4 F, Ft;
         if (wv == 0) {
-            s9_factor(s9_lds(rowp[k], lane), s_ref + 16 * k, 1e-12, ws, li, lk, F, Ft, bad);
-            s9_sts(s_F[1], lane, Ft);
+            s9_factor(s9_lds(rowp[k], lane), sh.ref + 16 * k, 1e-12, &sh.ws, li, lk, F, Ft, bad);
+            s9_sts(sh.F[1], lane, Ft);
         }
         __syncthreads();
-        Ft = s9_lds(s_F[1], lane);
+        Ft = s9_lds(sh.F[1], lane);
         if (k == 0) DBG_T(41);
         // G(k, c) = F S(k, c) for the block columns / block rows this wave touches
         s9_d4 Zr[BS], Zc[BS];
@@ -301,7 +274,7 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
                     for (int r = 0; r < 4; ++r) if (4 * r + lk > li) g[r] = 0.0;
                 }
                 s9_stg(tile(bG, k, j), lane, g);
-                s9_stg(tile(bL, j, k), lane, s9_transpose_tb(g, s_tb[wv], li, lk));
+                s9_stg(tile(bL, j, k), lane, s9_transpose_tb(g, sh.tb[wv], li, lk));
             } else if (i > k && j >= i) {
                 s9_d4 nz;
 #pragma unroll
@@ -311,7 +284,79 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
         }
         if (k == 0) DBG_T(42);
     }
+    if (bad) atomicOr(&sh.bad, 1);
     __syncthreads();
+    return sh.bad;
+}
+
+// The Cholesky phase as a ROLE of another launch (256 threads = 2 x 2 waves): one more workgroup of the per-feature launch (pipelined
+// frame) or of propagate's launch (staged entry points) factors the clone block while that launch does its own work; the verdict goes
+// to the slab's last word.  Same tiles, same order of operations per tile as solve9_kernel's own phase: the same bits.
+#define S9_SLAB_DOUBLES(NT) ((size_t)5 * (NT) * (NT) * S9_TILE + 8)
+template <int BS>
+__device__ __forceinline__ void s9_chol_role(const DevCfg& cfg, int n, const double* __restrict__ P, double* __restrict__ scr, S9CholLds<2 * BS, 4>& sh) {
+    const int bad = s9_cholesky<BS, 2>(cfg, n, P, scr, sh);
+    if (threadIdx.x == 0) scr[(size_t)5 * (2 * BS) * (2 * BS) * S9_TILE] = bad ? 1.0 : 0.0;
+}
+
+// BS x BS tiles per wave, WGR x WGR waves: NT = WGR * BS tiles per side.  scr: 5 * NT^2 * 256 (+ 8) doubles per instance.
+// PRE: L and G are in the slab already (s9_cholesky ran in the per-feature launch of this very update); *chol_bad: what it returned.
+template <int BS, int WGR, bool PRE = false>
+__global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
+                                                                const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ scr,
+                                                                double* __restrict__ Wout, double* __restrict__ x_out, size_t bs, size_t scr_bs) {
+    meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
+    scr = (double*)((char*)scr + (size_t)blockIdx.z * scr_bs);
+    constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
+    __shared__ S9CholLds<NT, NW> sh;
+    __shared__ double s_b[NP], s_y[NP], s_yp[NT][NP];
+    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    __shared__ double s_part[4 * (24 + 6 * RVIO_MAX_LEN)];
+    __shared__ int s_bad;
+    double (*s_rowp)[NT][S9_TILE] = sh.rowp;
+    double (*s_F)[S9_TILE] = sh.F;
+    double (*s_tb)[16 * 17] = sh.tb;
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int wa = wv / WGR, wb = wv % WGR;             // this wave's block row / block column
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    DBG_R(true, 2);
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; s_bad = 0; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        return;
+    }
+    DBG_T(30);
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    S9Wave* ws = &sh.ws;
+    double* bL = scr;                                   // L(i, k), i >= k
+    double* bG = scr + (size_t)NT * NT * S9_TILE;       // G = L^T: G(k, j), j >= k
+    double* bQ = scr + (size_t)2 * NT * NT * S9_TILE;   // Q = A L;   later X = Mi G
+    double* bQt = scr + (size_t)3 * NT * NT * S9_TILE;  // Q^T
+    double* bMi = scr + (size_t)4 * NT * NT * S9_TILE;  // M^-1
+    auto tile = [&](double* b, int i, int j) { return b + (size_t)(i * NT + j) * S9_TILE; };
+    // A(i, j) as a tile, straight from the information block (read-only input: ordinary loads); zero beyond 6n
+    auto ld_A = [&](int i, int j) {
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+            v[r] = (row < c6 && col < c6) ? Ab[(size_t)row * ldh + col] : 0.0;
+        }
+        return v;
+    };
+    for (int i = tid; i < NP; i += NTH) s_b[i] = (i < c6) ? Ab[(size_t)i * ldh + c6] : 0.0;
+    int bad = 0;
+    s9_d4 S[TS];
+    if constexpr (PRE) {
+        // the factor of Pcc came with the per-feature launch (its verdict travels in the slab's last word); an earlier KERNEL wrote the tiles: plain loads see them
+        if (tid == 0 && scr[(size_t)5 * NT * NT * S9_TILE] != 0.0) s_bad = 1;
+        __syncthreads();
+    } else {
+        if (s9_cholesky<BS, WGR>(cfg, n, P, scr, sh)) bad = 1;
+    }
 
     DBG_T(32);
     // ---- P2: Q = A L  (Q(i, j) = sum_{k >= j} A(k, i)^T L(k, j)); Q and Q^T to the slab
