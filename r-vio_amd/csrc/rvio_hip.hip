@@ -559,6 +559,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (batch == 1 && c6m <= 192 && !ab_env("RVIO_SOLVE7")) {
                 h->solve9_nt = (c6m <= 64) ? 4 : (c6m <= 96) ? 6 : (c6m <= 128) ? 8 : 12;
                 DALLOC(h, h->S9scr, S9_SLAB_DOUBLES(h->solve9_nt));
+                if (h->solve9_nt == 4) HIPCHK(h, hipFuncSetAttribute((const void*)solve9_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(S9SmallLds)));
             }
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
@@ -929,7 +930,9 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         h->chol_ready = false;
         switch (h->solve9_nt) {
         case 4:
-            if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            static const bool s9_generic = ab_env("RVIO_S9_GENERIC") != nullptr;   // A/B timing: the generic kernel (tiles through the L2 slab) at 6n <= 64
+            if (pre && !s9_generic) hipLaunchKernelGGL(solve9_small_kernel, dim3(1), dim3(1024), sizeof(S9SmallLds), h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout);
+            else if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
             else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
             return;
         case 6:

@@ -516,3 +516,206 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     DBG_T(38);
     DBG_R(true, 7);
 }
+
+// =============================================================== 6n <= 64 with the Cholesky factor already in the slab: everything in LDS
+// The pipelined frame's solve at the headline window (6n = 60).  The generic kernel above sends every phase's tiles through the L2 slab
+// (one L2 round trip per product step, ~1 k cycles, four or five steps per phase) and reads Pc for dx = Pc y from HBM at the very end; here
+//   * L and G come from the slab ONCE (written by the role workgroup of the per-feature launch) and every later tile lives in LDS,
+//   * 16 waves, one 16 x 16 tile each, no register blocking needed,
+//   * W^T = (I - L Mi (G A)) / s2 — the transposed Woodbury form: with R = G A beside Q = A L no tile is ever transposed
+//       Q = A L, R = G A;   M = s2 I + L^T Q;   Mi = M^-1 (sweep);   V = Mi R;   W^T = (I - L V) / s2,   y = W b
+//   * the IMU rows and the clone block of P (dx = Pc y) are fetched into registers at the start and parked in LDS once Q and R are dead.
+// LDS (dynamic): L -> V 32 KB | G (10 tiles) 20 KB | Q -> Mi 32 KB | R 32 KB | row panel 16 KB | F 4 KB | in-wave scratch | vectors.
+// Same arithmetic per tile as solve9_kernel<1, 4, true> up to the association of the Woodbury product (W^T instead of W): results agree to rounding.
+struct S9SmallLds {
+    double L[16][S9_TILE];                             // L(i, k) at [4 i + k]; later V(i, j)
+    double G[10][S9_TILE];                             // G(k, j), k <= j, at [j (j + 1) / 2 + k]
+    double Q[16][S9_TILE];                             // Q(i, j); later Mi(i, j); later (with R) the parked Pc
+    double R[16][S9_TILE];                             // R(i, j) = (G A)(i, j)
+    double rowp[2][4][S9_TILE];
+    double F[2][S9_TILE];
+    S9Wave ws;
+    double b[64], y[64], yp[4][64];
+    double dx[24 + 64];
+    double part[4 * (24 + 64)];
+    int bad;
+};
+__global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
+                                                            const double* __restrict__ x, const double* __restrict__ P, const double* __restrict__ scr,
+                                                            double* __restrict__ Wout, double* __restrict__ x_out) {
+    constexpr int NT = 4, NTH = 1024;
+    extern __shared__ __align__(16) double s9s_dyn[];
+    S9SmallLds& sh = *reinterpret_cast<S9SmallLds*>(s9s_dyn);
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int ti = wv >> 2, tj = wv & 3;                // this wave's tile
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    DBG_R(true, 2);
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; sh.bad = 0; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        return;
+    }
+    DBG_T(30);
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    auto ld_A = [&](int i, int j) {                     // A(i, j) as a tile, zero beyond 6n
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+            v[r] = (row < c6 && col < c6) ? Ab[(size_t)row * ldh + col] : 0.0;
+        }
+        return v;
+    };
+    // ---- everything this workgroup will ever read from memory, in flight at once, every byte ONCE: A (tile (ti, tj) per wave, staged in the Q region
+    // — one CU takes 64 B per clock from its L1: sixteen waves fetching the eight A tiles each of them multiplies with was 256 KB for a 29 KB matrix),
+    // the factor, Pc, b
+    const s9_d4 a0 = ld_A(ti, tj);
+    const bool lowt = ti >= tj;                         // tile (ti, tj) of L exists; its transpose position holds G(tj, ti)
+    s9_d4 l0 = s9_zero(), g0 = s9_zero();
+    if (lowt) { l0 = s9_ldg(scr + (size_t)(ti * NT + tj) * S9_TILE, lane); g0 = s9_ldg(scr + (size_t)NT * NT * S9_TILE + (size_t)(tj * NT + ti) * S9_TILE, lane); }
+    constexpr int PCN = (88 * 64 + NTH - 1) / NTH;      // Pc: d <= 88 rows x c6 <= 64 columns, column k of Pc at [k][88]
+    double pc[PCN];
+#pragma unroll
+    for (int u = 0; u < PCN; ++u) {
+        const int e = tid + u * NTH, k = e / 88, i = e - k * 88;
+        pc[u] = (k < c6 && i < d) ? P[(size_t)i + (size_t)(24 + k) * ld] : 0.0;
+    }
+    if (tid < 64) sh.b[tid] = (tid < c6) ? Ab[(size_t)tid * ldh + c6] : 0.0;
+    if (tid == 0 && scr[(size_t)5 * NT * NT * S9_TILE] != 0.0) sh.bad = 1;     // the Cholesky role's verdict
+    if (lowt) { s9_sts(sh.L[ti * NT + tj], lane, l0); s9_sts(sh.G[ti * (ti + 1) / 2 + tj], lane, g0); }
+    s9_sts(sh.Q[wv], lane, a0);
+    __syncthreads();
+    DBG_T(32);
+    // ---- Q = A L (Q(i, j) = sum_{k >= j} A(k, i)^T L(k, j)),  R = G A (R(i, j) = sum_{k >= i} L(k, i)^T A(k, j)); A leaves the Q region behind a barrier
+    {
+        s9_d4 q = s9_zero(), rr = s9_zero();
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            if (k >= tj) q = s9_tn(s9_lds(sh.Q[k * NT + ti], lane), s9_lds(sh.L[k * NT + tj], lane), q);
+            if (k >= ti) rr = s9_tn(s9_lds(sh.L[k * NT + ti], lane), s9_lds(sh.Q[k * NT + tj], lane), rr);
+        }
+        __syncthreads();
+        s9_sts(sh.Q[wv], lane, q);
+        s9_sts(sh.R[wv], lane, rr);
+    }
+    __syncthreads();
+    DBG_T(33);
+    // ---- M = s2 I + L^T Q into the tableau
+    s9_d4 S = s9_zero();
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+        if (k >= ti) S = s9_tn(s9_lds(sh.L[k * NT + ti], lane), s9_lds(sh.Q[k * NT + tj], lane), S);
+    if (ti == tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (4 * r + lk == li) S[r] += s2;
+    }
+    DBG_T(34);
+    // ---- the symmetric sweep (as in solve9_kernel); the tableau ends as -M^-1
+    int bad = 0;
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {
+        double (*rowp)[S9_TILE] = sh.rowp[k & 1];
+        if (ti == k) s9_sts(rowp[tj], lane, S);
+        __syncthreads();
+        s9_d4 F, Ft;
+        if (wv == 0) {
+            s9_factor(s9_lds(rowp[k], lane), nullptr, 0.0, &sh.ws, li, lk, F, Ft, bad);
+            s9_sts(sh.F[0], lane, F);
+            s9_sts(sh.F[1], lane, Ft);
+        }
+        __syncthreads();
+        F = s9_lds(sh.F[0], lane);
+        Ft = s9_lds(sh.F[1], lane);
+        const s9_d4 Zr = s9_tn(Ft, s9_lds(rowp[ti], lane), s9_zero());
+        const s9_d4 Zc = s9_tn(Ft, s9_lds(rowp[tj], lane), s9_zero());
+        if (ti == k && tj == k) {
+            const s9_d4 dd = s9_tn(F, F, s9_zero());
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[r] = -dd[r];
+        } else if (ti == k) S = s9_tn(F, Zc, s9_zero());
+        else if (tj == k) S = s9_tn(Zr, F, s9_zero());
+        else {
+            s9_d4 nz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nz[r] = -Zr[r];
+            S = s9_tn(nz, Zc, S);
+        }
+    }
+    {
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = -S[r];
+        s9_sts(sh.Q[wv], lane, v);                      // Mi over Q (every wave left Q behind before the sweep's first barrier)
+    }
+    __syncthreads();
+    DBG_T(35);
+    // ---- V = Mi R (V(i, j) = sum_k Mi(k, i)^T R(k, j)) over L (dead since M)
+    {
+        s9_d4 v = s9_zero();
+#pragma unroll
+        for (int k = 0; k < NT; ++k) v = s9_tn(s9_lds(sh.Q[k * NT + ti], lane), s9_lds(sh.R[k * NT + tj], lane), v);
+        s9_sts(sh.L[wv], lane, v);
+    }
+    __syncthreads();
+    DBG_T(36);
+    // park Pc in the dead Q | R region (64 KB >= 88 x 64 doubles) for dx
+    double* pcs = &sh.Q[0][0];
+#pragma unroll
+    for (int u = 0; u < PCN; ++u) { const int e = tid + u * NTH; if (e < 88 * 64) ((s9_lds_t*)pcs)[e] = pc[u]; }
+    // ---- W^T = (I - L V) / s2  (Wt(i, j) = (delta - sum_{k <= i} G(k, i)^T V(k, j)) / s2);  W(16 j + b, 16 i + a) = Wt(a, b);  y = W b by tile
+    {
+        const double is2 = 1.0 / s2;
+        s9_d4 acc = s9_zero();
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            if (k <= ti) acc = s9_tn(s9_lds(sh.G[ti * (ti + 1) / 2 + k], lane), s9_lds(sh.L[k * NT + tj], lane), acc);
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 16 * ti + 4 * r + lk, bcol = 16 * tj + li;      // Wt(a, bcol) = W(bcol, a)
+            const double w = (((a == bcol) ? 1.0 : 0.0) - acc[r]) * is2;
+            if (a < c6 && bcol < c6) Wout[(size_t)bcol * ldh + a] = w;
+            t = fma(w, sh.b[a], t);                     // this tile's share of y[bcol]: over its 16 rows a — four in the lane, then the four lane groups (fixed order)
+        }
+        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        if (lk == 0) sh.yp[ti][16 * tj + li] = t;
+    }
+    if (bad) atomicOr(&sh.bad, 1);
+    __syncthreads();
+    if (tid == 0 && sh.bad) atomicOr(&meta->err, 1);
+    if (tid < 64) sh.y[tid] = ((sh.yp[0][tid] + sh.yp[1][tid]) + sh.yp[2][tid]) + sh.yp[3][tid];
+    __syncthreads();
+    DBG_T(37);
+    // ---- dx = K r = Pc y (Updater.cc:544) from the parked Pc: 4 shares of the columns per row, summed in a fixed order
+    {
+        const int np = 4, share = (c6 + np - 1) / np;
+        const int pt = tid / 88, i = tid - pt * 88;
+        if (pt < np && i < d) {
+            double acc = 0;
+            const int k1 = min(c6, (pt + 1) * share);
+            for (int k = pt * share; k < k1; ++k) acc += ((const s9_lds_t*)pcs)[k * 88 + i] * sh.y[k];
+            sh.part[pt * 88 + i] = acc;
+        }
+        __syncthreads();
+        if (tid < d) sh.dx[tid] = ((sh.part[tid] + sh.part[88 + tid]) + sh.part[2 * 88 + tid]) + sh.part[3 * 88 + tid];
+    }
+    __syncthreads();
+    // ---- state injection (Updater.cc:546-613)
+    const double* dx = sh.dx;
+    if (tid == 0) {
+        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
+        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
+        st3(x_out + 7, unit3(ld3(x_out + 7)));
+        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
+        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
+    }
+    for (int p = tid - 64; p >= 0 && p < n; p += NTH - 64) {
+        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
+        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
+    }
+    DBG_T(38);
+    DBG_R(true, 7);
+}

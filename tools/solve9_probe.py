@@ -40,7 +40,8 @@ for name in names:
              us, "solve7" if os.environ.get("RVIO_SOLVE7") else "solve9", 1e3 * t_or), flush=True)
     if hasattr(h.L, "rvio_hip_debug_clocks") and os.environ.get("RVIO_HIP_LIB", "").endswith("dbg.so"):
         import ctypes as C
-        h.set_state(r["x1"], r["P1"]); h.update(types, lens, meas); h.sync()
+        if not os.environ.get("RVIO_PROBE_CHAIN"):   # default: the stamps of the update's own solve launch (the full kernel); RVIO_PROBE_CHAIN=1: of the launches just timed (the chain's form)
+            h.set_state(r["x1"], r["P1"]); h.update(types, lens, meas); h.sync()
         out = (C.c_longlong * 64)()
         h.L.rvio_hip_debug_clocks(h.h, out)
         t = np.array(list(out))
