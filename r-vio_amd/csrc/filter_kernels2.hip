@@ -56,12 +56,19 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     DBG_T(11);
     const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
     const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
-    m33 Rk = q2r(ldq(xs + 10)), RkT = tr33(Rk);
-    d3 pk = ld3(xs + 14), vk = vR, gk = gR;
-    d3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
+    // the serial chain's state (Rk, dp, dv, pk, vk, gk, Dt) lives in LDS BETWEEN the chunks' phase B: held in registers across the whole kernel it
+    // was 66 VGPRs of pressure on every other phase (the two-workgroups-per-CU form of batch handles spilled 916 B of scratch)
+    __shared__ double chain[9 + 3 * 5 + 1];
+    if (tid == 0) {
+        const m33 R0 = q2r(ldq(xs + 10));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) chain[k] = R0.m[k];
+        st3(chain + 9, mk3(0, 0, 0)); st3(chain + 12, mk3(0, 0, 0));      // dp, dv
+        st3(chain + 15, ld3(xs + 14)); st3(chain + 18, vR); st3(chain + 21, gR);   // pk, vk, gk
+        chain[24] = 0.0;                                                   // Dt
+    }
     const m33 I = eye33();
     const double nG = cfg.gravity;
-    double Dt = 0;
     // this thread's (row r9 of rows 9..17, column c9)
     const int r9 = tid / 24, c9 = tid % 24;
     for (int s0 = 0; s0 < m; s0 += PROP3_CH) {
@@ -98,23 +105,35 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         }
         __syncthreads();
         DBG_T(12);
-        // ---- B
-        for (int s = 0; s < mc; ++s) {
-            Prop3Sample& q = sm[s];
+        // ---- B (every thread runs the chain: no broadcast; its state comes from and returns to LDS)
+        {
+            m33 Rk = ldm33(chain), RkT = tr33(Rk);
+            d3 dp = ld3(chain + 9), dv = ld3(chain + 12), pk = ld3(chain + 15), vk = ld3(chain + 18), gk = ld3(chain + 21);
+            double Dt = chain[24];
+            for (int s = 0; s < mc; ++s) {
+                Prop3Sample& q = sm[s];
+                if (tid == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) q.Rk[k] = Rk.m[k];
+                    st3(q.vk, vk); st3(q.gk, gk);
+                }
+                const double dt = q.dt;
+                Dt += dt;
+                Rk = mul33(ldm33(q.dR), Rk); RkT = tr33(Rk);
+                dp = add3(dp, scl3(dt, dv));
+                dp = add3(dp, mv33(RkT, ld3(q.up)));
+                dv = add3(dv, mv33(RkT, ld3(q.uv)));
+                pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
+                vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
+                gk = unit3(mv33(Rk, gR));
+            }
+            __syncthreads();                               // every thread has read the chain's previous state
             if (tid == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) q.Rk[k] = Rk.m[k];
-                st3(q.vk, vk); st3(q.gk, gk);
+                for (int k = 0; k < 9; ++k) chain[k] = Rk.m[k];
+                st3(chain + 9, dp); st3(chain + 12, dv); st3(chain + 15, pk); st3(chain + 18, vk); st3(chain + 21, gk);
+                chain[24] = Dt;
             }
-            const double dt = q.dt;
-            Dt += dt;
-            Rk = mul33(ldm33(q.dR), Rk); RkT = tr33(Rk);
-            dp = add3(dp, scl3(dt, dv));
-            dp = add3(dp, mv33(RkT, ld3(q.up)));
-            dv = add3(dv, mv33(RkT, ld3(q.uv)));
-            pk = add3(sub3(scl3(Dt, vR), scl3(.5 * nG * Dt * Dt, gR)), dp);
-            vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
-            gk = unit3(mv33(Rk, gR));
         }
         __syncthreads();
         DBG_T(13);
@@ -228,29 +247,50 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         DBG_T(16);
     }
     if (tid == 0) {
-        stq(x + 10, r2q(Rk));
-        st3(x + 14, pk);
-        st3(x + 17, vk);
+        stq(x + 10, r2q(ldm33(chain)));
+        st3(x + 14, ld3(chain + 15));
+        st3(x + 17, ld3(chain + 18));
     }
     // P11 back (symmetrised, PreIntegrator.cc:192); P22 is untouched and already symmetric
     for (int e = tid; e < 576; e += 256) {
         int i = e % 24, j = e / 24;
         P[i + (size_t)j * ld] = .5 * (Pl[i][j] + Pl[j][i]);
     }
-    // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191).  Rows of Psi outside 9..17 are identity rows,
-    // so only rows 9..17 of each clone column change: one thread per column, 24 loads, 9 outputs (+ mirror).
-    for (int c = tid; c < 6 * n; c += 256) {
-        double* pc = P + (size_t)(24 + c) * ld;
-        double col[24];
+    // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191).  Rows of Psi outside 9..17 are identity rows, so only rows 9..17 of each clone
+    // column change.  One thread per (column, three of the nine rows): 24 loads, 3 outputs (+ mirror) — with one thread per COLUMN the compiler
+    // kept all nine rows of Psi (216 doubles) in registers across the column loop: 488 VGPRs for the one-workgroup-per-CU forms, 916 B of scratch
+    // spills in the two-per-CU form of batch handles, and only 6n of the 256 threads at work.  Same sums in the same order per output.
+    constexpr int P12_IT = (18 * (RVIO_MAX_LEN - 1) + 255) / 256;     // items per thread at the longest window
+    double outs[P12_IT][3];
 #pragma unroll
-        for (int k = 0; k < 24; ++k) col[k] = pc[k];
+    for (int it = 0; it < P12_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 18 * n) {
+            const int c = e % (6 * n), r0 = 9 + 3 * (e / (6 * n));
+            const double* pc = P + (size_t)(24 + c) * ld;
+            double col[24];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            double acc = 0;
+            for (int k = 0; k < 24; ++k) col[k] = pc[k];
 #pragma unroll
-            for (int k = 0; k < 24; ++k) acc += Psi[9 + r][k] * col[k];
-            pc[9 + r] = acc;
-            P[(24 + c) + (size_t)(9 + r) * ld] = acc;
+            for (int r = 0; r < 3; ++r) {
+                double acc = 0;
+#pragma unroll
+                for (int k = 0; k < 24; ++k) acc += Psi[r0 + r][k] * col[k];
+                outs[it][r] = acc;
+            }
+        }
+    }
+    __syncthreads();     // rows 9..17 of a column are inputs of the other two threads of that column: every read before any write
+#pragma unroll
+    for (int it = 0; it < P12_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 18 * n) {
+            const int c = e % (6 * n), r0 = 9 + 3 * (e / (6 * n));
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                P[(size_t)(r0 + r) + (size_t)(24 + c) * ld] = outs[it][r];
+                P[(24 + c) + (size_t)(r0 + r) * ld] = outs[it][r];
+            }
         }
     }
     DBG_T(17);
