@@ -34,8 +34,9 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     meta = zoff(meta, bs); x = zoff(x, bs); P = zoff(P, bs); imu = zoff(imu, imu_bs);
     __shared__ double Pl[24][25];
     __shared__ double Psi[24][25];
-    __shared__ double Phi9[PROP3_CH][9][25];
-    __shared__ double Sx[PROP3_CH][9][25];      // rows 9..17 of the suffix products S_s = Phi_{mc-1} ... Phi_{s+1}
+    __shared__ double PhiSx[2][PROP3_CH][9][25];   // (one array: the clone-column update at the end stages its columns in it)
+    double (*Phi9)[9][25] = PhiSx[0];
+    double (*Sx)[9][25] = PhiSx[1];             // rows 9..17 of the suffix products S_s = Phi_{mc-1} ... Phi_{s+1}
     __shared__ double PsiC[9][25];              // ... and of the chunk's Psi_c = S_0 Phi_0
     __shared__ double Nq[PROP3_CH][9][6];       // S_s[9..17, (theta, v)] Qd_s
     __shared__ double Qd[PROP3_CH][6][6];       // the dense (theta, v) block of Q_s
@@ -105,8 +106,10 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         }
         __syncthreads();
         DBG_T(12);
-        // ---- B (every thread runs the chain: no broadcast; its state comes from and returns to LDS)
-        {
+        // ---- B: the serial chain, in ONE wave (the other three wait at the barrier: run by all four it was four times the instruction issue for
+        // nothing — what the chain leaves behind is read from LDS; at 2048 instances per launch the kernel is issue bound); its state comes from
+        // and returns to LDS
+        if (tid < 64) {
             m33 Rk = ldm33(chain), RkT = tr33(Rk);
             d3 dp = ld3(chain + 9), dv = ld3(chain + 12), pk = ld3(chain + 15), vk = ld3(chain + 18), gk = ld3(chain + 21);
             double Dt = chain[24];
@@ -127,7 +130,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
                 vk = mv33(Rk, add3(sub3(vR, scl3(nG * Dt, gR)), dv));
                 gk = unit3(mv33(Rk, gR));
             }
-            __syncthreads();                               // every thread has read the chain's previous state
+            // (one wave: every lane has read the chain's previous state before lane 0 overwrites it — program order within the wave)
             if (tid == 0) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) chain[k] = Rk.m[k];
@@ -257,39 +260,31 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         P[i + (size_t)j * ld] = .5 * (Pl[i][j] + Pl[j][i]);
     }
     // P12 = Psi P12, P21 = P12^T (PreIntegrator.cc:186-191).  Rows of Psi outside 9..17 are identity rows, so only rows 9..17 of each clone
-    // column change.  One thread per (column, three of the nine rows): 24 loads, 3 outputs (+ mirror) — with one thread per COLUMN the compiler
-    // kept all nine rows of Psi (216 doubles) in registers across the column loop: 488 VGPRs for the one-workgroup-per-CU forms, 916 B of scratch
-    // spills in the two-per-CU form of batch handles, and only 6n of the 256 threads at work.  Same sums in the same order per output.
-    constexpr int P12_IT = (18 * (RVIO_MAX_LEN - 1) + 255) / 256;     // items per thread at the longest window
-    double outs[P12_IT][3];
+    // column change.  The columns are staged in LDS (over the dead Phi / suffix-product buffers, in tiles when the window is long) with
+    // COALESCED loads — a column is 24 contiguous doubles; one thread per column walking it was 64 cache lines per load instruction, ~24x the
+    // bytes at 2048 instances per launch — then one thread per (column, three of the nine rows): 24 LDS reads, 3 outputs (+ mirror).  (One
+    // thread per column also made the compiler keep all nine rows of Psi — 216 doubles — in registers across the column loop: 488 VGPRs in
+    // the one-workgroup-per-CU forms, 916 B of scratch spills in the two-per-CU form of batch handles.)  Same sums in the same order per output.
+    {
+        double* stage = &PhiSx[0][0][0][0];
+        constexpr int CAP_COLS = (2 * PROP3_CH * 9 * 25) / 25;     // columns of 25 doubles (24 + 1 pad: conflict-free when lanes differ in the column)
+        const int c6 = 6 * n;
+        for (int c0 = 0; c0 < c6; c0 += CAP_COLS) {
+            const int nc = min(CAP_COLS, c6 - c0);
+            __syncthreads();                                       // the buffers' previous readers are done
+            for (int e = tid; e < 24 * nc; e += 256) { const int k = e % 24, c = e / 24; stage[c * 25 + k] = P[(size_t)k + (size_t)(24 + c0 + c) * ld]; }
+            __syncthreads();
+            for (int e = tid; e < 3 * nc; e += 256) {
+                const int c = e % nc, r0 = 9 + 3 * (e / nc);
+                const double* col = stage + c * 25;
 #pragma unroll
-    for (int it = 0; it < P12_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 18 * n) {
-            const int c = e % (6 * n), r0 = 9 + 3 * (e / (6 * n));
-            const double* pc = P + (size_t)(24 + c) * ld;
-            double col[24];
+                for (int r = 0; r < 3; ++r) {
+                    double acc = 0;
 #pragma unroll
-            for (int k = 0; k < 24; ++k) col[k] = pc[k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                double acc = 0;
-#pragma unroll
-                for (int k = 0; k < 24; ++k) acc += Psi[r0 + r][k] * col[k];
-                outs[it][r] = acc;
-            }
-        }
-    }
-    __syncthreads();     // rows 9..17 of a column are inputs of the other two threads of that column: every read before any write
-#pragma unroll
-    for (int it = 0; it < P12_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 18 * n) {
-            const int c = e % (6 * n), r0 = 9 + 3 * (e / (6 * n));
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                P[(size_t)(r0 + r) + (size_t)(24 + c) * ld] = outs[it][r];
-                P[(24 + c) + (size_t)(r0 + r) * ld] = outs[it][r];
+                    for (int k = 0; k < 24; ++k) acc += Psi[r0 + r][k] * col[k];
+                    P[(size_t)(r0 + r) + (size_t)(24 + c0 + c) * ld] = acc;
+                    P[(24 + c0 + c) + (size_t)(r0 + r) * ld] = acc;
+                }
             }
         }
     }
