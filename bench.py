@@ -572,7 +572,7 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     t_klt = h.time_kernel(1, 50) * 1e-6
     t_feat = h.time_kernel(2, 50) * 1e-6
     t_subpix = h.time_kernel(6, 50) * 1e-6
-    solve_name = "solve7_kernel" if c6 <= 64 else "solve9_kernel"   # (rvio_hip.hip: the register-tableau elimination up to 6n = 64, the blocked SPD solve beyond)
+    solve_name = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel"   # (rvio_hip.hip: the blocked SPD solve; at 6n <= 64 behind the Cholesky role its all-LDS form)
     # solve: T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T (c6 = 6n columns, register tableau).  Algorithmic
     # FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8)
     fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
@@ -588,8 +588,9 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     cands = [
         {"bound": "mfma", "kernel": "%s (W = (s2 I + A Pcc)^-1, dx, state injection; one workgroup)" % solve_name, "match": solve_name, "launched_by_timed_path": solve_name,
          "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_solve * 1e6,
-         "note": ("latency bound: a %dx%d FP64 elimination is a chain of %d dependent pivot decisions on ONE CU" % (c6, c6 + 1, c6)) if c6 <= 64 else
-                 "blocked Cholesky + symmetric sweep on FP64 MFMA tiles, one workgroup on ONE CU (0.31 TFLOP/s of the chip's %.1f); algorithmic work = that of the LU inverse" % PEAK_F64},
+         "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles, one workgroup on ONE CU (0.31 TFLOP/s of the chip's %.1f); the Cholesky of the clone "
+                 "block rides in the per-feature launch at 6n <= 96; latency bound: %d 16 x 16 in-wave factorisations in sequence; algorithmic work = that of the LU inverse"
+                 % (PEAK_F64, (c6 + 15) // 16)},
         {"bound": "hbm", "kernel": "klt_kernel3 (4-level pyramidal LK, one wave per feature)", "match": "klt_kernel3", "launched_by_timed_path": "klt_kernel3 (forward match)",
          "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_klt * 1e6,
          "note": "timed matching the current image back onto the previous one from the current feature positions (the forward match's displacements, "
