@@ -8,9 +8,6 @@
 #pragma once
 #include "rvio_dev.h"
 #include "solve9.hip"   // the Cholesky role of the solve rides in the per-feature / propagate launches
-#ifdef RVIO_DBG_CLOCKS
-#include "solve8.hip"   // (measured, not adopted: instrumented build only — see its header)
-#endif
 
 // skew(v)[i][j] with v in LDS (dynamic indexing is fine there):  [[0,-z,y],[z,0,-x],[-y,x,0]]
 __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
@@ -324,8 +321,6 @@ __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterM
 // U1-U5 read only the clone states and P[24:,24:], which propagation does not touch (it rewrites the IMU state, P[0:24,0:24] and the
 // cross terms P[0:24,24:] / P[24:,0:24]), so the two are independent; the last workgroup IS propagate_kernel3, the others ARE
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
-// pinv != NULL (instrumented build, RVIO_SOLVE8: the solve without a pivot search — measured, not adopted, solve8.hip): one more workgroup
-// inverts the clone block Pcc, the measurement-independent half of that solve (propagation leaves Pcc alone, so it is the Pcc the solve will see).
 // chol_scr != NULL (round 5, solve9.hip at 6n <= 96): one more workgroup factors the clone block Pcc = L L^T into the solve's tile slab —
 // the measurement-independent part of the solve, off the filter chain (its LDS: the launch's dynamic LDS, idle in that workgroup).
 template <int CH>      // propagate's chunk size (its LDS: 86 KB at 16, 47 KB at 8 — long windows need the room for the per-feature stage)
@@ -333,7 +328,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
-                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* pinv, double* chol_scr, int chol_nt) {
+                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* chol_scr, int chol_nt) {
     DBG_R(blockIdx.x == 0, 0);
     if (blockIdx.x == gridDim.x - 1) { propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0); return; }
     if (chol_scr && blockIdx.x == gridDim.x - 2) {
@@ -342,9 +337,6 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
         else s9_chol_role<3>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<6, 4>*>(fp_dyn));
         return;
     }
-#ifdef RVIO_DBG_CLOCKS
-    if (pinv && blockIdx.x == gridDim.x - 2) { extern __shared__ __align__(16) double fp_dyn[]; pinv_role<4>(cfg, n, P, pinv, meta, fp_dyn); return; }
-#endif
     feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, 0, 1, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta, (int)blockIdx.x);
 }
 

@@ -20,8 +20,8 @@
 #include "solve6.hip"
 #include "solve7.hip"
 #include "solve9.hip"   // round 5: the solve as blocked SPD factorisations on the matrix cores (one instance; every window up to 6n = 192)
-#ifdef RVIO_DBG_CLOCKS
-#include "solve8.hip"   // the solve without a pivot search: measured, NOT adopted (its header says why); instrumented build only, RVIO_SOLVE8=1
+#ifndef S9_BATCH
+#define S9_BATCH (ab_env("RVIO_S9_BATCH") != nullptr)   // A/B timing: batch handles at 6n <= 64 through solve9_kernel<1, 4> instead of gemm_T + solve6
 #endif
 #pragma clang fp contract(off)
 #include "frontend_kernels.hip"
@@ -74,9 +74,6 @@ struct rvio_hip {
     int solve9_nt = 0;           // solve9_kernel (solve9.hip): tiles per side of the padded clone block (4, 6, 8, 12), 0: not used (batch handles, RVIO_SOLVE7=1)
     double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles (+ the verdict of the Cholesky role)
     bool chol_ready = false;     // the slab holds L, G of the clone block the next solve will see (written by the role workgroup of the per-feature / propagate launch)
-    bool solve8 = false;         // one instance, 6n <= 64: the solve without a pivot search (solve8.hip) — Pcc^-1 beside the per-feature stage, B^-1 on the chain
-    bool pinv_ready = false;     // Pinv holds the inverse of the clone block the next solve will see (written by the fused per-feature launch)
-    double* Pinv = nullptr;      // 64 x 64 (instrumented build only)
     float* eig_map = nullptr;    // W x H min-eigenvalue map of rvio_hip_get_corners(eig): allocated on first use
     size_t solve5_lds = 0, cholt_lds = 0;
     // staging
@@ -324,9 +321,6 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global) {
     DALLOC(h, h->gram_cnt, 8);
     DALLOC(h, h->stage_sync, 1);
     DALLOC(h, h->Tbuf, ldh * ldh); DALLOC(h, h->W, ldh * ldh);
-#ifdef RVIO_DBG_CLOCKS
-    DALLOC(h, h->Pinv, 64 * 64);   // solve8's Pcc^-1: the shipping pipeline never touches it
-#endif
     DALLOC(h, h->U, dm * ldh); DALLOC(h, h->G, dm * ldh);
     DALLOC(h, h->Pt1, PP);
     DALLOC(h, h->gamma, d.Fu); DALLOC(h, h->pfinv, (size_t)3 * d.Fu);
@@ -522,15 +516,11 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
-    // (instrumented build: + the 18 KB of static LDS of solve8's inverse role, which also stages Pcc in the launch's dynamic LDS)
     // propagate rides in the per-feature launch when both fit one CU's LDS: the dynamic per-feature footprint + the kernel's static LDS
-    // (propagate's composed-chunk buffers: 86 KB at 16 samples per chunk, 47 KB at 8; instrumented build: + solve8's inverse role)
+    // (propagate's composed-chunk buffers: 86 KB at 16 samples per chunk, 47 KB at 8)
     h->fprop_lds = h->feat_lds;
     // (round 5: + the Cholesky role of solve9 at 6n <= 96 — one more workgroup whose buffers live in the launch's dynamic LDS)
     if (batch == 1 && c6m <= 96) h->fprop_lds = std::max(h->fprop_lds, c6m <= 64 ? sizeof(S9CholLds<4, 4>) : sizeof(S9CholLds<6, 4>));
-#ifdef RVIO_DBG_CLOCKS
-    h->fprop_lds = std::max(h->feat_lds, (size_t)S8_PINV_LDS_DOUBLES * sizeof(double));
-#endif
     h->fuse_ch = 0;
     if (batch == 1 && !ab_env("RVIO_NO_FUSED_PROPAGATE")) {
         hipFuncAttributes a16, a8;
@@ -556,9 +546,9 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             // 6n = 84: 94.0 us against solve7's 102.6; 120: 173 against 212; 180: 511 against 797.  At 6n <= 96 the Cholesky of the clone block — the part that does
             // not depend on the measurements — rides as one more workgroup in the per-feature launch (pipelined frame) or in propagate's launch (staged entry
             // points), off the chain; the solve kernel then starts at Q = A L.  RVIO_SOLVE7=1 (instrumented build) keeps the register-tableau elimination: A/B timing.
-            if (batch == 1 && c6m <= 192 && !ab_env("RVIO_SOLVE7")) {
+            if ((batch == 1 || (c6m <= 64 && S9_BATCH)) && c6m <= 192 && !ab_env("RVIO_SOLVE7")) {
                 h->solve9_nt = (c6m <= 64) ? 4 : (c6m <= 96) ? 6 : (c6m <= 128) ? 8 : 12;
-                DALLOC(h, h->S9scr, S9_SLAB_DOUBLES(h->solve9_nt));
+                DALLOC(h, h->S9scr, S9_SLAB_DOUBLES(h->solve9_nt) * (size_t)batch);
                 if (h->solve9_nt == 4) HIPCHK(h, hipFuncSetAttribute((const void*)solve9_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(S9SmallLds)));
             }
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
@@ -567,14 +557,6 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             // launch — as the batch form at 6n <= 64, RVIO_BATCH_SOLVE7: 2.62 ms per batched frame at B = 2048 against 2.29 with solve6 behind gemm_T)
             if (batch > 1 && h->solve5_variant && !ab_env("RVIO_SOLVE7") && !(h->solve7_variant == 1 && ab_env("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
             if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
-#ifdef RVIO_DBG_CLOCKS
-            h->solve8 = h->solve7_variant == 1 && batch == 1 && ab_env("RVIO_SOLVE8");
-            if (h->solve8) {
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_LDS_DOUBLES * sizeof(double))));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_LDS_DOUBLES * sizeof(double))));
-                HIPCHK(h, hipFuncSetAttribute((const void*)pinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S8_PINV_LDS_DOUBLES * sizeof(double))));
-            }
-#endif
             if (h->solve7_variant == 1)
             {
                 HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
@@ -869,21 +851,19 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const size_t bs = h->slab_bytes;
     const int B = h->batch;
     if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
-        const bool pinv = h->solve8 && world == 1 && combine;   // (the unsharded update of this very launch follows: the solve will want Pcc^-1)
         // solve9 at 6n <= 96: the Cholesky of the clone block as one more workgroup of this launch (the solve of this very update follows on the stream)
-        const bool chol = !pinv && h->solve9_nt && h->solve9_nt <= 6 && n >= 1;
+        const bool chol = h->solve9_nt && h->solve9_nt <= 6 && n >= 1;
         double* cs = chol ? h->S9scr : (double*)nullptr;
-        const int extra = 1 + (pinv ? 1 : 0) + (chol ? 1 : 0);
+        const int extra = 1 + (chol ? 1 : 0);
         if (h->fuse_ch == 16)
             hipLaunchKernelGGL(feat_prop_kernel<16>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr, cs, h->solve9_nt);
+                               h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
         else
             hipLaunchKernelGGL(feat_prop_kernel<8>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, pinv ? h->Pinv : (double*)nullptr, cs, h->solve9_nt);
+                               h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
         h->chol_ready = chol;
-        h->pinv_ready = pinv;
         h->fuse_m = -1;
     } else
     if (B == 1)   // one stream: the latency form (every operand load of a gate tile in flight at once)
@@ -915,16 +895,6 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     const dim3 gb(1, 1, h->batch);
-#ifdef RVIO_DBG_CLOCKS
-    if (h->solve8) {   // no pivot search: Pcc^-1 (from the fused per-feature launch, or a launch of its own right here), then B^-1 on the chain
-        if (!h->pinv_ready) hipLaunchKernelGGL(pinv_kernel, dim3(1), dim3(64 * S8_NW), S8_PINV_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->Pinv, h->meta);
-        h->pinv_ready = false;
-        static const int gjw = ab_env("RVIO_S8_GJ") ? atoi(ab_env("RVIO_S8_GJ")) : 4;   // (A/B timing: waves that run the elimination)
-        if (gjw == 8) hipLaunchKernelGGL(solve8_kernel<8>, dim3(1), dim3(64 * S8_NW), S8_LDS_DOUBLES * sizeof(double), h->stream, d, h->meta, n, Ab, xin, Pc, h->Pinv, h->W, xout);
-        else hipLaunchKernelGGL(solve8_kernel<4>, dim3(1), dim3(64 * S8_NW), S8_LDS_DOUBLES * sizeof(double), h->stream, d, h->meta, n, Ab, xin, Pc, h->Pinv, h->W, xout);
-        return;
-    }
-#endif
     if (h->solve9_nt) {   // blocked SPD factorisations on the matrix cores (solve9.hip): one workgroup, one launch
         const bool pre = h->chol_ready;   // L, G of the clone block are in the slab already (the role workgroup of this update's per-feature / propagate launch)
         h->chol_ready = false;
@@ -933,7 +903,8 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
             static const bool s9_generic = ab_env("RVIO_S9_GENERIC") != nullptr;   // A/B timing: the generic kernel (tiles through the L2 slab) at 6n <= 64
             if (pre && !s9_generic) hipLaunchKernelGGL(solve9_small_kernel, dim3(1), dim3(1024), sizeof(S9SmallLds), h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout);
             else if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
-            else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes,
+                                    h->batch > 1 ? S9_SLAB_DOUBLES(4) * sizeof(double) : (size_t)0);
             return;
         case 6:
             if (pre) hipLaunchKernelGGL((solve9_kernel<2, 3, true>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
@@ -1012,7 +983,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
     }
     const int tt = (c6 + 31) / 32;
     static const bool no_gtl = ab_env("RVIO_NO_GEMM_T_LDS") != nullptr;   // A/B timing
-    if (!h->solve7_variant) {
+    if (!h->solve7_variant && !h->solve9_nt) {
         if (B >= 128 && d.ldh - 1 <= 64 && !no_gtl)
             hipLaunchKernelGGL(gemm_T_lds_kernel, dim3(1, 1, B), dim3(256), (size_t)2 * c6 * (c6 + 1) * sizeof(double), h->stream, d, n, Ab, Pc, h->Tbuf, bs);
         else
@@ -1920,8 +1891,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            h->pinv_ready = h->solve8;   // (time what the chain sees: the solve kernel alone; Pcc^-1 rides in the per-feature launch)
-            h->chol_ready = h->solve9_nt && h->solve9_nt <= 6 && !ab_env("RVIO_S9_FULL");   // (likewise the Cholesky role of solve9: the slab holds a factor from the last update)
+            h->chol_ready = h->solve9_nt && h->solve9_nt <= 6 && !ab_env("RVIO_S9_FULL");   // (time what the chain sees: the Cholesky role rides in the per-feature launch; the slab holds a factor from the last update)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT
