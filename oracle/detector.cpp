@@ -180,14 +180,14 @@ void rect_subpix(const uint8_t* src, int w, int h, int stride, float cx, float c
 
 // cornerSubPix, cornersubpix.cpp.  Accumulation order of the five double sums (OpenCV adds the (2 win + 1)^2 terms in one row-major
 // chain; any fixed order differs from it by O(1e-16) relative): canonical = the terms on a zero-padded G x G grid, G = 16 for window
-// half-sizes <= 7 (the stock 7: 15 rows / columns) and 32 for half-sizes <= 15; per row a balanced binary tree over the columns
-// ((j, j + G/2), then + G/4, ... + 1), the rows in groups of four ((R0 + R1) + (R2 + R3)), the G/4 groups by a balanced binary tree
-// (G = 16: (W0 + W1) + (W2 + W3)).
+// half-sizes <= 7 (the stock 7: 15 rows / columns), 32 for half-sizes <= 15, 64 for <= 31, 128 for <= 63 (Tracker.nMinDist < 128); per row a
+// balanced binary tree over the columns ((j, j + G/2), then + G/4, ... + 1), the rows in groups of four ((R0 + R1) + (R2 + R3)), the G/4
+// groups by a balanced binary tree over neighbours (G = 16: (W0 + W1) + (W2 + W3); G = 32: that + ((W4 + W5) + (W6 + W7)); ...).
 // row_major = true (orc_corner_subpix_rowmajor, measurement only): the five sums as one row-major chain each, OpenCV's own order.
 void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int n, int win, int max_iter, double eps, bool row_major = false) {
     const int ww = 2 * win + 1, pw = ww + 2;
-    const int G = ww <= 16 ? 16 : 32;          // (half-sizes up to 15: Tracker.nMinDist < 32)
-    if (win < 1 || ww > 32) return;
+    const int G = ww <= 16 ? 16 : ww <= 32 ? 32 : ww <= 64 ? 64 : 128;
+    if (win < 1 || ww > 128) return;
     std::vector<float> mask((size_t)ww * ww);
     for (int i = 0; i < ww; ++i) {
         const float y = (float)(i - win) / (float)win;
@@ -203,6 +203,7 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
 #pragma omp parallel for schedule(dynamic, 4)
     for (int p = 0; p < n; ++p) {
         std::vector<float> patch((size_t)pw * pw);
+        std::vector<double> term_((size_t)5 * G * G), tv_(G);
         const float tx = pts[2 * p], ty = pts[2 * p + 1];
         float cx = tx, cy = ty;
         int iter = 0;
@@ -210,8 +211,8 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
         do {
             rect_subpix(src, w, h, stride, cx, cy, pw, pw, patch.data());
             // term[q][i][j] on a G x G grid (rows / columns >= ww are zero padding)
-            static thread_local double term[5][32][32];
-            std::memset(term, 0, sizeof term);
+            std::fill(term_.begin(), term_.end(), 0.0);
+            auto term = [&](int q, int i) { return &term_[((size_t)q * G + i) * G]; };
             for (int i = 0; i < ww; ++i) {
                 const float* sp = &patch[(size_t)(i + 1) * pw + 1];
                 const double py = i - win;
@@ -221,29 +222,30 @@ void corner_subpix(const uint8_t* src, int w, int h, int stride, float* pts, int
                     const double tgx = sp[j + 1] - sp[j - 1];
                     const double tgy = sp[j + pw] - sp[j - pw];
                     const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                    term[0][i][j] = gxx; term[1][i][j] = gxy; term[2][i][j] = gyy;
-                    term[3][i][j] = gxx * px + gxy * py;
-                    term[4][i][j] = gxy * px + gyy * py;
+                    term(0, i)[j] = gxx; term(1, i)[j] = gxy; term(2, i)[j] = gyy;
+                    term(3, i)[j] = gxx * px + gxy * py;
+                    term(4, i)[j] = gxy * px + gyy * py;
                 }
             }
             // per row a balanced tree over the G columns: (j, j+G/2), then +G/4, ... +1 -> R_i; groups of four rows
             // W_g = (R_4g + R_4g+1) + (R_4g+2 + R_4g+3); the G/4 groups by a balanced tree (G = 16: (W_0 + W_1) + (W_2 + W_3))
             double tot[5];
             for (int q = 0; q < 5; ++q) {
-                double R[32];
+                double R[128];
                 for (int i = 0; i < G; ++i) {
-                    double* v = term[q][i];
+                    double* v = term(q, i);
+                    double* t = tv_.data();
                     for (int s = G / 2; s >= 1; s >>= 1) {
-                        double t[32];
                         for (int j = 0; j < G; ++j) t[j] = v[j] + v[(j + s) & (G - 1)];
                         for (int j = 0; j < G; ++j) v[j] = t[j];
                     }
                     R[i] = v[0];
                 }
-                double Wg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                double Wg[32];
                 for (int g = 0; g < G / 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
-                tot[q] = (Wg[0] + Wg[1]) + (Wg[2] + Wg[3]);
-                if (G == 32) tot[q] = tot[q] + ((Wg[4] + Wg[5]) + (Wg[6] + Wg[7]));
+                for (int m = G / 4; m > 1; m >>= 1)                 // neighbours pairwise, level by level
+                    for (int g = 0; g < m / 2; ++g) Wg[g] = Wg[2 * g] + Wg[2 * g + 1];
+                tot[q] = Wg[0];
             }
             if (row_major) {
                 const float* patchp = patch.data();

@@ -1126,3 +1126,105 @@ __global__ __launch_bounds__(SPG_T) void subpix_generic_kernel(const uint8_t* __
     if (fabsf(cx - tx) > win || fabsf(cy - ty) > win) { cx = tx; cy = ty; }
     if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
 }
+
+// cornerSubPix for half-windows 16 .. 63 (32 <= Tracker.nMinDist < 128): the canonical G x G grid (G = 64 / 128) does not fit LDS as doubles,
+// so the first levels of the balanced column tree are taken in registers: the thread of (row i, folded column jf < 16) forms the terms of the
+// columns jf + 16 m (m < G / 16) and adds them in the tree's own order ((j, j + G/2), then + G/4, ... down to + 16) before anything is stored —
+// the same additions as oracle/detector.cpp, in the same association.  LDS holds the 16 folded columns of every row; the rest as above.
+#define SPW_C 16
+__global__ __launch_bounds__(SPG_T) void subpix_wide_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
+    extern __shared__ __align__(16) double spw_dyn[];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n = *d.n_out;
+    if (p >= n) return;
+    const int W = d.W, H = d.H, win = d.sp_win, ww = 2 * win + 1, pw = ww + 2, G = ww <= 64 ? 64 : 128, M = G / SPW_C;
+    double* term = spw_dyn;                                   // [5][G][SPW_C + 1]
+    double* rowsum = term + (size_t)5 * G * (SPW_C + 1);      // [5][G]
+    double* tot = rowsum + 5 * G;                             // [5]
+    const float tx = d.raw_xy[2 * p], ty = d.raw_xy[2 * p + 1];
+    auto pix = [&](int x, int y) -> float { return (float)src[(size_t)min(max(y, 0), H - 1) * stride + min(max(x, 0), W - 1)]; };
+    float cx = tx, cy = ty;
+    const double eps = 1e-2 * 1e-2;
+    int iter = 0;
+    double err = 0;
+    do {
+        const float ox = cx - (float)(pw - 1) * 0.5f, oy = cy - (float)(pw - 1) * 0.5f;   // getRectSubPix, samplers.cpp
+        const int ix = (int)floorf(ox), iy = (int)floorf(oy);
+        float fa = ox - (float)ix;
+        const float fb = oy - (float)iy;
+        fa = fmaxf(fa, 0.0001f);
+        const float a11 = (1.f - fa) * (1.f - fb), a12 = fa * (1.f - fb), a21 = (1.f - fa) * fb, a22 = fa * fb;
+        auto samp = [&](int pi, int pj) -> float {
+            const int x = ix + pj, y = iy + pi;
+            return ((pix(x, y) * a11 + pix(x + 1, y) * a12) + pix(x, y + 1) * a21) + pix(x + 1, y + 1) * a22;
+        };
+        for (int e = tid; e < G * SPW_C; e += SPG_T) {
+            const int wi = e / SPW_C, jf = e - wi * SPW_C;
+            double v[5][8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int wj = jf + SPW_C * m;
+                double gxx = 0.0, gxy = 0.0, gyy = 0.0, t3 = 0.0, t4 = 0.0;
+                if (m < M && wi < ww && wj < ww) {
+                    const double wm = (double)d.spmask[wi * ww + wj], px = wj - win, py = wi - win;
+                    const double tgx = samp(wi + 1, wj + 2) - samp(wi + 1, wj);
+                    const double tgy = samp(wi + 2, wj + 1) - samp(wi, wj + 1);
+                    gxx = tgx * tgx * wm; gxy = tgx * tgy * wm; gyy = tgy * tgy * wm;
+                    t3 = gxx * px + gxy * py;
+                    t4 = gxy * px + gyy * py;
+                }
+                v[0][m] = gxx; v[1][m] = gxy; v[2][m] = gyy; v[3][m] = t3; v[4][m] = t4;
+            }
+            // the tree's levels above 16 columns: (m, m + M/2), then + M/4, ...
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (M == 8) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[q][m] = v[q][m] + v[q][m + 4];
+                }
+                v[q][0] = v[q][0] + v[q][2]; v[q][1] = v[q][1] + v[q][3];
+                term[((size_t)q * G + wi) * (SPW_C + 1) + jf] = v[q][0] + v[q][1];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 5 * G; e += SPG_T) {          // the tree's remaining levels: + 8, + 4, + 2, + 1
+            const double* t = term + (size_t)e * (SPW_C + 1);
+            double v[SPW_C];
+#pragma unroll
+            for (int j = 0; j < SPW_C; ++j) v[j] = t[j];
+#pragma unroll
+            for (int sft = SPW_C / 2; sft >= 1; sft >>= 1)
+#pragma unroll
+                for (int k = 0; k < SPW_C / 2; ++k) if (k < sft) v[k] = v[k] + v[k + sft];
+            rowsum[e] = v[0];
+        }
+        __syncthreads();
+        if (tid < 5) {
+            const double* R = rowsum + tid * G;
+            double Wg[32];
+            for (int g = 0; g < G / 4; ++g) Wg[g] = (R[4 * g] + R[4 * g + 1]) + (R[4 * g + 2] + R[4 * g + 3]);
+            for (int m = G / 4; m > 1; m >>= 1)
+                for (int g = 0; g < m / 2; ++g) Wg[g] = Wg[2 * g] + Wg[2 * g + 1];
+            tot[tid] = Wg[0];
+        }
+        __syncthreads();
+        const double a = tot[0], b = tot[1], c = tot[2], bb1 = tot[3], bb2 = tot[4];
+        const double det = a * c - b * b;
+        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+        const double scale = 1.0 / det;
+        const float nx = (float)(cx + c * scale * bb1 - b * scale * bb2);
+        const float ny = (float)(cy - b * scale * bb1 + a * scale * bb2);
+        const float ex = nx - cx, ey = ny - cy;
+        err = (double)(ex * ex + ey * ey);
+        cx = nx; cy = ny;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) break;
+    } while (++iter < 30 && err > eps);
+    if (fabsf(cx - tx) > win || fabsf(cy - ty) > win) { cx = tx; cy = ty; }
+    if (tid == 0) { d.xy[2 * p] = cx; d.xy[2 * p + 1] = cy; }
+}
+// dynamic LDS of subpix_wide_kernel for a half-window
+static inline size_t subpix_wide_lds(int win) {
+    const int G = 2 * win + 1 <= 64 ? 64 : 128;
+    return sizeof(double) * ((size_t)5 * G * (SPW_C + 1) + 5 * G + 8);
+}

@@ -88,6 +88,9 @@ struct rvio_hip {
                                                   // detectors of consecutive frames run on two streams, by frame parity
     int det_set_last = 0;                         // the set the last call used (rvio_hip_get_corners)
     bool det_ready = false, use_det = false;
+    hipStream_t stream_l = nullptr;               // long windows (6n > 96): = stream_c (one image chain in flight); the Cholesky factor of the clone block runs here, beside propagate / the per-feature stage of the frame it serves
+    hipEvent_t evA = nullptr, evL = nullptr;      // augment/compose done (filter stream) -> stream_l;  factor in the slab (stream_l) -> the solve
+    bool chol_async = false;                      // a factor of the CURRENT clone block is in flight on (or has left) stream_l
     hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
     hipStream_t stream_c = nullptr;               // CLAHE stream of the run-ahead mode (frame k+1 is equalised while frame k is still being detected)
     hipEvent_t evC[kIC] = {nullptr, nullptr, nullptr};   // equalised image + pyramid of the frame ready, by image chain
@@ -433,8 +436,18 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         // Image chains in flight.  Two (default): with the filter, tracker and side streams that makes FOUR busy queues.  A third chain on a
         // fifth queue was measured (RVIO_IC=3): the frame period goes from 131 to 180-250 us whatever CUs the front end is kept off — beyond
         // four busy queues the command processor time-slices them.
+        // Long windows (96 < 6n <= 192: the solve in its split form, filter chain >= 250 us): ONE image chain in flight is enough (the chain is ~180 us),
+        // and the queue that frees runs the Cholesky factor of the clone block beside the filter chain (augment_compose_dev).  A FIFTH queue for it was
+        // measured: cfg C 3.2 k frames/s instead of 3.9 k — the command processor time-slices beyond four busy queues.
+        const int c6m_ = 6 * (h->cfg.max_track_len - 1);
+        if (batch == 1 && c6m_ > 96 && c6m_ <= 192) h->n_ic = 1;
         if (const char* e = ab_env("RVIO_IC")) h->n_ic = std::max(1, std::min((int)rvio_hip::kIC, atoi(e)));
         if (h->n_ic > 2) HIPCHK(h, make_stream(h, &h->stream_e, true));
+        if (batch == 1 && c6m_ > 96 && c6m_ <= 192 && h->n_ic == 1) {
+            h->stream_l = h->stream_c;
+            HIPCHK(h, hipEventCreateWithFlags(&h->evA, kEvFlags));
+            HIPCHK(h, hipEventCreateWithFlags(&h->evL, kEvFlags));
+        }
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->evD0, kEvFlags));
     HIPCHK(h, hipEventCreateWithFlags(&h->evD1, kEvFlags));
@@ -609,6 +622,8 @@ void rvio_hip_destroy(rvio_hip* h) {
     for (void* p : h->allocs) hipFree(p);
     for (int k = 0; k < rvio_hip::kPin; ++k) { if (h->pin[k]) hipHostFree(h->pin[k]); if (h->evPin[k]) hipEventDestroy(h->evPin[k]); if (h->evPin2[k]) hipEventDestroy(h->evPin2[k]); }
     if (h->first_mirror) hipHostFree(h->first_mirror);
+    if (h->evA) hipEventDestroy(h->evA);
+    if (h->evL) hipEventDestroy(h->evL);
     if (h->evD0) hipEventDestroy(h->evD0);
     if (h->evD1) hipEventDestroy(h->evD1);
     if (h->stream_d && !h->one_stream) hipStreamDestroy(h->stream_d);
@@ -654,6 +669,7 @@ static int set_state_range(rvio_hip* h, int lo, int hi, const double* x, int xdi
     HIPCHK(h, hipSetDevice(h->device));
     FilterMeta m; std::memset(&m, 0, sizeof m);
     m.n_clones = n; m.img_count = h->img_count;
+    if (h->chol_async) { HIPCHK(h, hipStreamSynchronize(h->stream_l)); h->chol_async = false; }   // (a factor in flight reads the covariance that is about to be replaced)
     for (int i = lo; i < hi; ++i) {
         const size_t o = (size_t)i * h->slab_bytes;
         double* Pi = (double*)((char*)h->P[h->cur] + o);
@@ -896,8 +912,9 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     const dim3 gb(1, 1, h->batch);
     if (h->solve9_nt) {   // blocked SPD factorisations on the matrix cores (solve9.hip): one workgroup, one launch
-        const bool pre = h->chol_ready;   // L, G of the clone block are in the slab already (the role workgroup of this update's per-feature / propagate launch)
-        h->chol_ready = false;
+        if (h->chol_async) (void)hipStreamWaitEvent(h->stream, h->evL, 0);   // the factor that started behind the last augment / compose
+        const bool pre = h->chol_ready || h->chol_async;   // L, G of the clone block are in the slab already (role workgroup of this update's per-feature / propagate launch; stream_l)
+        h->chol_ready = false; h->chol_async = false;
         switch (h->solve9_nt) {
         case 4:
             static const bool s9_generic = ab_env("RVIO_S9_GENERIC") != nullptr;   // A/B timing: the generic kernel (tiles through the L2 slab) at 6n <= 64
@@ -910,9 +927,33 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
             if (pre) hipLaunchKernelGGL((solve9_kernel<2, 3, true>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
             else hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
             return;
-        case 8: hipLaunchKernelGGL((solve9_kernel<2, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
-        default: hipLaunchKernelGGL((solve9_kernel<3, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0); return;
+        default: break;
         }
+        // 6n > 96: the split form — the four product phases as launches that fill the chip, the two factorisations as one workgroup each (solve9.hip)
+        static const bool s9_one = ab_env("RVIO_S9_ONE") != nullptr;   // A/B timing: everything in ONE workgroup
+        const int NT = h->solve9_nt, nwg = (NT * NT + 3) / 4;
+        if (s9_one) {
+            if (NT == 8) hipLaunchKernelGGL((solve9_kernel<2, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            else hipLaunchKernelGGL((solve9_kernel<3, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+            return;
+        }
+        if (!pre) {
+            if (NT == 8) hipLaunchKernelGGL((solve9_chol_kernel<2, 4>), dim3(1), dim3(1024), 0, h->stream, d, n, Pc, h->S9scr);
+            else hipLaunchKernelGGL((solve9_chol_kernel<3, 4>), dim3(1), dim3(1024), 0, h->stream, d, n, Pc, h->S9scr);
+        }
+        hipLaunchKernelGGL(solve9_prod_kernel<0>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
+        hipLaunchKernelGGL(solve9_prod_kernel<1>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
+        static const bool sweep4 = ab_env("RVIO_S9_SWEEP4") != nullptr;   // A/B timing: the sweep on 2 x 2 waves with 16 / 36 tiles each (no spills, one wave per matrix pipe)
+        if (sweep4) {
+            if (NT == 8) hipLaunchKernelGGL((solve9_sweep_kernel<4, 2>), dim3(1), dim3(256), 0, h->stream, d, Ab, h->S9scr);
+            else hipLaunchKernelGGL((solve9_sweep_kernel<6, 2>), dim3(1), dim3(256), 0, h->stream, d, Ab, h->S9scr);
+        } else
+        if (NT == 8) hipLaunchKernelGGL((solve9_sweep_kernel<2, 4>), dim3(1), dim3(1024), 0, h->stream, d, Ab, h->S9scr);
+        else hipLaunchKernelGGL((solve9_sweep_kernel<3, 4>), dim3(1), dim3(1024), 0, h->stream, d, Ab, h->S9scr);
+        hipLaunchKernelGGL(solve9_prod_kernel<2>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
+        hipLaunchKernelGGL(solve9_prod_kernel<3>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
+        hipLaunchKernelGGL(solve9_dx_kernel, dim3(1), dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, NT);
+        return;
     }
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
     case 1: {
@@ -1054,12 +1095,25 @@ static int augment_compose_dev(rvio_hip* h, int do_augment) {
     const int cg = 1 + (h->batch >= 128 ? std::max(1, aug_wgs) : std::max(1, std::min(64, (d.dmax * d.dmax + 255) / 256)));
     unsigned long long* done = nullptr;
     if (h->batch == 1) { done = &h->stage_sync->aug; h->stage_tgt.aug += (unsigned long long)cg; }
+    if (h->chol_async) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->evL, 0)); h->chol_async = false; }   // (a frame without an update: its factor was never consumed)
     hipLaunchKernelGGL(augcomp_kernel2, dim3(cg, 1, h->batch), dim3(256), 0, h->stream, d, h->n_clones_host, do_augment, h->x[c], h->P[c], h->x[o], h->P[o], h->d_pose,
                        h->slab_bytes, done);
     HIPCHK(h, hipGetLastError());
     h->cur = o;
     h->chol_ready = false;   // the clone block has changed (window slide / new clone)
     if (do_augment && h->n_clones_host < d.nmax) h->n_clones_host++;
+    // Long windows (6n > 96, solve in its split form): Pcc = L L^T of the NEXT update is known from here on — propagation leaves the clone block
+    // alone — so the factor starts now on a stream of its own and runs beside propagate, the wait for the tracker and the per-feature stage; the
+    // solve's first product waits for it (launch_solve).  ~35 us at 6n = 120, ~95 us at 6n = 180 off the filter chain.
+    static const bool no_async = ab_env("RVIO_S9_NO_ASYNC") != nullptr;   // A/B timing
+    if (h->solve9_nt >= 8 && h->stream_l && !no_async && !profiler_serialises() && h->n_clones_host >= 1) {
+        HIPCHK(h, hipEventRecord(h->evA, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_l, h->evA, 0));
+        if (h->solve9_nt == 8) hipLaunchKernelGGL((solve9_chol_kernel<2, 4>), dim3(1), dim3(1024), 0, h->stream_l, d, h->n_clones_host, h->P[h->cur], h->S9scr);
+        else hipLaunchKernelGGL((solve9_chol_kernel<3, 4>), dim3(1), dim3(1024), 0, h->stream_l, d, h->n_clones_host, h->P[h->cur], h->S9scr);
+        HIPCHK(h, hipEventRecord(h->evL, h->stream_l));
+        h->chol_async = true;
+    }
     return RVIO_OK;
 }
 int rvio_hip_augment_compose(rvio_hip* h, int do_augment) {
@@ -1073,7 +1127,7 @@ static int detector_check(rvio_hip* h) {
     const int cell1 = (int)std::nearbyint((double)h->cfg.min_dist);
     if (cell1 < 1) { h->err = "Tracker.nMinDist < 1 is not supported by the device detector"; return RVIO_ERR_UNSUPPORTED; }
     const int spw = (int)std::floor(.5 * h->cfg.min_dist);   // cornerSubPix half-window, FeatureDetector.cc:68
-    if (spw < 1 || spw > 15) { h->err = "device cornerSubPix takes half-windows 1..15 (2 <= Tracker.nMinDist < 32)"; return RVIO_ERR_UNSUPPORTED; }
+    if (spw < 1 || spw > 63) { h->err = "device cornerSubPix takes half-windows 1..63 (2 <= Tracker.nMinDist < 128)"; return RVIO_ERR_UNSUPPORTED; }
     return RVIO_OK;
 }
 static int detector_alloc_set(rvio_hip* h, DetDev& q) {   // the scratch of ONE detector in flight
@@ -1104,7 +1158,8 @@ static int detector_alloc(rvio_hip* h) {   // DALLOCs only (runs twice for a sla
     DALLOC(h, h->det_xy2[0], (size_t)2 * d.F); DALLOC(h, h->det_xy2[1], (size_t)2 * d.F); DALLOC(h, h->det_xy2[2], (size_t)2 * d.F);
     DALLOC(h, h->det_nout, 3);
     float* mask = nullptr;
-    DALLOC(h, mask, (size_t)31 * 31);
+    const size_t mside = (size_t)std::max(31, 2 * (int)std::floor(.5 * h->cfg.min_dist) + 1);
+    DALLOC(h, mask, mside * mside);
     for (DetDev* q : {&h->dets[0], &h->dets[1], &h->dets[2]}) { q->xy = h->det_xy2[0]; q->n_out = h->det_nout; q->spmask = mask; q->sp_win = (int)std::floor(.5 * h->cfg.min_dist); }
     return RVIO_OK;
 }
@@ -1124,6 +1179,7 @@ static int detector_init(rvio_hip* h) {
     }
     HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm.data(), sizeof(float) * hm.size(), hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
     HIPCHK(h, hipStreamSynchronize(h->stream));   // (hm is a local)
+    if (spw > 15) HIPCHK(h, hipFuncSetAttribute((const void*)subpix_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)subpix_wide_lds(spw)));
     std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
     for (DetDev* qq : {&h->dets[0], &h->dets[1], &h->dets[2]})
         HIPCHK(h, hipMemcpy2DAsync(qq->maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
@@ -1181,7 +1237,9 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     const unsigned neigh_blocks = nb_env > 0 ? (unsigned)nb_env : (h->wide_px ? NEIGH_BLOCKS_WIDE : NEIGH_BLOCKS);
     hipLaunchKernelGGL(neigh_kernel, dim3(neigh_blocks, 1, B), dim3(NEIGH_T), NEIGH_LDS, ds, q, bs);
     hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, B), dim3(GREEDY_T), GREEDY_LDS, ds, q, bs);
-    if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
+    if (q.sp_win > 15)        // Tracker.nMinDist >= 32: the summation grid no longer fits LDS whole
+        hipLaunchKernelGGL(subpix_wide_kernel, dim3(d.F, 1, B), dim3(SPG_T), subpix_wide_lds(q.sp_win), ds, img, stride, q, src_bs, bs);
+    else if (q.sp_win != SP_WIN)   // a cornerSubPix window other than the stock 7: the plain form
         hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, B), dim3(SPG_T), 0, ds, img, stride, q, src_bs, bs);
     else if (h->wide_px)
         hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
@@ -1922,7 +1980,8 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
             const DetDev q = [&] { DetDev v = h->dets[h->det_set_last]; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
             const uint8_t* im = h->pyr[h->pyr_cur].img[0];   // level 0 of the current pyramid = the image the detector saw
-            if (q.sp_win != SP_WIN) hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, 1), dim3(SPG_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            if (q.sp_win > 15) hipLaunchKernelGGL(subpix_wide_kernel, dim3(d.F, 1, 1), dim3(SPG_T), subpix_wide_lds(q.sp_win), h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
+            else if (q.sp_win != SP_WIN) hipLaunchKernelGGL(subpix_generic_kernel, dim3(d.F, 1, 1), dim3(SPG_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
             else if (h->wide_px) hipLaunchKernelGGL(subpix_kernel16, dim3((d.F + 3) / 4, 1, 1), dim3(64), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes);
             else hipLaunchKernelGGL(subpix_kernel, dim3(d.F, 1, 1), dim3(SP_T), 0, h->stream, im, d.W, q, (size_t)0, h->slab_bytes, 0);
         } else return RVIO_ERR_INVALID;

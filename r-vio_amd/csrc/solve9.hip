@@ -197,7 +197,7 @@ __device__ __forceinline__ void s9_gemm_block(int k0, int k1, s9_d4 (&acc)[BS * 
 // LDS of the Cholesky phase (P0 + P1): static in solve9_kernel, carved out of the launch's dynamic LDS by the role workgroup of feat_prop_kernel
 template <int NT, int NW>
 struct S9CholLds {
-    double rowp[2][NT][S9_TILE];                       // the row panel of a step, by step parity
+    double rowp[2][NT][S9_TILE];                       // [0]: the row panel of a step, [1]: its Z tiles (F times the panel)
     S9Wave ws;                                         // the in-wave primitive runs in wave 0
     double F[2][S9_TILE];                              // its result: F and F^T of the step's diagonal tile
     double tb[NW][16 * 17];                            // per-wave transposition scratch (L from G; Q^T in the solve)
@@ -236,9 +236,13 @@ __device__ __forceinline__ int s9_cholesky(const DevCfg& cfg, int n, const doubl
     DBG_T(31);
 
     // ---- P1: Pcc = L L^T.  Only tiles i <= j are live (the row panel of step k is S(k, j >= k)).
+    // Per step three barriers: panel -> LDS | one wave factors the diagonal tile | every Z_j = F S(k, j) is formed ONCE (wave j - k mod NW) and
+    // published | the updates read their two operands from LDS.  (Each wave forming the Z tiles of its own block row and column itself — 2 BS
+    // products beside BS^2 updates, 2 BS tiles more in registers — spilled at BS = 3 and put 1 MB of scratch traffic into every step.)
+    double (*rowp)[S9_TILE] = sh.rowp[0];
+    double (*zb)[S9_TILE] = sh.rowp[1];
 #pragma unroll 1
     for (int k = 0; k < NT; ++k) {
-        double (*rowp)[S9_TILE] = sh.rowp[k & 1];
         if (wa == k / BS) {
 #pragma unroll
             for (int s = 0; s < TS; ++s) {
@@ -248,38 +252,45 @@ __device__ __forceinline__ int s9_cholesky(const DevCfg& cfg, int n, const doubl
         }
         __syncthreads();
         if (k == 0) DBG_T(40);
-        s9_d4 F, Ft;
         if (wv == 0) {
+            s9_d4 F, Ft;
             s9_factor(s9_lds(rowp[k], lane), sh.ref + 16 * k, 1e-12, &sh.ws, li, lk, F, Ft, bad);
             s9_sts(sh.F[1], lane, Ft);
         }
         __syncthreads();
-        Ft = s9_lds(sh.F[1], lane);
         if (k == 0) DBG_T(41);
-        // G(k, c) = F S(k, c) for the block columns / block rows this wave touches
-        s9_d4 Zr[BS], Zc[BS];
+        {   // G(k, j) = F S(k, j), j >= k
+            const s9_d4 Ft = s9_lds(sh.F[1], lane);
+            for (int j = k + wv; j < NT; j += NW) s9_sts(zb[j], lane, s9_tn(Ft, s9_lds(rowp[j], lane), s9_zero()));
+        }
+        __syncthreads();
+        s9_d4 Zc[BS];
 #pragma unroll
         for (int q = 0; q < BS; ++q) {
-            const int ir = wa * BS + q, jc = wb * BS + q;
-            Zr[q] = (ir > k) ? s9_tn(Ft, s9_lds(rowp[ir], lane), s9_zero()) : s9_zero();
-            Zc[q] = (jc >= k) ? s9_tn(Ft, s9_lds(rowp[jc], lane), s9_zero()) : s9_zero();
+            const int jc = wb * BS + q;
+            Zc[q] = (jc >= k) ? s9_lds(zb[jc], lane) : s9_zero();
         }
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
-            const int i = wa * BS + s / BS, j = wb * BS + s % BS;
-            if (i == k && j >= k) {
-                s9_d4 g = Zc[s % BS];
-                if (j == k) {                          // the diagonal tile of G = Lkk^T: exact zeros below the diagonal
+        for (int qi = 0; qi < BS; ++qi) {
+            const int i = wa * BS + qi;
+            s9_d4 nz = s9_zero();
+            if (i > k) {
+                const s9_d4 zr = s9_lds(zb[i], lane);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (4 * r + lk > li) g[r] = 0.0;
-                }
-                s9_stg(tile(bG, k, j), lane, g);
-                s9_stg(tile(bL, j, k), lane, s9_transpose_tb(g, sh.tb[wv], li, lk));
-            } else if (i > k && j >= i) {
-                s9_d4 nz;
+                for (int r = 0; r < 4; ++r) nz[r] = -zr[r];
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nz[r] = -Zr[s / BS][r];
-                S[s] = s9_tn(nz, Zc[s % BS], S[s]);
+            for (int qj = 0; qj < BS; ++qj) {
+                const int s = qi * BS + qj, j = wb * BS + qj;
+                if (i == k && j >= k) {
+                    s9_d4 g = Zc[qj];
+                    if (j == k) {                          // the diagonal tile of G = Lkk^T: exact zeros below the diagonal
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * r + lk > li) g[r] = 0.0;
+                    }
+                    s9_stg(tile(bG, k, j), lane, g);
+                    s9_stg(tile(bL, j, k), lane, s9_transpose_tb(g, sh.tb[wv], li, lk));
+                } else if (i > k && j >= i) S[s] = s9_tn(nz, Zc[qj], S[s]);
             }
         }
         if (k == 0) DBG_T(42);
@@ -292,11 +303,71 @@ __device__ __forceinline__ int s9_cholesky(const DevCfg& cfg, int n, const doubl
 // The Cholesky phase as a ROLE of another launch (256 threads = 2 x 2 waves): one more workgroup of the per-feature launch (pipelined
 // frame) or of propagate's launch (staged entry points) factors the clone block while that launch does its own work; the verdict goes
 // to the slab's last word.  Same tiles, same order of operations per tile as solve9_kernel's own phase: the same bits.
-#define S9_SLAB_DOUBLES(NT) ((size_t)5 * (NT) * (NT) * S9_TILE + 8)
+#define S9_SLAB_DOUBLES(NT) ((size_t)5 * (NT) * (NT) * S9_TILE + 8 + (size_t)16 * (NT) * (NT))   // five tile buffers, the verdict words, the by-tile-column shares of y (split form)
+#define S9_YP_OFF(NT) ((size_t)5 * (NT) * (NT) * S9_TILE + 8)
 template <int BS>
 __device__ __forceinline__ void s9_chol_role(const DevCfg& cfg, int n, const double* __restrict__ P, double* __restrict__ scr, S9CholLds<2 * BS, 4>& sh) {
     const int bad = s9_cholesky<BS, 2>(cfg, n, P, scr, sh);
     if (threadIdx.x == 0) scr[(size_t)5 * (2 * BS) * (2 * BS) * S9_TILE] = bad ? 1.0 : 0.0;
+}
+
+// The blocked symmetric sweep of the tableau S (wave (a, b) of WGR x WGR holds the BS x BS tiles of block row a, block column b): S ends as -M^-1.
+// Per step k: the row panel S(k, :) goes to LDS, ONE wave factors the diagonal tile (F = chol(S(k, k))^-1), the Z_j = F S(k, j) are formed once
+// each and published, every wave updates its tiles from them.  s_rowp: [2][NT][S9_TILE] (the panel; the Z tiles), s_F: [2][S9_TILE].
+template <int BS, int WGR>
+__device__ __forceinline__ void s9_sweep(s9_d4 (&S)[BS * BS], double (*s_rowp)[WGR * BS][S9_TILE], double (*s_F)[S9_TILE], S9Wave* ws, int& bad) {
+    constexpr int NT = WGR * BS, NW = WGR * WGR;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int wa = wv / WGR, wb = wv % WGR;
+    double (*rowp)[S9_TILE] = s_rowp[0];
+    double (*zb)[S9_TILE] = s_rowp[1];
+#pragma unroll 1
+    for (int k = 0; k < NT; ++k) {
+        if (wa == k / BS) {
+#pragma unroll
+            for (int s = 0; s < BS * BS; ++s) {
+                const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+                if (i == k) s9_sts(rowp[j], lane, S[s]);
+            }
+        }
+        __syncthreads();
+        if (k == 1) DBG_T(43);
+        DBG_T(46 + k);
+        if (wv == 0) {
+            s9_d4 F, Ft;
+            s9_factor(s9_lds(rowp[k], lane), nullptr, 0.0, ws, li, lk, F, Ft, bad);
+            s9_sts(s_F[0], lane, F);
+            s9_sts(s_F[1], lane, Ft);
+        }
+        __syncthreads();
+        if (k == 1) DBG_T(44);
+        {   // Z_j = F S(k, j): each tile once
+            const s9_d4 Ft = s9_lds(s_F[1], lane);
+            for (int j = wv; j < NT; j += NW) s9_sts(zb[j], lane, s9_tn(Ft, s9_lds(rowp[j], lane), s9_zero()));
+        }
+        __syncthreads();
+        s9_d4 Zc[BS];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) Zc[q] = s9_lds(zb[wb * BS + q], lane);
+#pragma unroll
+        for (int qi = 0; qi < BS; ++qi) {
+            const int i = wa * BS + qi;
+            s9_d4 nz = s9_lds(zb[i], lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nz[r] = -nz[r];
+#pragma unroll
+            for (int qj = 0; qj < BS; ++qj) {
+                const int s = qi * BS + qj, j = wb * BS + qj;
+                if (i == k || j == k) {                    // (wave-uniform; F is fetched where it is needed: nothing of it stays in registers)
+                    const s9_d4 F = s9_lds(s_F[0], lane);
+                    const s9_d4 t = (i == k && j == k) ? s9_tn(F, F, s9_zero()) : (i == k) ? s9_tn(F, Zc[qj], s9_zero()) : s9_tn(nz, F, s9_zero());
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[s][r] = (i == k && j != k) ? t[r] : -t[r];   // -F^T F | F^T Z_j | Z_i^T F = -((-Z_i)^T F)
+                } else S[s] = s9_tn(nz, Zc[qj], S[s]);
+            }
+        }
+        if (k == 1) DBG_T(45);
+    }
 }
 
 // BS x BS tiles per wave, WGR x WGR waves: NT = WGR * BS tiles per side.  scr: 5 * NT^2 * 256 (+ 8) doubles per instance.
@@ -393,49 +464,7 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
 
     DBG_T(34);
     // ---- P4: the symmetric sweep; the tableau ends as -M^-1
-#pragma unroll 1
-    for (int k = 0; k < NT; ++k) {
-        double (*rowp)[S9_TILE] = s_rowp[k & 1];
-        if (wa == k / BS) {
-#pragma unroll
-            for (int s = 0; s < TS; ++s) {
-                const int i = wa * BS + s / BS, j = wb * BS + s % BS;
-                if (i == k) s9_sts(rowp[j], lane, S[s]);
-            }
-        }
-        __syncthreads();
-        s9_d4 F, Ft;
-        if (wv == 0) {
-            s9_factor(s9_lds(rowp[k], lane), nullptr, 0.0, ws, li, lk, F, Ft, bad);
-            s9_sts(s_F[0], lane, F);
-            s9_sts(s_F[1], lane, Ft);
-        }
-        __syncthreads();
-        F = s9_lds(s_F[0], lane);
-        Ft = s9_lds(s_F[1], lane);
-        s9_d4 Zr[BS], Zc[BS];
-#pragma unroll
-        for (int q = 0; q < BS; ++q) {
-            Zr[q] = s9_tn(Ft, s9_lds(rowp[wa * BS + q], lane), s9_zero());
-            Zc[q] = s9_tn(Ft, s9_lds(rowp[wb * BS + q], lane), s9_zero());
-        }
-#pragma unroll
-        for (int s = 0; s < TS; ++s) {
-            const int i = wa * BS + s / BS, j = wb * BS + s % BS;
-            if (i == k && j == k) {
-                const s9_d4 dd = s9_tn(F, F, s9_zero());
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[s][r] = -dd[r];
-            } else if (i == k) S[s] = s9_tn(F, Zc[s % BS], s9_zero());          // F^T Z_j
-            else if (j == k) S[s] = s9_tn(Zr[s / BS], F, s9_zero());            // Z_i^T F
-            else {
-                s9_d4 nz;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nz[r] = -Zr[s / BS][r];
-                S[s] = s9_tn(nz, Zc[s % BS], S[s]);
-            }
-        }
-    }
+    s9_sweep<BS, WGR>(S, s_rowp, s_F, ws, bad);
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         const int i = wa * BS + s / BS, j = wb * BS + s % BS;
@@ -501,6 +530,163 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     }
     __syncthreads();
     // ---- state injection (Updater.cc:546-613)
+    const double* dx = s_dx;
+    if (tid == 0) {
+        stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
+        for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
+        st3(x_out + 7, unit3(ld3(x_out + 7)));
+        stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
+        for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
+    }
+    for (int p = tid - 64; p >= 0 && p < n; p += NTH - 64) {
+        stq(x_out + 26 + 7 * p, qmul(small_q(dx[24 + 6 * p], dx[24 + 6 * p + 1], dx[24 + 6 * p + 2]), ldq(x + 26 + 7 * p)));
+        for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[24 + 6 * p + 3 + i] + x[26 + 7 * p + 4 + i];
+    }
+    DBG_T(38);
+    DBG_R(true, 7);
+}
+
+// =============================================================== long windows (NT >= 8: 6n > 96): the phases as launches of their own
+// In ONE workgroup the four product phases (Q = A L, M, X = Mi G, W) are 537 k of the 1.28 M cycles at 6n = 180: 144 output tiles on the four matrix
+// pipes of one CU.  They are plain tile products with no dependence inside a phase: as launches of their own — one wave per output tile, four to a
+// workgroup, 36 workgroups at 6n = 180 — each takes a few microseconds, and the kernel boundary is the only synchronisation the slab needs (plain
+// loads see what an earlier KERNEL wrote).  Same tiles, same k order, same MFMA sequence per tile as solve9_kernel: the same bits.
+//   chol (one workgroup; depends on P only) -> prod<0> Q, Q^T -> prod<1> M -> sweep (one workgroup) -> prod<2> X -> prod<3> W, shares of y -> dx
+template <int BS, int WGR>
+__global__ __launch_bounds__(64 * WGR * WGR) void solve9_chol_kernel(DevCfg cfg, int n, const double* __restrict__ P, double* __restrict__ scr) {
+    constexpr int NT = WGR * BS;
+    __shared__ S9CholLds<NT, WGR * WGR> sh;
+    const int bad = s9_cholesky<BS, WGR>(cfg, n, P, scr, sh);
+    if (threadIdx.x == 0) scr[(size_t)5 * NT * NT * S9_TILE] = bad ? 1.0 : 0.0;
+}
+
+template <int PH>
+__global__ __launch_bounds__(256) void solve9_prod_kernel(DevCfg cfg, int n, const double* __restrict__ Ab, double* __restrict__ scr, double* __restrict__ Wout, int NT) {
+    __shared__ double s_tb[4][16 * 17];
+    const int c6 = 6 * n, ldh = cfg.ldh;
+    if ((int)Ab[(size_t)ldh * (ldh - 1)] <= 2) return;          // pass-through (Updater.cc:460): solve9_dx_kernel writes W = 0
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= NT * NT) return;                                    // (no workgroup barrier below)
+    const int i = t / NT, j = t - i * NT;
+    double* bL = scr;
+    double* bG = scr + (size_t)NT * NT * S9_TILE;
+    double* bQ = scr + (size_t)2 * NT * NT * S9_TILE;
+    double* bQt = scr + (size_t)3 * NT * NT * S9_TILE;
+    double* bMi = scr + (size_t)4 * NT * NT * S9_TILE;
+    auto tile = [&](double* b, int a, int c) { return b + (size_t)(a * NT + c) * S9_TILE; };
+    if constexpr (PH == 0) {                                     // Q(i, j) = sum_{k >= j} A(k, i)^T L(k, j); Q and Q^T
+        auto ld_A = [&](int a, int c) {
+            s9_d4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * a + 4 * r + lk, col = 16 * c + li;
+                v[r] = (row < c6 && col < c6) ? Ab[(size_t)row * ldh + col] : 0.0;
+            }
+            return v;
+        };
+        const s9_d4 acc = s9_gemm(j, NT, [&](int k) { return ld_A(k, i); }, [&](int k) { return s9_ldg(tile(bL, k, j), lane); });
+        s9_stg(tile(bQ, i, j), lane, acc);
+        s9_stg(tile(bQt, j, i), lane, s9_transpose_tb(acc, s_tb[wv], li, lk));
+    } else if constexpr (PH == 1) {                              // M(i, j) = s2 delta + sum_{k >= i} L(k, i)^T Q(k, j)
+        s9_d4 acc = s9_gemm(i, NT, [&](int k) { return s9_ldg(tile(bL, k, i), lane); }, [&](int k) { return s9_ldg(tile(bQ, k, j), lane); });
+        if (i == j) {
+            const double s2 = cfg.sigma_im * cfg.sigma_im;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * r + lk == li) acc[r] += s2;
+        }
+        s9_stg(tile(bMi, i, j), lane, acc);
+    } else if constexpr (PH == 2) {                              // X(i, j) = sum_{k <= j} Mi(k, i)^T G(k, j), over Q's buffer (W reads Q^T)
+        const s9_d4 acc = s9_gemm(0, j + 1, [&](int k) { return s9_ldg(tile(bMi, k, i), lane); }, [&](int k) { return s9_ldg(tile(bG, k, j), lane); });
+        s9_stg(tile(bQ, i, j), lane, acc);
+    } else {                                                     // W(i, j) = (delta - sum_k Qt(k, i)^T X(k, j)) / s2; this tile's share of y = W b
+        const s9_d4 acc = s9_gemm(0, NT, [&](int k) { return s9_ldg(tile(bQt, k, i), lane); }, [&](int k) { return s9_ldg(tile(bQ, k, j), lane); });
+        const double is2 = 1.0 / (cfg.sigma_im * cfg.sigma_im);
+        double* yp = scr + S9_YP_OFF(NT);
+        const int col = 16 * j + li;
+        const double bj = col < c6 ? Ab[(size_t)col * ldh + c6] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * r + lk;
+            const double w = (((row == col) ? 1.0 : 0.0) - acc[r]) * is2;
+            if (row < c6 && col < c6) Wout[(size_t)row * ldh + col] = w;
+            double tt = w * bj;
+            tt += __shfl_xor(tt, 1, 16); tt += __shfl_xor(tt, 2, 16); tt += __shfl_xor(tt, 4, 16); tt += __shfl_xor(tt, 8, 16);
+            if (li == 0) yp[(size_t)j * 16 * NT + row] = tt;
+        }
+    }
+}
+
+template <int BS, int WGR>
+__global__ __launch_bounds__(64 * WGR * WGR) void solve9_sweep_kernel(DevCfg cfg, const double* __restrict__ Ab, double* __restrict__ scr) {
+    constexpr int NT = WGR * BS, TS = BS * BS;
+    __shared__ double s_rowp[2][NT][S9_TILE];
+    __shared__ double s_F[2][S9_TILE];
+    __shared__ S9Wave ws;
+    __shared__ int s_bad;
+    const int ldh = cfg.ldh;
+    if ((int)Ab[(size_t)ldh * (ldh - 1)] <= 2) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wv / WGR, wb = wv % WGR;
+    double* bMi = scr + (size_t)4 * NT * NT * S9_TILE;
+    DBG_T(34);
+    if (tid == 0) s_bad = 0;
+    s9_d4 S[TS];
+#pragma unroll
+    for (int s = 0; s < TS; ++s) S[s] = s9_ldg(bMi + (size_t)((wa * BS + s / BS) * NT + wb * BS + s % BS) * S9_TILE, lane);
+    int bad = 0;
+    s9_sweep<BS, WGR>(S, s_rowp, s_F, &ws, bad);
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        s9_d4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = -S[s][r];
+        s9_stg(bMi + (size_t)((wa * BS + s / BS) * NT + wb * BS + s % BS) * S9_TILE, lane, v);
+    }
+    if (bad) atomicOr(&s_bad, 1);
+    __syncthreads();
+    if (tid == 0) scr[(size_t)5 * NT * NT * S9_TILE + 1] = s_bad ? 1.0 : 0.0;
+    DBG_T(35);
+}
+
+// y = sum of the shares, dx = K r = Pc y (Updater.cc:544), state injection (Updater.cc:546-613); the pass-through of an update without rows
+__global__ __launch_bounds__(1024) void solve9_dx_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab, const double* __restrict__ x,
+                                                         const double* __restrict__ P, const double* __restrict__ scr, double* __restrict__ Wout,
+                                                         double* __restrict__ x_out, int NT) {
+    constexpr int NTH = 1024;
+    __shared__ double s_y[16 * 12];
+    __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
+    __shared__ double s_part[4 * (24 + 6 * RVIO_MAX_LEN)];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, xd = 26 + 7 * n, NP = 16 * NT;
+    const int tid = threadIdx.x;
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    DBG_R(true, 2);
+    if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; }
+    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
+        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        return;
+    }
+    DBG_T(37);
+    const double* yp = scr + S9_YP_OFF(NT);
+    if (tid == 0 && (scr[(size_t)5 * NT * NT * S9_TILE] != 0.0 || scr[(size_t)5 * NT * NT * S9_TILE + 1] != 0.0)) atomicOr(&meta->err, 1);
+    for (int i = tid; i < NP; i += NTH) { double acc = yp[i]; for (int j = 1; j < NT; ++j) acc += yp[(size_t)j * NP + i]; s_y[i] = acc; }
+    __syncthreads();
+    {
+        const int np = max(1, min(4, NTH / d)), share = (c6 + np - 1) / np;
+        const int pt = tid / d, i = tid - pt * d;
+        if (pt < np) {
+            double acc = 0;
+            const int k1 = min(c6, (pt + 1) * share);
+#pragma unroll 8
+            for (int k = pt * share; k < k1; ++k) acc += P[(size_t)i + (size_t)(24 + k) * ld] * s_y[k];
+            s_part[pt * d + i] = acc;
+        }
+        __syncthreads();
+        if (tid < d) { double acc = s_part[tid]; for (int q = 1; q < np; ++q) acc += s_part[q * d + tid]; s_dx[tid] = acc; }
+    }
+    __syncthreads();
     const double* dx = s_dx;
     if (tid == 0) {
         stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));

@@ -49,4 +49,7 @@ for name in names:
         nm = ["P0 load", "P1 chol", "P2 Q", "P3 M", "P4 sweep", "P5 X", "P6 W+y", "dx+inject"]
         print("   phases (cycles): " + "  ".join("%s %d" % (nm[i], t[ph[i + 1]] - t[ph[i]]) for i in range(8)) + "  total %d" % (t[38] - t[30]))
         print("   first Cholesky step: factor %d, panel + trailing %d" % (t[41] - t[40], t[42] - t[41]))
+        print("   second sweep step: factor + barrier %d, Z + trailing %d; sweep launch (34 -> 35) %d; dx launch (37 -> 38) %d   [the split form stamps per launch: only differences inside one launch mean anything]"
+              % (t[44] - t[43], t[45] - t[44], t[35] - t[34], t[38] - t[37]))
+        print("   sweep steps (start to start): " + " ".join("%d" % (t[47 + k] - t[46 + k]) for k in range(11) if t[47 + k] > 0) + "; launch start -> first step %d" % (t[46] - t[34]))
     h.close()
