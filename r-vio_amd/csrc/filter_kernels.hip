@@ -1345,6 +1345,140 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
     }
 }
 
+// =============================================================== one instance, 6n > 64: U, G, P1 and the Joseph form with one wave per TILE
+// ug_kernel gives a 16-row strip of all three products to ONE workgroup (13 workgroups at 6n = 180, each walking ~120 tile products with cold operands:
+// 78 us) and final_kernel both tiles and both sums of a tile pair to one wave (28 us).  A single instance has the whole chip to itself: here every
+// output TILE of U, of G and of P1 is a wave of its own (three launches: each needs the one before complete), and a tile pair of P+ is a workgroup whose
+// four waves take (X_IJ, X_JI) x (P1c G^T, G U^T).  Operands, the order of the MFMAs of a tile and the closing expressions are ug_kernel's /
+// final_kernel's: the same bits.
+template <int PH>
+__global__ __launch_bounds__(256) void ug_tile_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W, const double* __restrict__ Ab,
+                                                      double* __restrict__ U, double* __restrict__ G, double* __restrict__ P1) {
+    __shared__ double tl[4][16][17];
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
+    const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int nj = PH == 2 ? dt : c6t;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= dt * nj) return;                                  // (wave-private LDS only: no workgroup barrier below)
+    const int it = t / nj, jt = t - it * nj;
+    const int i0 = it * 16, ai = i0 + li, bj = jt * 16 + li;
+    const bool aok = ai < d, bok = bj < (PH == 2 ? d : c6);
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < c6; k0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const bool kok = k < c6;
+            if constexpr (PH == 0) {                           // U = Pc W
+                a[u] = (aok && kok) ? P[(size_t)ai + (size_t)(24 + k) * ld] : 0.0;
+                b[u] = (bok && kok) ? W[(size_t)k * ldh + bj] : 0.0;
+            } else if constexpr (PH == 1) {                    // G = U A  (U k-major: U[k ld + i])
+                a[u] = (aok && kok) ? U[(size_t)k * ld + ai] : 0.0;
+                b[u] = (bok && kok) ? Ab[(size_t)k * ldh + bj] : 0.0;
+            } else {                                           // G Pc^T
+                a[u] = (aok && kok) ? G[(size_t)k * ld + ai] : 0.0;
+                b[u] = (bok && kok) ? P[(size_t)bj + (size_t)(24 + k) * ld] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if constexpr (PH == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + lk + 4 * r;
+            if (row < d && bj < d) P1[(size_t)row + (size_t)bj * ld] = P[(size_t)row + (size_t)bj * ld] - acc[r];
+        }
+    } else {                                                   // k-major store (see ug_kernel): 16 consecutive rows of one k are one 128-byte segment
+        double* out = PH == 0 ? U : G;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl[wave][lk + 4 * r][li] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = jt * 16 + lk + 4 * r, row = i0 + li;  // element (row, kk) = tile (li, lk + 4 r)
+            if (kk < c6 && row < d) out[(size_t)kk * ld + row] = tl[wave][li][lk + 4 * r];
+        }
+    }
+}
+
+// one workgroup per unordered tile pair (I <= J) of P+; wave w: tile (w & 2 ? (J, I) : (I, J)), sum (w & 1 ? G U^T : P1c G^T)
+__global__ __launch_bounds__(256) void final_tile_kernel(DevCfg cfg, int n, const double* __restrict__ P1, const double* __restrict__ G, const double* __restrict__ U,
+                                                         double* __restrict__ Pout) {
+    __shared__ double s2acc[2][4][64];                          // the G U^T sums of the two tiles, in accumulator layout
+    __shared__ double tl[16][17];
+    const int c6 = 6 * n, d = 24 + c6, ld = cfg.dmax;
+    const double s2 = cfg.sigma_im * cfg.sigma_im;
+    const int nt = (d + 15) / 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    int I = 0, rem = blockIdx.x;
+    while (rem >= nt - I) { rem -= nt - I; ++I; }
+    const int J = I + rem;
+    const int second = wave >> 1, which = wave & 1;
+    const bool live = !(second && I == J);
+    const int i0 = (second ? J : I) * 16, j0 = (second ? I : J) * 16;
+    const int ai = i0 + li, bj = j0 + li;
+    const bool aok = ai < d, bok = bj < d;
+    d4 acc = {0, 0, 0, 0};
+    if (live) {
+        for (int k0 = 0; k0 < c6; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk;
+                const bool kok = k < c6;
+                if (which == 0) {
+                    a[u] = (aok && kok) ? P1[(size_t)ai + (size_t)(24 + k) * ld] : 0.0;   // P1c[i][k]
+                    b[u] = (bok && kok) ? G[(size_t)k * ld + bj] : 0.0;                   // G[j][k]
+                } else {
+                    a[u] = (aok && kok) ? G[(size_t)k * ld + ai] : 0.0;                   // G[i][k]
+                    b[u] = (bok && kok) ? U[(size_t)k * ld + bj] : 0.0;                   // U[j][k]
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+        if (which == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s2acc[second][r][lane] = acc[r];
+        }
+    }
+    __syncthreads();
+    d4 out = {0, 0, 0, 0};
+    if (live && which == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + lk + 4 * r;
+            const double p1 = (row < d && bj < d) ? P1[(size_t)row + (size_t)bj * ld] : 0.0;
+            const double acc2 = s2acc[second][r][lane];
+            out[r] = p1 - acc[r] + s2 * acc2;
+        }
+        if (second) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tl[lk + 4 * r][li] = out[r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (I == J) {                                          // X_JI = X_IJ: the transpose is this wave's own tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tl[lk + 4 * r][li] = out[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = lk + 4 * r, row = I * 16 + rr, col = J * 16 + li;
+            const double v = .5 * (out[r] + tl[li][rr]);       // X_JI[col_local][row_local]
+            if (row < d && col < d) {
+                Pout[(size_t)row + (size_t)col * ld] = v;
+                if (I != J) Pout[(size_t)col + (size_t)row * ld] = v;
+            }
+        }
+    }
+}
+
 // =============================================================== batch handles, 6n <= 60: U, G, P1 and the Joseph form in ONE kernel
 // ug_kernel + final_kernel move P1, U and G through HBM / L2 between them and fetch every MFMA operand from global memory inside the k-loop (at B = 2048:
 // 0.55 ms of the 1.94 ms batched frame for 125 us of matrix-core work).  Here ONE workgroup of JB_WAVES waves owns an instance from P to P+: W (then A), Pc,

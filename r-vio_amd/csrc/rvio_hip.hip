@@ -1000,6 +1000,14 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
         if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
         if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);
+    } else if (B == 1 && !ab_env("RVIO_NO_UG_TILE")) {   // one instance, 6n > 64: one wave per output tile, the chip is this instance's alone
+        const int c6t = (c6 + 15) / 16;
+        if (ug) {
+            hipLaunchKernelGGL(ug_tile_kernel<0>, dim3((nt * c6t + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+            hipLaunchKernelGGL(ug_tile_kernel<1>, dim3((nt * c6t + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+            hipLaunchKernelGGL(ug_tile_kernel<2>, dim3((nt * nt + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+        }
+        if (fin) hipLaunchKernelGGL(final_tile_kernel, dim3(npair), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn);
     } else {
         if (ug) hipLaunchKernelGGL(ug_kernel, dim3((dd + 15) / 16, 1, B), dim3(256), h->ug_lds, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, bs);
         if (fin) hipLaunchKernelGGL(final_kernel, dim3((npair + 3) / 4, 1, B), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn, bs);
