@@ -572,7 +572,9 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     t_klt = h.time_kernel(1, 50) * 1e-6
     t_feat = h.time_kernel(2, 50) * 1e-6
     t_subpix = h.time_kernel(6, 50) * 1e-6
-    solve_name = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel"   # (rvio_hip.hip: the blocked SPD solve; at 6n <= 64 behind the Cholesky role its all-LDS form)
+    # (rvio_hip.hip: the blocked SPD solve; at 6n <= 64 behind the Cholesky role its all-LDS form; at 6n > 96 its split form — six launches)
+    solve_name = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel" if c6 <= 96 else "solve9_prod_kernel<0..3> + solve9_sweep_kernel + solve9_dx_kernel"
+    solve_match = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel" if c6 <= 96 else "solve9_sweep_kernel"
     # solve: T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T (c6 = 6n columns, register tableau).  Algorithmic
     # FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8)
     fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
@@ -586,17 +588,19 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10: template + it_l bilinear windows per level
     by_subpix = F * (4.0 * 17 * 17) * 5                          # cornerSubPix: a 17x17 float window re-sampled per iteration, ~5 iterations per corner
     cands = [
-        {"bound": "mfma", "kernel": "%s (W = (s2 I + A Pcc)^-1, dx, state injection; one workgroup)" % solve_name, "match": solve_name, "launched_by_timed_path": solve_name,
+        {"bound": "mfma", "kernel": "%s (W = (s2 I + A Pcc)^-1, dx, state injection%s)" % (solve_name, "; one workgroup" if c6 <= 96 else "; avg_us = the six launches together"),
+         "match": solve_match, "launched_by_timed_path": solve_name,
          "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_solve * 1e6,
-         "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles, one workgroup on ONE CU (0.31 TFLOP/s of the chip's %.1f); the Cholesky of the clone "
-                 "block rides in the per-feature launch at 6n <= 96; latency bound: %d 16 x 16 in-wave factorisations in sequence; algorithmic work = that of the LU inverse"
+         "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles; 6n <= 96: one workgroup on ONE CU (0.31 TFLOP/s of the chip's %.1f), the Cholesky of the "
+                 "clone block rides in the per-feature launch; 6n > 96: the four product phases are chip-wide launches, the sweep one workgroup, the Cholesky factor runs beside the "
+                 "filter chain on a queue of its own; latency bound: %d 16 x 16 in-wave factorisations in sequence; algorithmic work = that of the LU inverse"
                  % (PEAK_F64, (c6 + 15) // 16)},
         {"bound": "hbm", "kernel": "klt_kernel3 (4-level pyramidal LK, one wave per feature)", "match": "klt_kernel3", "launched_by_timed_path": "klt_kernel3 (forward match)",
          "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_klt * 1e6,
          "note": "timed matching the current image back onto the previous one from the current feature positions (the forward match's displacements, "
                  "reversed): the frame's own inputs are gone once book-keeping has moved the features"},
         {"bound": "mfma", "kernel": "the per-feature workgroups of feat_prop_kernel (U1-U5, FP64 MFMA gate; %d features handed over by the last frame)" % len(ln_l), "match": "feat_",
-         "launched_by_timed_path": "feat_prop_kernel<CH>: these workgroups + propagate as one more workgroup of the same launch; timed here as feat_build_kernel<16> = the same "
+         "launched_by_timed_path": "feat_prop_kernel: these workgroups + propagate as one more workgroup of the same launch; timed here as feat_build_kernel<16> = the same "
                                    "workgroups in a launch of their own (propagate mutates P in place and cannot be repeated)",
          "achieved": (fl_feat / t_feat / 1e12) if fl_feat > 0 else None, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_feat * 1e6},
     ]

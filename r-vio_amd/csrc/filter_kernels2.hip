@@ -25,21 +25,39 @@ __device__ __forceinline__ double skew_e(const double* v, int i, int j) {
 //     P <- Psi_c P Psi_c^T + sum_s S_s Q_s S_s^T  (rounds 1-3: sample by sample, four barriers each)
 struct Prop3Sample { double dR[9], up[3], uv[3], w[3], dt, Rk[9], vk[3], gk[3]; };
 
+// propagate's LDS: static in the kernels of their own, carved out of the launch's DYNAMIC LDS by the propagate workgroup of feat_prop_kernel (that
+// workgroup builds no feature: the per-feature footprint is idle in it — so the fused launch needs max(per-feature, propagate), not the sum,
+// and fits every window with the 16-sample chunk)
+template <int PROP3_CH>
+struct Prop3Lds {
+    double Pl[24][25];
+    double Psi[24][25];
+    double PhiSx[2][PROP3_CH][9][25];       // (one array: the clone-column update at the end stages its columns in it)
+    double PsiC[9][25];                     // rows 9..17 of the chunk's Psi_c = S_0 Phi_0
+    double Nq[PROP3_CH][9][6];              // S_s[9..17, (theta, v)] Qd_s
+    double Qd[PROP3_CH][6][6];              // the dense (theta, v) block of Q_s
+    double vxs[PROP3_CH][9];
+    Prop3Sample sm[PROP3_CH];
+    double xs[26];
+    double chain[9 + 3 * 5 + 1];            // the serial chain's state between the chunks' phase B
+};
+
 template <int PROP3_CH = 16>     // samples composed per chunk: 16 for one stream (one chunk at 200 Hz / 20 Hz), 8 for batch handles (47 instead of 86 KB of LDS: two workgroups per CU)
 __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
-                                               double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
+                                               double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs, Prop3Lds<PROP3_CH>& L) {
     meta = zoff(meta, bs); x = zoff(x, bs); P = zoff(P, bs); imu = zoff(imu, imu_bs);
-    __shared__ double Pl[24][25];
-    __shared__ double Psi[24][25];
-    __shared__ double PhiSx[2][PROP3_CH][9][25];   // (one array: the clone-column update at the end stages its columns in it)
+    auto& Pl = L.Pl;
+    auto& Psi = L.Psi;
+    auto& PhiSx = L.PhiSx;
     double (*Phi9)[9][25] = PhiSx[0];
     double (*Sx)[9][25] = PhiSx[1];             // rows 9..17 of the suffix products S_s = Phi_{mc-1} ... Phi_{s+1}
-    __shared__ double PsiC[9][25];              // ... and of the chunk's Psi_c = S_0 Phi_0
-    __shared__ double Nq[PROP3_CH][9][6];       // S_s[9..17, (theta, v)] Qd_s
-    __shared__ double Qd[PROP3_CH][6][6];       // the dense (theta, v) block of Q_s
-    __shared__ double vxs[PROP3_CH][9];
-    __shared__ Prop3Sample sm[PROP3_CH];
-    __shared__ double xs[26];
+    auto& PsiC = L.PsiC;
+    auto& Nq = L.Nq;
+    auto& Qd = L.Qd;
+    auto& vxs = L.vxs;
+    auto& sm = L.sm;
+    auto& xs = L.xs;
+    auto& chain = L.chain;
     const int tid = threadIdx.x;
     const int ld = cfg.dmax;
     if (tid == 0) { meta->n_good = 0; meta->n_rows = 0; meta->updated = 0; meta->trunc_at = -1; }
@@ -56,7 +74,6 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
     const d3 gR = ld3(xs + 7), vR = ld3(xs + 17);
     // the serial chain's state (Rk, dp, dv, pk, vk, gk, Dt) lives in LDS BETWEEN the chunks' phase B: held in registers across the whole kernel it
     // was 66 VGPRs of pressure on every other phase (the two-workgroups-per-CU form of batch handles spilled 916 B of scratch)
-    __shared__ double chain[9 + 3 * 5 + 1];
     if (tid == 0) {
         const m33 R0 = q2r(ldq(xs + 10));
 #pragma unroll
@@ -290,18 +307,12 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
 
 __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                          double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
-    propagate_body(cfg, meta, n, x, P, imu, m, bs, imu_bs);
-}
-// the same with 8-sample chunks: the standalone propagate of a handle whose FUSED per-feature + propagate launch runs with CH = 8 (long
-// windows: the per-feature stage needs the LDS) — one chunk size per handle, so frame_dev (fused) and frame_begin_dev / the sharded path
-// (unfused) give the same last bits (the composed-chunk form re-associates PreIntegrator.cc's per-sample recursion: DESIGN.md section 3 item 5)
-__global__ __launch_bounds__(256) void propagate_kernel3c(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
-                                                          double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
-    propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+    __shared__ Prop3Lds<16> L;
+    propagate_body<16>(cfg, meta, n, x, P, imu, m, bs, imu_bs, L);
 }
 // propagate with the Cholesky role of solve9 as a second workgroup (plain handle, 6n <= 96; staged entry points: rvio_hip_propagate[_dev],
 // rvio_hip_frame_begin_dev): propagation rewrites the IMU block and the cross terms of P, the role reads the clone block only
-template <int CH, int BS>
+template <int BS>
 __global__ __launch_bounds__(256) void propagate_chol_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                              double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, double* __restrict__ chol_scr) {
     if (blockIdx.x == 1) {
@@ -309,12 +320,14 @@ __global__ __launch_bounds__(256) void propagate_chol_kernel(DevCfg cfg, FilterM
         s9_chol_role<BS>(cfg, n, P, chol_scr, sh);
         return;
     }
-    propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0);
+    __shared__ Prop3Lds<16> L;
+    propagate_body<16>(cfg, meta, n, x, P, imu, m, 0, 0, L);
 }
 // batch handles: two workgroups per CU (256 VGPRs, part of the working set in scratch) — throughput, not latency
 __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
                                                              double* __restrict__ P, const rvio_imu* __restrict__ imu, int m, size_t bs, size_t imu_bs) {
-    propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs);
+    __shared__ Prop3Lds<8> L;
+    propagate_body<8>(cfg, meta, n, x, P, imu, m, bs, imu_bs, L);
 }
 
 // PreIntegrator::propagate and the per-feature stage of Updater::update in ONE launch (single instance, pipelined whole-frame path):
@@ -323,16 +336,15 @@ __global__ __launch_bounds__(256, 2) void propagate_kernel3b(DevCfg cfg, FilterM
 // feat_build_kernel (256 threads).  Takes propagate's ~30 us off the filter stream's serial chain.
 // chol_scr != NULL (round 5, solve9.hip at 6n <= 96): one more workgroup factors the clone block Pcc = L L^T into the solve's tile slab —
 // the measurement-independent part of the solve, off the filter chain (its LDS: the launch's dynamic LDS, idle in that workgroup).
-template <int CH>      // propagate's chunk size (its LDS: 86 KB at 16, 47 KB at 8 — long windows need the room for the per-feature stage)
 __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, double* x, double* P,
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
                                                         FilterMeta* meta, const rvio_imu* imu, int m, double* chol_scr, int chol_nt) {
     DBG_R(blockIdx.x == 0, 0);
-    if (blockIdx.x == gridDim.x - 1) { propagate_body<CH>(cfg, meta, n, x, P, imu, m, 0, 0); return; }
+    extern __shared__ __align__(16) double fp_dyn[];
+    if (blockIdx.x == gridDim.x - 1) { propagate_body<16>(cfg, meta, n, x, P, imu, m, 0, 0, *reinterpret_cast<Prop3Lds<16>*>(fp_dyn)); return; }   // (its LDS: the launch's dynamic LDS)
     if (chol_scr && blockIdx.x == gridDim.x - 2) {
-        extern __shared__ __align__(16) double fp_dyn[];
         if (chol_nt == 4) s9_chol_role<2>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<4, 4>*>(fp_dyn));
         else s9_chol_role<3>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<6, 4>*>(fp_dyn));
         return;

@@ -150,7 +150,6 @@ struct rvio_hip {
     const rvio_imu* fuse_imu = nullptr;   // whole-frame path: propagate of this frame rides in the per-feature launch (feat_prop_kernel)
     int fuse_m = -1;                      // >= 0 while such a propagate is pending
     bool fuse_ok = false;
-    int fuse_ch = 0;                      // propagate's chunk size inside the fused launch (16 or 8: what fits beside the per-feature stage's LDS)
     bool one_stream = false;
     bool wide_px = false;            // throughput forms of the image kernels (several pixels per thread): batch handles of >= 8 instances
     bool front_end = true;           // a batch handle may carry the filter only
@@ -529,22 +528,15 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
         HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
     }
-    // propagate rides in the per-feature launch when both fit one CU's LDS: the dynamic per-feature footprint + the kernel's static LDS
-    // (propagate's composed-chunk buffers: 86 KB at 16 samples per chunk, 47 KB at 8)
+    // propagate rides in the per-feature launch: its workgroup builds no feature, so its buffers (Prop3Lds<16>, 86 KB) and the per-feature footprint
+    // share the launch's dynamic LDS — max of the two, which fits one CU for every window (rounds 2-4: static + dynamic, the SUM: long windows
+    // fell back to 8-sample chunks, cfg E to a propagate launch of its own on the chain)
     h->fprop_lds = h->feat_lds;
-    // (round 5: + the Cholesky role of solve9 at 6n <= 96 — one more workgroup whose buffers live in the launch's dynamic LDS)
+    // (round 5: + the Cholesky role of solve9 at 6n <= 96 — one more workgroup whose buffers live in the launch's dynamic LDS too)
     if (batch == 1 && c6m <= 96) h->fprop_lds = std::max(h->fprop_lds, c6m <= 64 ? sizeof(S9CholLds<4, 4>) : sizeof(S9CholLds<6, 4>));
-    h->fuse_ch = 0;
-    if (batch == 1 && !ab_env("RVIO_NO_FUSED_PROPAGATE")) {
-        hipFuncAttributes a16, a8;
-        HIPCHK(h, hipFuncGetAttributes(&a16, (const void*)feat_prop_kernel<16>));
-        HIPCHK(h, hipFuncGetAttributes(&a8, (const void*)feat_prop_kernel<8>));
-        if (h->fprop_lds + a16.sharedSizeBytes <= 160 * 1024) h->fuse_ch = 16;
-        else if (h->fprop_lds + a8.sharedSizeBytes <= 160 * 1024) h->fuse_ch = 8;
-    }
-    h->fuse_ok = h->fuse_ch != 0;
-    if (h->fuse_ch == 16) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
-    if (h->fuse_ch == 8) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
+    h->fprop_lds = std::max(h->fprop_lds, sizeof(Prop3Lds<16>));
+    h->fuse_ok = batch == 1 && !ab_env("RVIO_NO_FUSED_PROPAGATE") && h->fprop_lds <= 160 * 1024;
+    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
     h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
     HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
     {
@@ -803,20 +795,12 @@ static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_b
                            h->slab_bytes, imu_bs);
     else if (h->batch == 1 && h->solve9_nt && h->solve9_nt <= 6 && h->n_clones_host >= 1 && !imu_bs) {
         // plain handle, 6n <= 96: the Cholesky role of the solve (solve9.hip) as a second workgroup — the clone block it factors is the one the update
-        // behind this propagate will see (propagation does not touch it); one chunk size per handle (the fused launch's)
+        // behind this propagate will see (propagation does not touch it)
         const int nc = h->n_clones_host;
-        if (h->solve9_nt == 4) {
-            if (h->fuse_ch == 8) hipLaunchKernelGGL((propagate_chol_kernel<8, 2>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
-            else hipLaunchKernelGGL((propagate_chol_kernel<16, 2>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
-        } else {
-            if (h->fuse_ch == 8) hipLaunchKernelGGL((propagate_chol_kernel<8, 3>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
-            else hipLaunchKernelGGL((propagate_chol_kernel<16, 3>), dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
-        }
+        if (h->solve9_nt == 4) hipLaunchKernelGGL(propagate_chol_kernel<2>, dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
+        else hipLaunchKernelGGL(propagate_chol_kernel<3>, dim3(2), dim3(256), 0, st, h->dc, h->meta, nc, h->x[h->cur], h->P[h->cur], d_imu, m, h->S9scr);
         h->chol_ready = true;
     }
-    else if (h->fuse_ch == 8)   // one chunk size per handle: the fused launch of this handle composes 8 samples at a time
-        hipLaunchKernelGGL(propagate_kernel3c, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
-                           h->slab_bytes, imu_bs);
     else
     hipLaunchKernelGGL(propagate_kernel3, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                        h->slab_bytes, imu_bs);
@@ -871,14 +855,9 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
         const bool chol = h->solve9_nt && h->solve9_nt <= 6 && n >= 1;
         double* cs = chol ? h->S9scr : (double*)nullptr;
         const int extra = 1 + (chol ? 1 : 0);
-        if (h->fuse_ch == 16)
-            hipLaunchKernelGGL(feat_prop_kernel<16>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
-        else
-            hipLaunchKernelGGL(feat_prop_kernel<8>, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
-                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                               h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
+        hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                           h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                           h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
         h->chol_ready = chol;
         h->fuse_m = -1;
     } else
@@ -1957,7 +1936,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int it = 0; it < iters; ++it) {
         if (which == 0) {
-            h->chol_ready = h->solve9_nt && h->solve9_nt <= 6 && !ab_env("RVIO_S9_FULL");   // (time what the chain sees: the Cholesky role rides in the per-feature launch; the slab holds a factor from the last update)
+            h->chol_ready = h->solve9_nt && (h->solve9_nt <= 6 || h->stream_l) && !ab_env("RVIO_S9_FULL");   // (time what the chain sees: the Cholesky factor rides in the per-feature launch / runs on its own queue; the slab holds the factor of the last update)
             launch_solve(h, n, h->block);
         } else if (which == 1) {
             // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT
