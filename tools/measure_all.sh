@@ -24,6 +24,11 @@ python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/kernel_s
 # kernel trace of the plain single-stream loop only (no secondary legs): the per-frame kernels
 eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --steps 200 --warmup 40 --no-cpu --no-streams --no-latency --batch "''" --batch-streams "''" > /dev/null 2>&1
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/kernel_stats_stream.md > /dev/null; rm -rf $OUT/kt
+# the per-frame kernels of the long-window configurations (the split solve, the tile-parallel Joseph kernels, the Cholesky factor on its own queue)
+for C in ${KT_CONFIGS:-}; do
+  eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --config $C --steps 100 --warmup 20 --no-cpu --no-streams --no-latency --batch "''" --batch-streams "''" > /dev/null 2>&1
+  python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/kernel_stats_stream_cfg$C.md > /dev/null; rm -rf $OUT/kt
+done
 # batched filter at B = 2048
 eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt -o k -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --no-defined-load --batch-streams "''" > /dev/null 2>&1
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/batched_kernel_stats.md --grid-z 2048 > /dev/null; rm -rf $OUT/kt
