@@ -191,6 +191,35 @@ def test_stock_settings_file_window_under_every_pacing(gpu_required, stock_a, ki
     assert same_bits(r, ref), first_diff(r, ref)
 
 
+@pytest.fixture(scope="module")
+def stock_c():
+    """cfg C (400 features, 20-clone window, 6n = 120): the LONG-window form of the frame — the solve in its split form (six launches), the
+    Cholesky factor of the next update's clone block on the queue the second image chain holds at the short windows (ordered by two events:
+    augment / compose -> factor -> the solve's first product), the Joseph stage one wave per tile — 60 frames, window full after 21"""
+    cfg, seq, imgs, imus = stock("C", 60)
+    init = seq.init_from_static(K0)
+    s = O.System(cfg)
+    s.set_state(*O.initialize(cfg, *init))
+    for img, imu in zip(imgs, imus):
+        s.frame(imu, None, img=img)
+    d = dict(cfg=cfg, init=init, imgs=imgs, imus=imus, x=s.get_state()[0], pts=s.tracker().get_points()[0])
+    d["ref"] = run_hip(d, "host", True, sync_every=True)
+    return d
+
+
+@pytest.mark.parametrize("kind", ["flat", "stall1", "stall2", "stall3", "stall4", "noise256", "noise1024+stall"])
+def test_long_window_under_every_pacing(gpu_required, stock_c, kind):
+    """cfg C: the synchronised run tracks the literal oracle (<= 1e-6, bit-exact feature list); flat out, with stalled queues (the factor's queue
+    among them: the solve then waits for its event, a late augment / compose holds the factor back) and on a loaded chip the results are
+    the synchronised run's, bit for bit"""
+    ref = stock_c["ref"]
+    assert np.array_equal(ref["pts"], stock_c["pts"]) and S.state_delta(ref["x"], stock_c["x"]) <= 1e-6
+    kw = {"flat": {}, "stall1": dict(stalls=1), "stall2": dict(stalls=2), "stall3": dict(stalls=3), "stall4": dict(stalls=7), "noise256": dict(noise=(256, 1500, 6)),
+          "noise1024+stall": dict(noise=(1024, 3000, 10), stalls=4)}[kind]
+    r = run_hip(stock_c, "host", True, **kw)
+    assert same_bits(r, ref), first_diff(r, ref)
+
+
 @pytest.mark.parametrize("mode", ["host", "dev"])
 def test_queues_descheduled_for_milliseconds(gpu_required, stock_b, sync_ref, mode):
     """An oversubscribed GPU (other tenants hold hardware queue slots) time-slices the handle's four queues with a quantum of milliseconds: one
