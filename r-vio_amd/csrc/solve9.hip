@@ -176,7 +176,11 @@ __device__ __forceinline__ s9_d4 s9_gemm(int k0, int k1, FX fx, FY fy) {
 }
 
 // A wave's BS x BS block of a product: per k the BS y-tiles are loaded once and each x-tile once (2 BS tile loads for BS^2 products —
-// a single CU takes 64 B per clock from its L1: at 12 tiles per side the tile-at-a-time loop above is bound by exactly that)
+// a single CU takes 64 B per clock from its L1: at 12 tiles per side the tile-at-a-time loop above is bound by exactly that).
+// The phases of the one-workgroup kernel are MATRIX-PIPE bound: gfx950 issues one v_mfma_f64_16x16x4 per SIMD every 64 cycles (78.6 TFLOP/s over 256 x 4 SIMDs
+// = 32 flop per clock each), i.e. 256 cycles per tile product — a k step of 4 products per wave, 2-3 waves to a SIMD, is 2-3 k cycles of pipe time, which is what the
+// stamps show (2.7-4.7 k per step at 6n = 84).  Measured and NOT adopted there (round 5): the operands of step k + 1 in flight while step k multiplies (64.4
+// against 61.5 us), the loads of two / three steps issued together (62.2 us / spills) — the loads were never the bound
 template <int BS, class FX, class FY, class FOK>
 __device__ __forceinline__ void s9_gemm_block(int k0, int k1, s9_d4 (&acc)[BS * BS], FX fx, FY fy, FOK ok) {
 #pragma unroll 1
@@ -314,6 +318,10 @@ __device__ __forceinline__ void s9_chol_role(const DevCfg& cfg, int n, const dou
 // The blocked symmetric sweep of the tableau S (wave (a, b) of WGR x WGR holds the BS x BS tiles of block row a, block column b): S ends as -M^-1.
 // Per step k: the row panel S(k, :) goes to LDS, ONE wave factors the diagonal tile (F = chol(S(k, k))^-1), the Z_j = F S(k, j) are formed once
 // each and published, every wave updates its tiles from them.  s_rowp: [2][NT][S9_TILE] (the panel; the Z tiles), s_F: [2][S9_TILE].
+// Measured and NOT adopted (round 5): LOOK-AHEAD of the factor — block row k + 1 updated first and published, wave 0 factoring its diagonal tile beside
+// the other waves' trailing update: 20.8 k cycles per step at 6n = 180 against 18 k (10.5 / 10.3 k at 120, 9.4 / 8.8 k at 84).  The factor wave shares its
+// matrix pipe with three updating waves (its eight dependent MFMAs queue behind theirs) and still has its own tiles to update afterwards: the step ends
+// with that tail.  It would take a wave that owns no tiles.
 template <int BS, int WGR>
 __device__ __forceinline__ void s9_sweep(s9_d4 (&S)[BS * BS], double (*s_rowp)[WGR * BS][S9_TILE], double (*s_F)[S9_TILE], S9Wave* ws, int& bad) {
     constexpr int NT = WGR * BS, NW = WGR * WGR;
@@ -380,6 +388,9 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     scr = (double*)((char*)scr + (size_t)blockIdx.z * scr_bs);
     constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
     __shared__ S9CholLds<NT, NW> sh;
+    // 6n <= 96 (NT = 6): Q = A L, later X = Mi G, stays in LDS (72 KB): the y operands of M = L^T Q and of W = (I - Q X) / s2 come from there (-1.7 us at 6n = 84)
+    constexpr bool QLDS = (NT == 6);
+    __shared__ double s_q[QLDS ? NT * NT : 1][S9_TILE];
     __shared__ double s_b[NP], s_y[NP], s_yp[NT][NP];
     __shared__ double s_dx[24 + 6 * RVIO_MAX_LEN];
     __shared__ double s_part[4 * (24 + 6 * RVIO_MAX_LEN)];
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const int i = wa * BS + s / BS, j = wb * BS + s % BS;
-            s9_stg(tile(bQ, i, j), lane, acc[s]);
+            if constexpr (QLDS) s9_sts(s_q[i * NT + j], lane, acc[s]);
+            else s9_stg(tile(bQ, i, j), lane, acc[s]);
             s9_stg(tile(bQt, j, i), lane, s9_transpose_tb(acc[s], s_tb[wv], li, lk));
         }
     }
@@ -451,7 +463,8 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
 #pragma unroll
     for (int s = 0; s < TS; ++s) S[s] = s9_zero();
     s9_gemm_block<BS>(wa * BS, NT, S, [&](int k, int qi) { return s9_ldg(tile(bL, k, wa * BS + qi), lane); },
-                      [&](int k, int qj) { return s9_ldg(tile(bQ, k, wb * BS + qj), lane); }, [&](int k, int qi, int) { return k >= wa * BS + qi; });
+                      [&](int k, int qj) { if constexpr (QLDS) return s9_lds(s_q[k * NT + wb * BS + qj], lane); else return s9_ldg(tile(bQ, k, wb * BS + qj), lane); },
+                      [&](int k, int qi, int) { return k >= wa * BS + qi; });
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         const int i = wa * BS + s / BS, j = wb * BS + s % BS;
@@ -482,7 +495,10 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     s9_gemm_block<BS>(0, wb * BS + BS, S, [&](int k, int qi) { return s9_ldg(tile(bMi, k, wa * BS + qi), lane); },
                       [&](int k, int qj) { return s9_ldg(tile(bG, k, wb * BS + qj), lane); }, [&](int k, int, int qj) { return k <= wb * BS + qj; });
 #pragma unroll
-    for (int s = 0; s < TS; ++s) s9_stg(tile(bQ, wa * BS + s / BS, wb * BS + s % BS), lane, S[s]);
+    for (int s = 0; s < TS; ++s) {
+        if constexpr (QLDS) s9_sts(s_q[(wa * BS + s / BS) * NT + wb * BS + s % BS], lane, S[s]);      // (Q's last reader was P3, two barriers ago)
+        else s9_stg(tile(bQ, wa * BS + s / BS, wb * BS + s % BS), lane, S[s]);
+    }
     __syncthreads();
 
     DBG_T(36);
@@ -491,7 +507,8 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
 #pragma unroll
     for (int s = 0; s < TS; ++s) S[s] = s9_zero();
     s9_gemm_block<BS>(0, NT, S, [&](int k, int qi) { return s9_ldg(tile(bQt, k, wa * BS + qi), lane); },
-                      [&](int k, int qj) { return s9_ldg(tile(bQ, k, wb * BS + qj), lane); }, [&](int, int, int) { return true; });
+                      [&](int k, int qj) { if constexpr (QLDS) return s9_lds(s_q[k * NT + wb * BS + qj], lane); else return s9_ldg(tile(bQ, k, wb * BS + qj), lane); },
+                      [&](int, int, int) { return true; });
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         const int i = wa * BS + s / BS, j = wb * BS + s % BS;
