@@ -850,14 +850,14 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     const int n = h->n_clones_host;
     const size_t bs = h->slab_bytes;
     const int B = h->batch;
-    if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance, unsharded
+    if (h->fuse_m >= 0) {   // propagate + U1..U5 in one launch (independent: see feat_prop_kernel); single instance (sharded or not: every rank propagates, builds its features)
         // solve9 at 6n <= 96: the Cholesky of the clone block as one more workgroup of this launch (the solve of this very update follows on the stream)
         const bool chol = h->solve9_nt && h->solve9_nt <= 6 && n >= 1;
         double* cs = chol ? h->S9scr : (double*)nullptr;
         const int extra = 1 + (chol ? 1 : 0);
         hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                            h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                           h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt);
+                           h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt, rank, world);
         h->chol_ready = chol;
         h->fuse_m = -1;
     } else
@@ -1581,7 +1581,7 @@ int rvio_hip_frame_tracks_dev(rvio_hip* h, const rvio_imu* d_imu, int imu_stride
 // hand-over is double-buffered; two events per buffer order (a) update(k) after track(k), (b) track(k+2) after update(k).
 // PreIntegrator::propagate needs nothing from the tracker either: it is enqueued first and runs beside the front end.
 static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const rvio_imu* d_imu, int m, const float* d_cand, int n_cand, bool staged,
-                          bool begin_only = false) {
+                          bool begin_only = false, bool defer_propagate = false) {   // defer_propagate: the caller runs update_local_dev itself right behind (the sharded frame)
     if (h->in_frame) { h->err = "rvio_hip_frame_begin_dev without rvio_hip_frame_end"; return RVIO_ERR_INVALID; }
     const int b = (int)(h->frame_no & 1);                   // parity: the staging of rvio_hip_frame
     const int hb = (int)(h->frame_no % rvio_hip::kHand);    // hand-over table of this frame
@@ -1610,7 +1610,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
     }
     // propagate: with an update in this frame (and nobody sequencing the update from outside) it rides in the per-feature launch,
     // otherwise it goes to the filter stream right behind augment/compose(k-1)
-    const bool fuse = h->fuse_ok && !begin_only && h->n_clones_host > h->cfg.min_track_len - 1;
+    const bool fuse = h->fuse_ok && (!begin_only || defer_propagate) && h->n_clones_host > h->cfg.min_track_len - 1;
     int rc = RVIO_OK;
     h->fuse_m = -1;
     if (!fuse) rc = propagate_dev(h, d_imu, m, h->imu_bs);
@@ -1628,7 +1628,11 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
         h->gate_pending = false;
     } else if (!(kDbgSkip & 16)) HIPCHK(h, hipStreamWaitEvent(h->stream, h->handover_evt ? h->evH[h->frame_no & 3] : h->evT[h->frame_no & 3], 0));
     const double t3 = dbg_host ? now() : 0;
-    if (begin_only) { h->in_frame = true; return RVIO_OK; }   // the caller sequences update / augment itself, then rvio_hip_frame_end
+    if (begin_only) {   // the caller sequences update / augment itself, then rvio_hip_frame_end
+        h->in_frame = true;
+        if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // (the sharded frame: consumed by its update_local_dev, same condition)
+        return RVIO_OK;
+    }
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
     rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
     h->fuse_m = -1;
@@ -1724,7 +1728,7 @@ int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, co
         h->allocs.push_back(q);
         h->gathered = (double*)q; h->gathered_world = world;
     }
-    int rc = frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false, /*begin_only=*/true);
+    int rc = frame_dev_impl(h, d_img, stride, d_imu, m, d_cand, n_cand, false, /*begin_only=*/true, /*defer_propagate=*/true);
     if (rc != RVIO_OK) return rc;
     h->img_count++;
     if (h->n_clones_host > h->cfg.min_track_len - 1) {   // System.cc:266
