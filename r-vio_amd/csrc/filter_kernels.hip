@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "rvio_dev.h"
 #include "../../include/rvio_hip.h"
+#include "solve9.hip"   // (the dx / state-injection roles of the split solve ride in ug_tile_kernel<0>)
 
 __device__ const double kChi2Dev[500] = {
 #include "chi2_table.inc"
@@ -1351,10 +1352,22 @@ __global__ __launch_bounds__(256) void final_kernel(DevCfg cfg, int n, const dou
 // output TILE of U, of G and of P1 is a wave of its own (three launches: each needs the one before complete), and a tile pair of P+ is a workgroup whose
 // four waves take (X_IJ, X_JI) x (P1c G^T, G U^T).  Operands, the order of the MFMAs of a tile and the closing expressions are ug_kernel's /
 // final_kernel's: the same bits.
+// dx_scr != NULL (PH = 0 behind the split solve): ceil(d / 24) more workgroups at the end of the grid are the solve's dx / state-injection roles (solve9.hip)
 template <int PH>
 __global__ __launch_bounds__(256) void ug_tile_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W, const double* __restrict__ Ab,
-                                                      double* __restrict__ U, double* __restrict__ G, double* __restrict__ P1) {
+                                                      double* __restrict__ U, double* __restrict__ G, double* __restrict__ P1,
+                                                      FilterMeta* __restrict__ meta, const double* __restrict__ x, double* __restrict__ x_out, const double* __restrict__ dx_scr, int dx_nt) {
     __shared__ double tl[4][16][17];
+    if constexpr (PH == 0) {
+        if (dx_scr) {
+            const int n_roles = (24 + 6 * n + 23) / 24, first = (int)gridDim.x - n_roles;
+            if ((int)blockIdx.x >= first) {
+                __shared__ S9DxLds dxl;
+                s9_dx_role(cfg, meta, n, Ab, x, P, dx_scr, x_out, dx_nt, (int)blockIdx.x - first, dxl);
+                return;
+            }
+        }
+    }
     const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax;
     const int c6t = (c6 + 15) / 16, dt = (d + 15) / 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;

@@ -90,6 +90,7 @@ struct rvio_hip {
     bool det_ready = false, use_det = false;
     hipStream_t stream_l = nullptr;               // long windows (6n > 96): = stream_c (one image chain in flight); the Cholesky factor of the clone block runs here, beside propagate / the per-feature stage of the frame it serves
     hipEvent_t evA = nullptr, evL = nullptr;      // augment/compose done (filter stream) -> stream_l;  factor in the slab (stream_l) -> the solve
+    bool dx_pending = false;                      // split solve: dx = Pc y and the state injection ride in the Joseph stage's first launch (launch_ug_final)
     bool chol_async = false;                      // a factor of the CURRENT clone block is in flight on (or has left) stream_l
     hipStream_t stream_d = nullptr;               // side stream of the front end: forks from / joins the tracker stream (see build_pyramid_dev)
     hipStream_t stream_c = nullptr;               // CLAHE stream of the run-ahead mode (frame k+1 is equalised while frame k is still being detected)
@@ -886,7 +887,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
     return RVIO_OK;
 }
 
-static void launch_solve(rvio_hip* h, int n, const double* Ab) {
+static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = false) {   // defer_dx: the caller launches the Joseph stage right behind (update_global_dev)
     const DevCfg& d = h->dc;
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     const dim3 gb(1, 1, h->batch);
@@ -931,7 +932,9 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab) {
         else hipLaunchKernelGGL((solve9_sweep_kernel<3, 4>), dim3(1), dim3(1024), 0, h->stream, d, Ab, h->S9scr);
         hipLaunchKernelGGL(solve9_prod_kernel<2>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
         hipLaunchKernelGGL(solve9_prod_kernel<3>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
-        hipLaunchKernelGGL(solve9_dx_kernel, dim3(1), dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, NT);
+        static const bool no_dx_role = ab_env("RVIO_S9_NO_DX_ROLE") != nullptr;   // A/B timing
+        if (defer_dx && 6 * n > 64 && !no_dx_role && !ab_env("RVIO_NO_UG_TILE")) h->dx_pending = true;   // (6n <= 64 while the window fills: launch_ug_final takes its short-window kernels)
+        else hipLaunchKernelGGL(solve9_dx_kernel, dim3(1), dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, NT);
         return;
     }
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
@@ -982,9 +985,13 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     } else if (B == 1 && !ab_env("RVIO_NO_UG_TILE")) {   // one instance, 6n > 64: one wave per output tile, the chip is this instance's alone
         const int c6t = (c6 + 15) / 16;
         if (ug) {
-            hipLaunchKernelGGL(ug_tile_kernel<0>, dim3((nt * c6t + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
-            hipLaunchKernelGGL(ug_tile_kernel<1>, dim3((nt * c6t + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
-            hipLaunchKernelGGL(ug_tile_kernel<2>, dim3((nt * nt + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
+            const bool dxr = h->dx_pending;   // the split solve left dx = Pc y and the state injection to role workgroups of this launch
+            h->dx_pending = false;
+            const double* nod = nullptr;
+            hipLaunchKernelGGL(ug_tile_kernel<0>, dim3((nt * c6t + 3) / 4 + (dxr ? (dd + 23) / 24 : 0)), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1,
+                               h->meta, (const double*)h->x[h->cur], h->x[h->cur ^ 1], dxr ? (const double*)h->S9scr : nod, h->solve9_nt);
+            hipLaunchKernelGGL(ug_tile_kernel<1>, dim3((nt * c6t + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, h->meta, nod, (double*)nullptr, nod, 0);
+            hipLaunchKernelGGL(ug_tile_kernel<2>, dim3((nt * nt + 3) / 4), dim3(256), 0, h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1, h->meta, nod, (double*)nullptr, nod, 0);
         }
         if (fin) hipLaunchKernelGGL(final_tile_kernel, dim3(npair), dim3(256), 0, h->stream, d, n, h->Pt1, h->G, h->U, Pn);
     } else {
@@ -1017,7 +1024,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
         else
             hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     }
-    launch_solve(h, n, Ab);
+    launch_solve(h, n, Ab, /*defer_dx=*/true);
     launch_ug_final(h, n, Ab, Pn, true, true);
     HIPCHK(h, hipGetLastError());
     h->cur ^= 1;

@@ -581,11 +581,20 @@ template <int PH>
 __global__ __launch_bounds__(256) void solve9_prod_kernel(DevCfg cfg, int n, const double* __restrict__ Ab, double* __restrict__ scr, double* __restrict__ Wout, int NT) {
     __shared__ double s_tb[4][16 * 17];
     const int c6 = 6 * n, ldh = cfg.ldh;
-    if ((int)Ab[(size_t)ldh * (ldh - 1)] <= 2) return;          // pass-through (Updater.cc:460): solve9_dx_kernel writes W = 0
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
     const int t = blockIdx.x * 4 + wv;
     if (t >= NT * NT) return;                                    // (no workgroup barrier below)
     const int i = t / NT, j = t - i * NT;
+    if ((int)Ab[(size_t)ldh * (ldh - 1)] <= 2) {                 // pass-through (Updater.cc:460, 621-627): W = 0 => U = G = 0 => P+ = P exactly
+        if constexpr (PH == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
+                if (row < c6 && col < c6) Wout[(size_t)row * ldh + col] = 0.0;
+            }
+        }
+        return;
+    }
     double* bL = scr;
     double* bG = scr + (size_t)NT * NT * S9_TILE;
     double* bQ = scr + (size_t)2 * NT * NT * S9_TILE;
@@ -680,8 +689,7 @@ __global__ __launch_bounds__(1024) void solve9_dx_kernel(DevCfg cfg, FilterMeta*
     const bool upd = n_good > 2;                       // Updater.cc:460
     DBG_R(true, 2);
     if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; }
-    if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
-        for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
+    if (!upd) {                                        // pass-through (Updater.cc:621-627; solve9_prod_kernel<3> wrote W = 0)
         for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
         return;
     }
@@ -718,6 +726,60 @@ __global__ __launch_bounds__(1024) void solve9_dx_kernel(DevCfg cfg, FilterMeta*
     }
     DBG_T(38);
     DBG_R(true, 7);
+}
+
+// The same as ROLE workgroups of the launch that follows the solve on the chain (ug_tile_kernel<0>: U = Pc W needs W complete, exactly like dx = Pc W b):
+// role r of ceil(d / 24) takes 24 rows of dx — the IMU block, or four clones — and injects that part of the state; 256 threads, row = tid % 24 along the
+// lanes (a column of Pc is contiguous), ten column groups summed in a fixed order.  Takes solve9_dx_kernel (one CU pulling all of Pc: 11 us at 6n = 180)
+// and its launch off the filter chain.  role 0 also reports (meta, the factorisations' verdicts).
+struct S9DxLds { double y[16 * 12]; double part[10][24]; double dx[24]; };
+__device__ __forceinline__ void s9_dx_role(const DevCfg& cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab, const double* __restrict__ x,
+                                           const double* __restrict__ P, const double* __restrict__ scr, double* __restrict__ x_out, int NT, int role, S9DxLds& L) {
+    const int c6 = 6 * n, d = 24 + c6, ldh = cfg.ldh, ld = cfg.dmax, NP = 16 * NT;
+    const int tid = threadIdx.x;
+    const int n_good = (int)Ab[(size_t)ldh * (ldh - 1)], n_rows = (int)Ab[(size_t)ldh * (ldh - 1) + 1];
+    const bool upd = n_good > 2;                       // Updater.cc:460
+    if (role == 0 && tid == 0) {
+        meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2];
+        if (upd && (scr[(size_t)5 * NT * NT * S9_TILE] != 0.0 || scr[(size_t)5 * NT * NT * S9_TILE + 1] != 0.0)) atomicOr(&meta->err, 1);
+    }
+    const int x0 = role == 0 ? 0 : 26 + 28 * (role - 1), x1 = role == 0 ? 26 : min(26 + 7 * n, x0 + 28);   // this role's part of the state vector
+    if (!upd) {                                        // pass-through (Updater.cc:621-627)
+        for (int i = x0 + tid; i < x1; i += blockDim.x) x_out[i] = x[i];
+        return;
+    }
+    const double* yp = scr + S9_YP_OFF(NT);
+    for (int i = tid; i < NP; i += blockDim.x) { double acc = yp[i]; for (int j = 1; j < NT; ++j) acc += yp[(size_t)j * NP + i]; L.y[i] = acc; }
+    __syncthreads();
+    const int r0 = 24 * role, rl = tid % 24, grp = tid / 24, share = (c6 + 9) / 10;
+    if (grp < 10) {
+        double acc = 0;
+        const int k1 = min(c6, (grp + 1) * share);
+        if (r0 + rl < d) {
+#pragma unroll 6
+            for (int k = grp * share; k < k1; ++k) acc += P[(size_t)(r0 + rl) + (size_t)(24 + k) * ld] * L.y[k];
+        }
+        L.part[grp][rl] = acc;
+    }
+    __syncthreads();
+    if (tid < 24) { double acc = L.part[0][tid]; for (int q = 1; q < 10; ++q) acc += L.part[q][tid]; L.dx[tid] = acc; }
+    __syncthreads();
+    const double* dx = L.dx;                            // rows 24 role .. of K r (Updater.cc:544)
+    if (role == 0) {                                    // state injection (Updater.cc:546-613), the IMU block
+        if (tid == 0) {
+            stq(x_out, qmul(small_q(dx[0], dx[1], dx[2]), ldq(x)));
+            for (int i = 0; i < 6; ++i) x_out[4 + i] = dx[3 + i] + x[4 + i];
+            st3(x_out + 7, unit3(ld3(x_out + 7)));
+            stq(x_out + 10, qmul(small_q(dx[9], dx[10], dx[11]), ldq(x + 10)));
+            for (int i = 0; i < 12; ++i) x_out[14 + i] = dx[12 + i] + x[14 + i];
+        }
+    } else if (tid < 4) {                               // ... four clones
+        const int p = 4 * (role - 1) + tid;
+        if (p < n) {
+            stq(x_out + 26 + 7 * p, qmul(small_q(dx[6 * tid], dx[6 * tid + 1], dx[6 * tid + 2]), ldq(x + 26 + 7 * p)));
+            for (int i = 0; i < 3; ++i) x_out[26 + 7 * p + 4 + i] = dx[6 * tid + 3 + i] + x[26 + 7 * p + 4 + i];
+        }
+    }
 }
 
 // =============================================================== 6n <= 64 with the Cholesky factor already in the slab: everything in LDS
