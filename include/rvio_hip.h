@@ -41,7 +41,7 @@ typedef enum rvio_status {
     RVIO_OK = 0,
     RVIO_ERR_INVALID = -1,     /* bad argument / size                                   */
     RVIO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error (see last_error)    */
-    RVIO_ERR_UNSUPPORTED = -3, /* e.g. Tracker.nMinDist >= 32 with the device detector (cornerSubPix half-windows 1..15) */
+    RVIO_ERR_UNSUPPORTED = -3, /* e.g. Tracker.nMinDist >= 128 with the device detector (cornerSubPix half-windows 1..63) */
     RVIO_ERR_STATE = -4        /* call out of sequence (e.g. update before set_state)    */
 } rvio_status;
 
