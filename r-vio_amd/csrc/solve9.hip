@@ -321,7 +321,11 @@ __device__ __forceinline__ void s9_chol_role(const DevCfg& cfg, int n, const dou
 // Measured and NOT adopted (round 5): LOOK-AHEAD of the factor — block row k + 1 updated first and published, wave 0 factoring its diagonal tile beside
 // the other waves' trailing update: 20.8 k cycles per step at 6n = 180 against 18 k (10.5 / 10.3 k at 120, 9.4 / 8.8 k at 84).  The factor wave shares its
 // matrix pipe with three updating waves (its eight dependent MFMAs queue behind theirs) and still has its own tiles to update afterwards: the step ends
-// with that tail.  It would take a wave that owns no tiles.
+// with that tail.  A wave that owns no tiles was tried next, together with keeping only the UPPER TRIANGLE of the symmetric tableau (78 of 144 tiles at
+// 6n = 180, dealt to ten waves so that the four matrix pipes carry 21 / 21 / 18 / 18 tiles; row panels completed by transposes; results identical): 19.5 k
+// cycles per step against 18 k, 10.3 k against 10.3 k at 6n = 120.  Halving the tiles per matrix pipe changed nothing: the trailing update of a step is not
+// bound by the pipe's throughput but by each wave's own chain (operand tiles from LDS, four dependent MFMAs per tile, two tiles of the tableau in
+// scratch at BS = 3) — the step gets shorter with fewer tiles per WAVE, i.e. with more than one workgroup, not with fewer tiles per pipe.
 template <int BS, int WGR>
 __device__ __forceinline__ void s9_sweep(s9_d4 (&S)[BS * BS], double (*s_rowp)[WGR * BS][S9_TILE], double (*s_F)[S9_TILE], S9Wave* ws, int& bad) {
     constexpr int NT = WGR * BS, NW = WGR * WGR;
