@@ -227,6 +227,7 @@ __device__ __forceinline__ int s9_cholesky(const DevCfg& cfg, int n, const doubl
 #pragma unroll
     for (int s = 0; s < TS; ++s) {
         const int i = wa * BS + s / BS, j = wb * BS + s % BS;
+        if (i > j) { S[s] = s9_zero(); continue; }     // (never read: one CU pulls P at ~10 B per clock — at 6n = 180 the 66 dead tiles were 12 us of the load)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * i + 4 * r + lk, col = 16 * j + li;
