@@ -10,6 +10,7 @@
 //   stage_gate_kernel, stage_signal_kernel one-workgroup poll / bump of a device-side counter (StageSync): hand-over -> filter, corners -> refill
 #include "rvio_dev.h"
 #include "frontend_dev.h"
+#include "pyr_sep.h"
 #include "../../include/rvio_hip.h"
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -25,13 +26,36 @@ __device__ __forceinline__ int reflect2(int i, int n) { return reflect1(reflect1
 
 // ------------------------------------------------------------------ pyramid
 // buildOpticalFlowPyramid of cv::calcOpticalFlowPyrLK (Tracker.cc:244) in ONE launch: a workgroup owns an 8x8 tile of level 3 and
-// everything above it — it stages the 85x85 patch of level 0 that tile depends on, forms its 41x41 / 19x19 dependency patches of
-// levels 1 / 2 in LDS (cv::pyrDown: [1 4 6 4 1]/16 separable, BORDER_REFLECT_101 at every level's own size, (v+128)>>8) and
-// stores the tiles it owns: 64x64 of level 0 (the copy of the frame into the pyramid), 32x32 of level 1, 16x16 of level 2, 8x8 of
-// level 3.  The patches overlap between neighbours ((85/64)^2 = 1.8 x the level-0 reads, all L2 hits); nothing but the u8 levels is
-// written: the Scharr derivatives of the template are formed by the KLT kernel from its staged patch (they used to be
-// materialised as int16x2 images: 2.5 MB of stores per 752x480 frame against 0.12 MB for levels 1..3).
-#define PYR_T 256
+// everything above it.  The body lives in pyr_sep.h as per-thread phases between barriers (the same code runs thread by thread on the
+// host in tests/test_pyramid_phases.py): each cv::pyrDown as a vertical pass + a horizontal pass through LDS, the reflect-101 indices
+// from tables the workgroup fills once.  The patches overlap between neighbours ((85/64)^2 = 1.8 x the level-0 reads, all L2 hits);
+// nothing but the u8 levels is written: the Scharr derivatives of the template are formed by the KLT kernel from its staged patch.
+__global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
+    src = zoff(src, src_bs); pyr_shift(p, (size_t)blockIdx.z * bs);
+    __shared__ PyrLds s;
+    PyrOut o;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { o.img[l] = (uint8_t*)p.img[l]; o.w[l] = p.w[l]; o.h[l] = p.h[l]; }
+    const PyrGeom g = pyr_geom(o, blockIdx.x, blockIdx.y, levels, copy0);   // (uniform over the workgroup: so is every early-out below)
+    const int tid = threadIdx.x;
+    if (g.nl < 1) return;
+    pyr_phase0(g, tid, s, src, stride);
+    __syncthreads();
+    pyr_phase1(g, tid, s, o);
+    if (g.nl < 2) return;
+    __syncthreads();
+    pyr_phase2(g, tid, s, o);
+    if (g.nl < 3) return;
+    __syncthreads();
+    pyr_phase3(g, tid, s);
+    __syncthreads();
+    pyr_phase4(g, tid, s, o);
+    if (g.nl < 4) return;
+    __syncthreads();
+    pyr_phase5(g, tid, s, o);
+}
+
+// The round-1..4 form (a 25-tap gather per output, reflect-101 per tap), kept for A/B timing in the instrumented build (RVIO_PYR_V1=1)
 __device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int sw, int sx0, int sy0, int w, int h, int x, int y) {
     // pyrDown pixel (x, y) of the next level from the LDS patch `src` (row stride sw) that holds level pixels [sx0.., sy0..]
     int xs[5];
@@ -45,7 +69,7 @@ __device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int 
     }
     return (rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6 + 128) >> 8;
 }
-__global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
+__global__ __launch_bounds__(PYR_T) void pyramid_kernel_v1(const uint8_t* __restrict__ src, int stride, PyrDev p, int levels, int copy0, size_t src_bs, size_t bs) {
     src = zoff(src, src_bs); pyr_shift(p, (size_t)blockIdx.z * bs);
     __shared__ uint8_t L0[85 * 88], L1[41 * 44], L2[19 * 20];
     const int tid = threadIdx.x;
