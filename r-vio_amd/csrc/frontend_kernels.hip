@@ -55,7 +55,8 @@ __global__ __launch_bounds__(PYR_T) void pyramid_kernel(const uint8_t* __restric
     pyr_phase5(g, tid, s, o);
 }
 
-// The round-1..4 form (a 25-tap gather per output, reflect-101 per tap), kept for A/B timing in the instrumented build (RVIO_PYR_V1=1)
+// The round-1..4 form (a 25-tap gather per output, reflect-101 per tap), kept for A/B timing in the instrumented build only (RVIO_PYR_V1=1)
+#ifdef RVIO_DBG_CLOCKS
 __device__ __forceinline__ int pyr_down_at(const uint8_t* __restrict__ src, int sw, int sx0, int sy0, int w, int h, int x, int y) {
     // pyrDown pixel (x, y) of the next level from the LDS patch `src` (row stride sw) that holds level pixels [sx0.., sy0..]
     int xs[5];
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(PYR_T) void pyramid_kernel_v1(const uint8_t* __rest
         if (x < w3 && y < h3) ((uint8_t*)p.img[3])[(size_t)y * w3 + x] = (uint8_t)pyr_down_at(L2, 20, ex, ey, w2, h2, x, y);
     }
 }
+#endif
 
 // calcSharrDeriv of one pyramid level, on demand (rvio_hip_debug_pyramid): un-normalised 3x3 Scharr with reflect-101 neighbours,
 // int16 (dx,dy) packed — the same arithmetic the KLT kernel applies to its staged template patch

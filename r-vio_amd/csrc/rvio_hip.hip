@@ -1257,9 +1257,11 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
         PyrDev pv = p;
         const bool own = h->cfg.enable_equalizer != 0;   // d_img is the handle's equalised image: level 0 without a copy
         if (own) { h->pyr[b].img[0] = d_img; pv.img[0] = d_img; }
+#ifdef RVIO_DBG_CLOCKS
         static const bool pyr_v1 = ab_env("RVIO_PYR_V1") != nullptr;   // A/B timing: the 25-tap gather form
         if (pyr_v1) hipLaunchKernelGGL(pyramid_kernel_v1, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, st, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
         else
+#endif
         hipLaunchKernelGGL(pyramid_kernel, dim3((w3 + 7) / 8, (h3 + 7) / 8, B), dim3(PYR_T), 0, st, d_img, stride, pv, d.levels, own ? 0 : 1, src_bs, bs);
     };
     // Run-ahead mode: the image chain of frame k (CLAHE, detector; with the equaliser also the pyramid) rewrites buffers that book-keeping /
