@@ -1017,9 +1017,40 @@ def batched_streams_leg(cfg, torch, sizes, name="B", seeds=4, n_warm=12, n_timed
         res.append({"streams": B, "ms_per_batched_frame": 1e3 * el / n_timed, "frames_per_s": fps,
                     "klt_chain_algorithmic_GBps": by_klt * fps / 1e9, "frac_hbm_peak": by_klt * fps / 1e9 / 8000.0,
                     "staged_up_front": True, "finite": bool(np.all(np.isfinite(x_last))), "updated_last_frame": int(info["updated"])})
+    for e in res:
+        e.update(issue_slots(e["streams"], e["ms_per_batched_frame"]))
     return {"workload": "cfg%s whole frame (stock: CLAHE + device detector), %d seeded scenes, stream b replays scene b mod %d, %d frames timed after %d, "
                         "one launch per stage for all streams" % (name, seeds, seeds, n_timed, 1 + n_warm),
             "algorithmic_MB_per_frame_klt_chain": by_klt / 1e6, "sizes": res}
+
+
+SHADER_HZ, N_SIMD = 2.4e9, 256 * 4     # MI355X: peak engine clock, 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+
+
+def issue_slots(streams, ms_per_frame, path=None):
+    """The bound the batched camera-stream frame actually hits (not HBM: ~6 %): instruction issue.  The SQ counters of one batched frame
+    (committed rocprofv3 --pmc pass, tools/issue_slots_json.py — counters cannot be read live) over the issue slots of the frame time
+    measured live: one slot = one wave instruction on one SIMD = 4 cycles."""
+    path = path or os.path.join(ROOT, "profiles", "r05_streams_issue_slots.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        with open(path) as f:
+            cm = json.load(f)
+        if cm.get("streams") != streams:
+            return {}
+        slots = ms_per_frame * 1e-3 * SHADER_HZ * N_SIMD / 4.0
+        pf = cm["per_batched_frame"]
+        o = {"bound": "instruction issue", "slots_per_batched_frame": slots, "unit": "SIMD issue slots (4 cycles each, 1024 SIMDs at 2.4 GHz)",
+             "what": "SQ counters of one batched frame (committed pass: profiles/r05_streams_issue_slots.json) / the issue slots of the frame time measured here; "
+                     "VALU is a utilisation (<= 1), ANY counts scalar / LDS / memory instructions of other waves issuing beside it (can exceed 1)"}
+        if "SQ_ACTIVE_INST_VALU" in pf:
+            o["valu_busy"] = pf["SQ_ACTIVE_INST_VALU"]; o["frac_valu"] = pf["SQ_ACTIVE_INST_VALU"] / slots
+        if "SQ_ACTIVE_INST_ANY" in pf:
+            o["any_busy"] = pf["SQ_ACTIVE_INST_ANY"]; o["frac_any"] = pf["SQ_ACTIVE_INST_ANY"] / slots
+        return {"issue_slots": o}
+    except Exception as e:   # noqa: BLE001
+        return {"issue_slots": {"error": repr(e)[:100]}}
 
 
 _CFG_NAME = ["B"]

@@ -146,3 +146,33 @@ def test_rocpd_stats_reports_the_median(tmp_path):
     assert len(line) == 1 and "other" not in out.stdout
     cells = [c.strip() for c in line[0].strip("|").split("|")]
     assert int(cells[1]) == 10 and abs(float(cells[4]) - 345.0) < 1e-6 and float(cells[3]) > 1400.0     # median 345 us, mean dragged up by the 11 ms launch
+
+
+def test_issue_slots_of_the_batched_streams(tmp_path):
+    """tools/issue_slots_json.py (rocprofv3 --pmc csv -> per-frame SQ figures) and bench.issue_slots (those figures over the issue slots of
+    a live frame time): only launches that cover every stream count, torch's harness kernels do not, a frame = one pyramid launch"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import issue_slots_json as T
+    rows = ["Kernel_Name,Grid_Size,Workgroup_Size,Counter_Name,Counter_Value"]
+    for f in range(3):                                   # three batched frames of 128 streams
+        rows += ['"pyramid_kernel(unsigned char const*, int)",%d,256,SQ_ACTIVE_INST_ANY,%d' % (96 * 128 * 256, 100 + f),
+                 '"pyramid_kernel(unsigned char const*, int)",%d,256,SQ_ACTIVE_INST_VALU,60' % (96 * 128 * 256),
+                 '"void klt_kernel16(PyrDev, PyrDev)",%d,64,SQ_ACTIVE_INST_ANY,50' % (50 * 128 * 64),
+                 '"void klt_kernel16(PyrDev, PyrDev)",%d,64,SQ_ACTIVE_INST_VALU,40' % (50 * 128 * 64),
+                 '"void at::native::vectorized_gather_kernel<16, long>(char*)",%d,128,SQ_ACTIVE_INST_ANY,1000' % (4096 * 128),
+                 '"stage_gate_kernel(unsigned long long const*)",64,64,SQ_ACTIVE_INST_ANY,7']
+    p = tmp_path / "c.csv"
+    p.write_text("\n".join(rows) + "\n")
+    cm = T.summarise(T.collect([str(p)], 128), 128)
+    assert cm["frames_profiled"] == 3 and set(cm["per_kernel"]) == {"pyramid_kernel", "klt_kernel16"}
+    assert cm["per_batched_frame"]["SQ_ACTIVE_INST_ANY"] == pytest.approx(101 + 50)
+    assert cm["per_batched_frame"]["SQ_ACTIVE_INST_VALU"] == pytest.approx(100)
+    j = tmp_path / "s.json"
+    j.write_text(json.dumps(cm))
+    o = bench.issue_slots(128, 1.0, path=str(j))["issue_slots"]
+    slots = 1e-3 * 2.4e9 * 1024 / 4
+    assert o["slots_per_batched_frame"] == pytest.approx(slots)
+    assert o["frac_valu"] == pytest.approx(100 / slots) and o["frac_any"] == pytest.approx(151 / slots)
+    assert bench.issue_slots(16, 1.0, path=str(j)) == {}                   # committed counters are for another batch size: nothing is claimed
+    assert bench.issue_slots(128, 1.0, path=str(tmp_path / "none.json")) == {}
