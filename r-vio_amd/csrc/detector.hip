@@ -14,7 +14,7 @@
 //   subpix_kernel     one workgroup of 4 waves per corner: the neighbourhood cached in LDS, 17x17 bilinear patch, one
 //                     window term per thread, double sums in the oracle's canonical tree order, 2x2 solve, <= 30 iterations
 //   subpix_kernel16   the throughput form (four corners per wave, one 16-lane DPP row each: batch handles); subpix_generic_kernel: any half-window 1..15 other than the stock 7
-//   mineig_nms_strip_kernel: the fused pass of batch handles (one wave per strip of 60 x 32 pixels, rows walked with the state in registers)
+//   mineig_nms_strip_kernel: the fused pass of batch handles (one wave per strip of 60 x 16 pixels, rows walked with the state in registers)
 #pragma once
 
 #define DET_NBCAP 64          // stronger-neighbour list capacity per candidate (global memory)
@@ -281,9 +281,23 @@ __global__ __launch_bounds__(DET_T) void mineig_nms_kernel(const uint8_t* __rest
 // (BORDER_REFLECT_101 on the pixels for the Sobel rows / columns, and on the GRADIENT products for the box sums): row -1 of anything is
 // row 1, row H is row H - 2, column -1 is column 1, column W is column W - 2 — two virtual steps behind the last image row flush the
 // pipeline.  A wave keeps two columns of halo on either side (its lanes 0, 1, 62, 63 only feed their neighbours).
-#define DET_SH 32
+// Strip height and list size are measured choices (profiles/r05_strip_ab.md, 128 batched streams, shipping-flag builds back to back on one box):
+// the LDS list of a wave's maxima at 128 instead of 256 entries (1 KB instead of 2 KB of the workgroup's LDS: more strips resident per CU)
+// 144.0 -> 146.4 k frames/s at every strip height; taller strips (fewer halo rows per output row) are SLOWER — 64 rows 140.5 k, 96 rows
+// 138.6 k against 144.0 k at 32: the row walk is a dependent chain per wave, the chip wants more waves, not fewer instructions per wave.
+// The loop is not unrolled (the compiler declines: #pragma unroll 2 gives the same code).
+#ifndef DET_SH
+#define DET_SH 16                       // rows a wave walks (6 rows of halo per strip)
+#endif
+#ifndef DET_STRIP_UNROLL
+#define DET_STRIP_UNROLL 1
+#endif
+#define DET_STR2(x) #x
+#define DET_STR(x) DET_STR2(x)
 #define DET_SW 60
-#define DET_SL 256                       // the wave's list of local maxima in LDS: flushed to the provisional list when a row might not fit
+#ifndef DET_SL
+#define DET_SL 128                      // the wave's list of local maxima in LDS: flushed to the provisional list when a row might not fit
+#endif
 __global__ __launch_bounds__(64) void mineig_nms_strip_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs) {
     src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     constexpr int TR = DET_SH + 6, TWB = 68;                          // raw tile: rows ys-3 .. ys+SH+2, columns X0-3 .. X0+64 (17 dwords)
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(64) void mineig_nms_strip_kernel(const uint8_t* __r
     const int r_lo = max(ys - 3, 0), r_hi = min(ye + 2, H + 1);
     const int g_min = (ys - 3 <= 0) ? 0 : r_lo + 1;                    // first gradient row this strip forms
     const int c_min = (g_min == 0) ? 0 : g_min + 1;                    // first row of column sums / of the map
-#pragma unroll 1
+_Pragma(DET_STR(unroll DET_STRIP_UNROLL))
     for (int r = r_lo; r <= r_hi; ++r) {
         // ---- stage A: raw row r -> rr, q; gradient row g = r - 1 -> products
         bool have_p = false;
