@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/ref_*.npz: the EXPECTED OUTPUTS of the two golden fixtures as computed by the reference's OWN sources
+(oracle/_ref/libref.so = /root/reference/src/rvio/*.cc compiled unmodified against oracle/refshim/, `make -C oracle ref`) on the inputs the
+oracle-written fixtures carry (cfgB_direct_seed0_frame30.npz, small_images_tracker.npz: their inputs are reused, nothing is stored twice).
+
+Runs only where /root/reference exists (this container).  The GPU box has neither the reference nor a way to build it: its tests read
+the committed files (tests/test_gpu_golden.py, both fixture families), and tests/test_golden_ref.py checks on the CPU that the two
+families agree — and, where the reference is present, that the committed files are what this script writes today.
+
+Filter stages: PreIntegrator::propagate -> Updater::update -> the System.cc:279-365 block, chained on the reference's own intermediate
+results.  Front end: RVIO::Tracker::track on the four images (its OpenCV IMAGE calls forward to the oracle's restatements — the shim has no
+other implementation — so what the reference contributes here is Tracker.cc / FeatureDetector.cc / Ransac.cc: undistortion, RANSAC, the
+book-keeping, FindNewer / ChessGrid)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle as O  # noqa: E402
+import scenarios as S  # noqa: E402
+import ref as R  # noqa: E402
+
+abi = O.abi
+
+
+def filter_outputs():
+    g = np.load(os.path.join(HERE, "cfgB_direct_seed0_frame30.npz"))
+    cfg = abi.config_named("B", enable_equalizer=0)
+    x1, P1 = R.propagate(cfg, g["x0"], g["P0"], g["imu"].view(abi.IMU_DTYPE))
+    x2, P2, d = R.update(cfg, x1, P1, g["types"], g["lens"], g["meas"])
+    x3, P3, pp, pq = R.augment_compose(cfg, x2, P2, bool(g["do_augment"]))
+    return dict(x1=x1, P1=P1, x2=x2, P2=P2, x3=x3, P3=P3, pose_p=pp, pose_q=pq, n_cloud=np.int32(d["n_cloud"]),
+                gate_rejects=np.int32(d["gate_rejects"]), invalid=np.int32(d["invalid"]), updated=np.int32(d["updated"]), cloud=d["cloud"])
+
+
+def tracker_outputs():
+    g = np.load(os.path.join(HERE, "small_images_tracker.npz"))
+    cfg = S.small_image_config()
+    t = R.Tracker(cfg)
+    out = {}
+    for i in range(4):
+        t.track(g["imgs"][i], g["imu%d" % i].view(abi.IMU_DTYPE), None)
+        out["pts%d" % i], out["hist%d" % i] = t.get_points()
+        ty, ln, me = t.get_tracks()
+        out["types%d" % i], out["lens%d" % i], out["meas%d" % i] = ty, ln, me
+    return out
+
+
+if __name__ == "__main__":
+    assert R.available(), "needs /root/reference (make -C oracle ref)"
+    np.savez_compressed(os.path.join(HERE, "ref_cfgB_direct_seed0_frame30.npz"), **filter_outputs())
+    np.savez_compressed(os.path.join(HERE, "ref_small_images_tracker.npz"), **tracker_outputs())
+    for f in ("ref_cfgB_direct_seed0_frame30.npz", "ref_small_images_tracker.npz"):
+        print("written", f, os.path.getsize(os.path.join(HERE, f)), "bytes")

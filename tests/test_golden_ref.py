@@ -1,0 +1,56 @@
+"""The two families of golden fixtures agree: tests/golden/ref_*.npz (expected outputs computed by the reference's OWN compiled sources,
+tests/golden/make_golden_ref.py) against tests/golden/*.npz (the oracle's, make_golden.py) on the same stored inputs.
+
+This runs anywhere (the files are committed).  Where /root/reference exists it also recomputes the reference's outputs and holds the
+committed files against them, so a stale fixture cannot survive.  The GPU suite compares the HIP path with BOTH families
+(tests/test_gpu_golden.py): against the reference-written one the device is held to numbers no code of this repository's oracle produced."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+import scenarios as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def test_filter_snapshot_reference_vs_oracle():
+    g, r = np.load(os.path.join(GOLD, "cfgB_direct_seed0_frame30.npz")), np.load(os.path.join(GOLD, "ref_cfgB_direct_seed0_frame30.npz"))
+    for k in ("1", "2", "3"):
+        assert S.state_delta(r["x" + k], g["x" + k]) <= 1e-12, k
+        assert _rel(r["P" + k], g["P" + k]) <= 1e-12, k
+    assert int(r["updated"]) == 1
+    assert int(r["n_cloud"]) == int(np.count_nonzero(g["accepted"]))                       # the chi-square gate: same number of accepted features
+    assert int(r["gate_rejects"]) + int(r["invalid"]) == len(g["types"]) - int(r["n_cloud"])
+
+
+def test_tracker_tables_reference_vs_oracle():
+    g, r = np.load(os.path.join(GOLD, "small_images_tracker.npz")), np.load(os.path.join(GOLD, "ref_small_images_tracker.npz"))
+    for i in range(4):
+        assert np.array_equal(r["pts%d" % i], g["pts%d" % i]) and np.array_equal(r["hist%d" % i], g["hist%d" % i]), i   # bit-identical tables
+    assert sum(len(r["types%d" % i]) for i in range(4)) >= 0
+
+
+def test_committed_reference_fixtures_are_current():
+    try:
+        import ref as R
+        have = R.available()
+    except Exception as e:   # a broken build must fail loudly where the sources exist
+        if "failed to build" in str(e):
+            raise
+        have = False
+    if not have:
+        pytest.skip("oracle/_ref/libref.so needs the reference's sources (/root/reference)")
+    sys.path.insert(0, GOLD)
+    import make_golden_ref as M
+    for name, fresh in (("ref_cfgB_direct_seed0_frame30.npz", M.filter_outputs()), ("ref_small_images_tracker.npz", M.tracker_outputs())):
+        stored = np.load(os.path.join(GOLD, name))
+        assert set(stored.files) == set(fresh), name
+        for k, v in fresh.items():
+            assert np.array_equal(np.asarray(v), stored[k]), (name, k)                      # the same program on the same inputs: the same bits
