@@ -49,9 +49,43 @@ def tracker_outputs():
     return out
 
 
+from golden_io import FULL_LOAD, load_full_load_case, probes  # noqa: E402
+
+
+def full_load_inputs():
+    """the worst-case update load of SURVEY.md 8(d) at the 14- / 10- / 20- / 30-clone windows (written ONCE, by the oracle's sequence
+    recorder; stored because another host's libm may round a sine differently and the GPU box must see exactly these inputs)"""
+    out = {}
+    for name, mix, nf in FULL_LOAD:
+        cfg = abi.config_named(name)
+        seq, recs = S.record_sequence(cfg, n_frames=cfg.max_track_len + 4, duration=(38 + cfg.max_track_len + 8) / 20.0)
+        r = recs[-1]
+        types, lens, meas = S.worst_case_tracks(cfg, r, seq, n_feat=nf, mix=mix)
+        d = r["P1"].shape[0]
+        out.update({name + "_x1": r["x1"], name + "_P1u": r["P1"][np.triu_indices(d)], name + "_types": types, name + "_lens": lens,
+                    name + "_meas": meas[:, : int(lens.max())].copy()})
+    return out
+
+
+def full_load_outputs(g):
+    """Updater::update of the reference's own sources on the stored loads: state, diag P, P V, the size of the accepted set"""
+    out = {}
+    for name, _, _ in FULL_LOAD:
+        cfg, x1, P1, types, lens, meas = load_full_load_case(g, name)
+        x2, P2, d = R.update(cfg, x1, P1, types, lens, meas)
+        assert d["updated"] == 1
+        out.update({name + "_x2": x2, name + "_diagP2": np.diag(P2).copy(), name + "_P2V": P2 @ probes(P2.shape[0]), name + "_maxP2": np.float64(np.max(np.abs(P2))),
+                    name + "_n_cloud": np.int32(d["n_cloud"])})
+    return out
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (make -C oracle ref)"
     np.savez_compressed(os.path.join(HERE, "ref_cfgB_direct_seed0_frame30.npz"), **filter_outputs())
     np.savez_compressed(os.path.join(HERE, "ref_small_images_tracker.npz"), **tracker_outputs())
-    for f in ("ref_cfgB_direct_seed0_frame30.npz", "ref_small_images_tracker.npz"):
+    fl = os.path.join(HERE, "full_load_inputs.npz")
+    if not os.path.exists(fl) or "--inputs" in sys.argv:
+        np.savez_compressed(fl, **full_load_inputs())
+    np.savez_compressed(os.path.join(HERE, "ref_full_load_outputs.npz"), **full_load_outputs(np.load(fl)))
+    for f in ("ref_cfgB_direct_seed0_frame30.npz", "ref_small_images_tracker.npz", "full_load_inputs.npz", "ref_full_load_outputs.npz"):
         print("written", f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -54,3 +54,49 @@ def test_committed_reference_fixtures_are_current():
         assert set(stored.files) == set(fresh), name
         for k, v in fresh.items():
             assert np.array_equal(np.asarray(v), stored[k]), (name, k)                      # the same program on the same inputs: the same bits
+
+
+def _golden_ref_module():
+    sys.path.insert(0, GOLD)
+    import make_golden_ref as M
+    return M
+
+
+def _golden_io():
+    sys.path.insert(0, GOLD)
+    import golden_io as M
+    return M
+
+
+@pytest.mark.parametrize("name", ["A", "B", "C", "E"])
+def test_full_load_digest_reference_vs_oracle(name):
+    """the worst-case update loads at the 14- / 10- / 20- / 30-clone windows: the oracle's update on the stored inputs against
+    the digest the reference's own Updater::update left (state, diag P, P V on fixed probe vectors, size of the accepted set)"""
+    M = _golden_io()
+    g, r = np.load(os.path.join(GOLD, "full_load_inputs.npz")), np.load(os.path.join(GOLD, "ref_full_load_outputs.npz"))
+    cfg, x1, P1, types, lens, meas = M.load_full_load_case(g, name)
+    assert np.array_equal(P1, P1.T) and len(types) == len(lens) == len(meas)
+    x2, P2, dg = O.update(cfg, x1, P1, types, lens, meas)
+    assert dg["updated"] and dg["n_rows"] > 6 * (cfg.max_track_len - 1)                   # a tall stack: compression and rank scan ran
+    scale = float(r[name + "_maxP2"])
+    assert S.state_delta(x2, r[name + "_x2"]) <= 1e-11
+    assert np.max(np.abs(np.diag(P2) - r[name + "_diagP2"])) <= 1e-11 * scale
+    assert np.max(np.abs(P2 @ M.probes(P2.shape[0]) - r[name + "_P2V"])) <= 1e-10 * scale
+    assert dg["n_good"] == int(r[name + "_n_cloud"])
+
+
+def test_committed_full_load_digest_is_current():
+    try:
+        import ref as R
+        have = R.available()
+    except Exception as e:
+        if "failed to build" in str(e):
+            raise
+        have = False
+    if not have:
+        pytest.skip("oracle/_ref/libref.so needs the reference's sources (/root/reference)")
+    M = _golden_ref_module()
+    fresh, stored = M.full_load_outputs(np.load(os.path.join(GOLD, "full_load_inputs.npz"))), np.load(os.path.join(GOLD, "ref_full_load_outputs.npz"))
+    assert set(stored.files) == set(fresh)
+    for k, v in fresh.items():
+        assert np.array_equal(np.asarray(v), stored[k]), k

@@ -69,3 +69,27 @@ def test_tracker_against_the_golden_image_fixture(gpu_required, family):
         pts, hl = h.get_points()
         assert np.array_equal(pts, g["pts%d" % i]) and np.array_equal(hl, g["hist%d" % i]), i
     h.close()
+
+
+@pytest.mark.parametrize("name", ["A", "B", "C", "E"])
+def test_full_load_update_against_the_reference_written_digest(gpu_required, name):
+    """the worst-case update load at the 14- / 10- / 20- / 30-clone windows — every form of the solve (all-LDS, one workgroup,
+    split) and of the Joseph stage — from stored inputs, against what the reference's own Updater::update left for them
+    (tests/golden/ref_full_load_outputs.npz: state, diag P, P V on fixed probe vectors, the size of the accepted set)"""
+    import sys
+    from rvio_amd import hip
+    sys.path.insert(0, GOLD)
+    import golden_io as M
+    g, r = np.load(os.path.join(GOLD, "full_load_inputs.npz")), np.load(os.path.join(GOLD, "ref_full_load_outputs.npz"))
+    cfg, x1, P1, types, lens, meas = M.load_full_load_case(g, name)
+    h = hip.RvioHip(cfg)
+    h.set_state(x1, P1)
+    h.update(types, lens, meas)
+    x2, P2 = h.get_state()
+    diag = h.update_diag()
+    h.close()
+    scale = float(r[name + "_maxP2"])
+    assert S.state_delta(x2, r[name + "_x2"]) <= 1e-9
+    assert np.max(np.abs(np.diag(P2) - r[name + "_diagP2"])) <= 1e-9 * scale
+    assert np.max(np.abs(P2 @ M.probes(P2.shape[0]) - r[name + "_P2V"])) <= 1e-8 * scale
+    assert int(np.count_nonzero(diag["accepted"])) == int(r[name + "_n_cloud"])
