@@ -79,6 +79,43 @@ def full_load_outputs(g):
     return out
 
 
+FREE_RUN_FRAMES = 30
+FREE_RUN_TABLES = (9, 19, 29)      # frames whose feature tables are stored
+
+
+def free_run():
+    """System::MonoVIO of the reference's own sources, free-running for 30 direct-track frames from System::initialize (window filling,
+    the first type-'2' features, the window sliding): the inputs of every frame (the simulated KLT result depends on the tracker's own
+    feature table, so they are recorded while the reference runs), the reference's state after every frame, a digest of its final
+    covariance, its feature tables at three frames.  A device that replays the inputs must end every frame where the reference did."""
+    cfg = abi.config_named("B", enable_equalizer=0)
+    n = FREE_RUN_FRAMES
+    seq = O.rv.synth.SynthSequence(cfg, duration=(38 + n + 4) / 20.0, seed=0)
+    w, a, ni = seq.init_from_static(38)
+    x0, P0 = R.initialize(cfg, w, a, ni)
+    sr = R.System(cfg)
+    sr.set_state(x0, P0)
+    drv = O.rv.synth.DirectTrackDriver(seq)
+    out = dict(init_w=np.asarray(w, float), init_a=np.asarray(a, float), init_n=np.int32(ni), x0=x0, P0=P0)
+    xs = np.zeros((n, 26 + 7 * (cfg.max_track_len - 1)))
+    xlen, updated, ncloud = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for i, k in enumerate(range(39, 39 + n)):
+        inp = drv.inputs(k)
+        info, pp, pq = sr.frame(inp["imu"], inp["cand"], tracked=inp["tracked"], status=inp["status"])
+        pts, hl = sr.get_points()
+        drv.after(pts)
+        x, P = sr.get_state()
+        xs[i, : len(x)] = x
+        xlen[i], updated[i], ncloud[i] = len(x), info["updated"], info["n_cloud"]
+        out.update({"tracked%d" % i: np.ascontiguousarray(inp["tracked"], np.float32), "status%d" % i: np.ascontiguousarray(inp["status"], np.uint8),
+                    "imu%d" % i: np.ascontiguousarray(inp["imu"]).view(np.uint8), "cand%d" % i: np.ascontiguousarray(inp["cand"], np.float32)})
+        if i in FREE_RUN_TABLES:
+            out.update({"pts%d" % i: pts, "hist%d" % i: hl})
+    out.update(ref_x=xs, ref_xlen=xlen, ref_updated=updated, ref_n_cloud=ncloud, ref_diagP=np.diag(P).copy(), ref_PV=P @ probes(P.shape[0]),
+               ref_maxP=np.float64(np.max(np.abs(P))))
+    return out
+
+
 if __name__ == "__main__":
     assert R.available(), "needs /root/reference (make -C oracle ref)"
     np.savez_compressed(os.path.join(HERE, "ref_cfgB_direct_seed0_frame30.npz"), **filter_outputs())
@@ -87,5 +124,6 @@ if __name__ == "__main__":
     if not os.path.exists(fl) or "--inputs" in sys.argv:
         np.savez_compressed(fl, **full_load_inputs())
     np.savez_compressed(os.path.join(HERE, "ref_full_load_outputs.npz"), **full_load_outputs(np.load(fl)))
-    for f in ("ref_cfgB_direct_seed0_frame30.npz", "ref_small_images_tracker.npz", "full_load_inputs.npz", "ref_full_load_outputs.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_free_run_30_frames.npz"), **free_run())
+    for f in ("ref_cfgB_direct_seed0_frame30.npz", "ref_small_images_tracker.npz", "full_load_inputs.npz", "ref_full_load_outputs.npz", "ref_free_run_30_frames.npz"):
         print("written", f, os.path.getsize(os.path.join(HERE, f)), "bytes")

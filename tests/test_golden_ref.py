@@ -100,3 +100,48 @@ def test_committed_full_load_digest_is_current():
     assert set(stored.files) == set(fresh)
     for k, v in fresh.items():
         assert np.array_equal(np.asarray(v), stored[k]), k
+
+
+def _replay_free_run(make_system, per_frame):
+    """replays tests/golden/ref_free_run_30_frames.npz through `make_system(cfg, g)` -> object with frame(i, tracked, status, imu, cand),
+    state() and points(); returns the worst state delta against the reference's per-frame states"""
+    M = _golden_io()
+    g = np.load(os.path.join(GOLD, "ref_free_run_30_frames.npz"))
+    cfg = O.abi.config_named("B", enable_equalizer=0)
+    s = make_system(cfg, g)
+    n, worst = len(g["ref_xlen"]), 0.0
+    for i in range(n):
+        s.frame(g["tracked%d" % i], g["status%d" % i], g["imu%d" % i].view(O.abi.IMU_DTYPE), g["cand%d" % i])
+        x, P = s.state()
+        assert len(x) == int(g["ref_xlen"][i]), i                                         # the window grew / slid when the reference's did
+        worst = max(worst, S.state_delta(x, g["ref_x"][i, : len(x)]))
+        if ("pts%d" % i) in g.files:
+            pts, hl = s.points()
+            assert np.array_equal(pts, g["pts%d" % i]) and np.array_equal(hl, g["hist%d" % i]), i   # the reference's own feature table
+        per_frame(s, i, g)
+    scale = float(g["ref_maxP"])
+    assert np.max(np.abs(np.diag(P) - g["ref_diagP"])) <= 1e-6 * scale
+    assert np.max(np.abs(P @ M.probes(P.shape[0]) - g["ref_PV"])) <= 1e-6 * scale
+    return worst
+
+
+def test_free_run_oracle_replays_the_reference_states():
+    """the oracle's System fed the recorded inputs of the reference's free run: every frame's state, the feature tables, the final covariance"""
+    class Sys:
+        def __init__(self, cfg, g):
+            self.s = O.System(cfg)
+            self.s.set_state(g["x0"], g["P0"])
+        def frame(self, tracked, status, imu, cand):
+            self.info = self.s.frame(imu, cand, tracked=tracked, status=status)[0]
+        def state(self):
+            return self.s.get_state()
+        def points(self):
+            return self.s.tracker().get_points()
+
+    def per_frame(s, i, g):
+        if s.info["updated"]:   # (the reference reports an update only through the landmark cloud it publishes: its size is the accepted set)
+            assert int(s.info["n_feat_accepted"]) == int(g["ref_n_cloud"][i]), i
+            counted[0] += 1
+    counted = [0]
+    assert _replay_free_run(Sys, per_frame) <= 1e-11
+    assert counted[0] >= 20

@@ -93,3 +93,38 @@ def test_full_load_update_against_the_reference_written_digest(gpu_required, nam
     assert np.max(np.abs(np.diag(P2) - r[name + "_diagP2"])) <= 1e-9 * scale
     assert np.max(np.abs(P2 @ M.probes(P2.shape[0]) - r[name + "_P2V"])) <= 1e-8 * scale
     assert int(np.count_nonzero(diag["accepted"])) == int(r[name + "_n_cloud"])
+
+
+def test_free_run_replays_the_reference_states(gpu_required):
+    """30 free-running frames from System::initialize (direct-track mode: window filling, the first type-'2' features, the window sliding)
+    on the inputs recorded while the reference's OWN System::MonoVIO ran them (tests/golden/ref_free_run_30_frames.npz): the device must
+    end every frame where the reference did — state <= 1e-6 (observed ~1e-12), the accepted count of every update, the reference's feature
+    tables bit for bit, the final covariance's digest."""
+    import sys
+    from rvio_amd import hip
+    sys.path.insert(0, GOLD)
+    import golden_io as M
+    g = np.load(os.path.join(GOLD, "ref_free_run_30_frames.npz"))
+    cfg = abi.config_named("B", enable_equalizer=0)
+    h = hip.RvioHip(cfg)
+    h.initialize(g["init_w"], g["init_a"], int(g["init_n"]))
+    x, P = h.get_state()
+    assert S.state_delta(x, g["x0"]) <= 1e-12 and np.max(np.abs(P - g["P0"])) <= 1e-12 * np.max(np.abs(g["P0"]))   # System::initialize: the reference's own x0, P0
+    worst, n_upd = 0.0, 0
+    for i in range(len(g["ref_xlen"])):
+        h.frame_points(g["tracked%d" % i], g["status%d" % i], g["imu%d" % i].view(abi.IMU_DTYPE), g["cand%d" % i])
+        x, P = h.get_state()
+        info = h.frame_info()
+        assert len(x) == int(g["ref_xlen"][i]), i
+        worst = max(worst, S.state_delta(x, g["ref_x"][i, : len(x)]))
+        if info["updated"]:
+            assert info["n_feat_accepted"] == int(g["ref_n_cloud"][i]), i
+            n_upd += 1
+        if ("pts%d" % i) in g.files:
+            pts, hl = h.get_points()
+            assert np.array_equal(pts, g["pts%d" % i]) and np.array_equal(hl, g["hist%d" % i]), i
+    h.close()
+    scale = float(g["ref_maxP"])
+    assert n_upd >= 20 and worst <= 1e-6, (n_upd, worst)
+    assert np.max(np.abs(np.diag(P) - g["ref_diagP"])) <= 1e-6 * scale
+    assert np.max(np.abs(P @ M.probes(P.shape[0]) - g["ref_PV"])) <= 1e-6 * scale
