@@ -462,6 +462,7 @@ def main():
                 ncpu = min(len(pin[0]), CPU_WARM + CPU_TIMED)
                 npar = min(ncpu, PARITY_FRAMES)     # the free-running device-vs-CPU comparison keeps its 141 frames (the rank truncation bites from frame 51 on)
                 out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, ncpu)
+                safe_leg(out, "cpu_baseline_reference", cpu_baseline_reference, cfg, pin[0], pin[1], pin[2], pin[3], wi, ai, ni, ncpu, cpu_states[-1][0])
                 if n_frames <= len(cpu_states):
                     xc, Pc = cpu_states[n_frames - 1][0], cpu_states[n_frames - 1][1]
                     out["timed_run_max_state_delta"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(xc))))
@@ -1136,6 +1137,38 @@ def cpu_baseline(cfg, seq, imgs, imu_arr, imu_cnt, cand_arr, cand_cnt, wi, ai, n
                        "reference (kind: port — not Eigen / OpenCV; pinned against the reference's own sources by tests/test_ref_pins.py), g++ -O3, single thread; "
                        "the spans of System.cc:255-260,367 (track; propagate + update + augment + compose), no ROS publishing / debug images / usleep"
                        % (warm, n - 1, warm)}, xs)
+
+
+def cpu_baseline_reference(cfg, imgs, imu_arr, imu_cnt, cand_arr, wi, ai, ni, n, port_end_state=None, timeout=150):
+    """The reference's OWN translation units (oracle/_ref/libref.so: Updater.cc, PreIntegrator.cc, Ransac.cc, Tracker.cc, FeatureDetector.cc,
+    InputBuffer.cc, System.cc compiled unmodified against oracle/refshim/) driven frame by frame through System::MonoVIO on the same frames
+    as cpu_baseline — in a child process with a time-out (tools/cpu_baseline_ref.py: the reference's code can spin forever with 17..31 RANSAC
+    candidates).  libref.so is built where /root/reference exists and travels with the repository snapshot; where it is
+    absent the leg says so.  Test infrastructure, like the oracle: timed here as a baseline only."""
+    import subprocess
+    import tempfile
+    if cand_arr is not None:
+        return {"skipped": "host-corner mode: the reference leg replays the stock configuration (its own FeatureDetector)"}
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")) and not os.path.isdir("/root/reference/src/rvio"):
+        return {"skipped": "oracle/_ref/libref.so is not here (it is built by `make -C oracle ref` where the reference's sources exist)"}
+    warm = CPU_WARM if n >= CPU_WARM + 100 else min(20, n // 4)
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "in.npz")
+        np.savez(f, config=_CFG_NAME[0], equalizer=int(cfg.enable_equalizer), imgs=imgs[:n], imu=imu_arr[:n].view(np.uint8), imu_cnt=imu_cnt[:n],
+                 wi=np.asarray(wi, float), ai=np.asarray(ai, float), ni=int(ni), warm=int(warm))
+        r = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_ref.py"), f], timeout=timeout,
+                                               stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+    if "skipped" in r:
+        return r
+    o = {"value": r["value"], "unit": "frames/s", "cores": 1, "kind": "reference", "frames_timed": r["frames_timed"], "frames_warmup": int(warm),
+         "frame_ms_p50": r["frame_ms_p50"], "frame_ms_p95": r["frame_ms_p95"],
+         "sample": "the same frames as cpu_baseline through System::MonoVIO of the reference's own sources, g++ -O2, single thread, on oracle/refshim: its Eigen is "
+                   "a header of plain loops (no SIMD kernels: the filter stages run slower than on real Eigen) and its OpenCV IMAGE algorithms forward to the port's "
+                   "restatements (the track span is the port's) - so this is the reference's CODE on the host cores, not the Eigen / OpenCV build BASELINE.md names"}
+    if port_end_state is not None:
+        xr = np.array(r["x"])
+        o["max_state_delta_vs_port_after_these_frames"] = float(np.max(np.abs(_qfix(xr) - _qfix(port_end_state)))) if len(xr) == len(port_end_state) else None
+    return o
 
 
 if __name__ == "__main__":
