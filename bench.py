@@ -462,7 +462,6 @@ def main():
                 ncpu = min(len(pin[0]), CPU_WARM + CPU_TIMED)
                 npar = min(ncpu, PARITY_FRAMES)     # the free-running device-vs-CPU comparison keeps its 141 frames (the rank truncation bites from frame 51 on)
                 out["cpu_baseline"], cpu_states = cpu_baseline(cfg, seq, *pin, wi, ai, ni, ncpu)
-                safe_leg(out, "cpu_baseline_reference", cpu_baseline_reference, cfg, pin[0], pin[1], pin[2], pin[3], wi, ai, ni, ncpu, cpu_states[-1][0])
                 if n_frames <= len(cpu_states):
                     xc, Pc = cpu_states[n_frames - 1][0], cpu_states[n_frames - 1][1]
                     out["timed_run_max_state_delta"] = float(np.max(np.abs(_qfix(x_gpu) - _qfix(xc))))
@@ -476,6 +475,8 @@ def main():
                     out["cpu_baseline_multicore"] = _MULTI[0]
                 out["parity"] = parity_leg(cfg, torch, pin, wi, ai, ni, npar, cpu_states)
                 out["max_state_delta_vs_cpu"] = out["parity"]["max_state_delta"]
+                # last, so that nothing above can depend on it: the same frames through the reference's own compiled sources (a child process with a time-out)
+                safe_leg(out, "cpu_baseline_reference", cpu_baseline_reference, cfg, pin[0], pin[1], pin[2], pin[3], wi, ai, ni, ncpu, cpu_states[-1][0])
             except Exception as e:   # noqa: BLE001
                 out.setdefault("cpu_baseline", {"error": repr(e)[:300]})
                 out.setdefault("parity", {"error": repr(e)[:300]})
