@@ -267,3 +267,87 @@ def test_last_bit_noise_per_frame_moves_the_reference_by_1e_7_at_rest():
     noise, mirror = A.study("stationary", frames=100, seeds=2)
     assert max(noise) > 1e-7, noise          # last-bit noise alone reaches 1e-7 (measured 2e-7 .. 2e-6)
     assert mirror < 20 * max(noise) and mirror < 5e-6, (mirror, noise)
+
+
+def _gap_stop(n, types, lens):
+    """greedy fill of the leading rows of R by the accepted features' row counts in the order of their first columns (type '2': columns
+    0..e2, 2 ceil(L/2) - 3 rows; type '1': columns 6(n-L+1)..6n-1, 2L - 3 rows): the position of the first row no feature can fill while
+    later features still wait — a COLUMN GAP —, or -1"""
+    groups = {}
+    for t, L in zip(types, lens):
+        if t == ord("2"):
+            Lu = (int(L) + 1) // 2
+            s, e, rho = 0, 6 * (Lu - 1) - 1, 2 * Lu - 3
+        else:
+            s, e, rho = 6 * (n - (int(L) - 1)), 6 * n - 1, 2 * int(L) - 3
+        if rho > 0:
+            g = groups.setdefault(s, [0, e])
+            g[0] += rho
+            g[1] = max(g[1], e)
+    p = 0
+    for s in sorted(groups):
+        if p < s:
+            return p
+        p = min(p + groups[s][0], groups[s][1] + 1)
+    return -1
+
+
+def test_wider_random_sweep_known_exceptions():
+    """Round 5: 1500 randomised stacks on hand-degenerate windows with ALL length mixes (half / all type '2' / all type '1'; the 400-stack
+    test above draws 'half' only).  The structural rule equals the literal sweep + scan to 1e-9 in all but a handful (measured: 5 of
+    1422 tall updates, 0.35 %; state deltas 1e-8 .. 2e-4), and every one of those belongs to one of two classes the rule does not cover —
+    both are the reference discarding information its scan was not written to discard:
+      (i)  a row whose norm lies just under the scan's 1e-4 threshold WITHOUT being rounding residue (constant-velocity windows: two
+           singular values of the stack at 1e-16, one at 2e-5): the scan stops there, at 6n-2 or 6n-1, and drops the weak but real row(s)
+           behind it; the information form keeps them;
+      (ii) a column gap in a barely tall stack of ~8 features: the type-'1' features that start at one column bring fewer rows than there
+           are columns before the next feature starts, the rows in between are rounding residue (1e-17), the scan stops at the gap and
+           discards every later feature.
+    None of the simulated motions (stock, at rest, rotation, straight line, one depth; direct tracks and images: the tests above and
+    tests/test_gpu_truncation.py) produces either: they need a window made degenerate by hand AND either a handful of features or exactly
+    repeated relative poses.  A device-side literal sweep would close both (restructuring 2)."""
+    synth = O.rv.synth
+    cfg = abi.config_named("B", enable_equalizer=0)
+    n, Fu = 10, abi.fu(cfg)
+    base = [r for r in _run(cfg, 60, image=False, seed=3) if (len(r["x1"]) - 26) // 7 == n][-1]
+    rng = np.random.default_rng(11)
+    tall, exceptions = 0, []
+    for trial in range(1500):
+        x, P = base["x1"].copy(), base["P1"]
+        mode = trial % 4
+        if mode == 1:
+            a = int(rng.integers(0, n - 2))
+            for c in range(a, int(rng.integers(a + 1, n))):
+                x[26 + 7 * c: 33 + 7 * c] = [0, 0, 0, 1, 0, 0, 0]
+        elif mode == 2:
+            for c in range(n):
+                x[30 + 7 * c: 33 + 7 * c] = 0
+        elif mode == 3:
+            for c in range(n):
+                x[26 + 7 * c: 33 + 7 * c] = [0, 0, 0, 1, 0.02, 0.01, 0.0]
+        nf = int(rng.integers(3, Fu + 1))
+        mix = ("half", "all2", "all1")[int(rng.integers(0, 3))]
+        ty, ln, me = synth.worst_case_tracks(cfg, x, n_feat=nf, seed=int(rng.integers(1 << 30)), mix=mix)
+        for f in range(nf):
+            if ty[f] == ord("1") and rng.uniform() < 0.35:
+                L = int(rng.integers(2, ln[f] + 1))
+                me[f, :L] = me[f, ln[f] - L: ln[f]].copy()
+                ln[f] = L
+        x2, P2, d = O.update(cfg, x, P, ty, ln, me)
+        if not d["updated"] or d["n_rows"] <= 6 * n:
+            continue
+        tall += 1
+        xi, Pi, di = O.update_global(cfg, x, P, O.update_local(cfg, x, P, ty, ln, me, 0, 1)[None, :])
+        delta = S.state_delta(x2, xi)
+        if di["truncated_at"] >= 0:
+            assert di["truncated_at"] == d["rank"], trial          # where the rule cuts, it cuts where the reference does
+        if delta > 1e-9:
+            acc = d["accepted"].astype(bool)
+            exceptions.append((trial, mode, d["n_good"], d["n_rows"], d["rank"], _gap_stop(n, ty[acc], ln[acc]), delta))
+    assert tall > 1300
+    assert len(exceptions) <= 8, exceptions                          # measured: 5
+    for trial, mode, n_good, n_rows, rank, gap, delta in exceptions:
+        weak_row = rank >= 6 * n - 2 and mode in (1, 3)              # class (i)
+        column_gap = gap == rank and n_good <= 12 and n_rows <= 6 * n + 20   # class (ii)
+        assert weak_row or column_gap, (trial, mode, n_good, n_rows, rank, gap, delta)
+        assert delta < 1e-3
