@@ -303,9 +303,9 @@ def test_wider_random_sweep_known_exceptions():
       (ii) a column gap in a barely tall stack of ~8 features: the type-'1' features that start at one column bring fewer rows than there
            are columns before the next feature starts, the rows in between are rounding residue (1e-17), the scan stops at the gap and
            discards every later feature.
-    None of the simulated motions (stock, at rest, rotation, straight line, one depth; direct tracks and images: the tests above and
-    tests/test_gpu_truncation.py) produces either: they need a window made degenerate by hand AND either a handful of features or exactly
-    repeated relative poses.  A device-side literal sweep would close both (restructuring 2)."""
+    None of the simulated SEQUENCES (stock, at rest, rotation, straight line, one depth; direct tracks and images: the tests above and
+    tests/test_gpu_truncation.py) produces either; the next test shows that a handful of features is enough (no degenerate window needed).
+    A device-side literal sweep would close both (restructuring 2)."""
     synth = O.rv.synth
     cfg = abi.config_named("B", enable_equalizer=0)
     n, Fu = 10, abi.fu(cfg)
@@ -350,4 +350,50 @@ def test_wider_random_sweep_known_exceptions():
         weak_row = rank >= 6 * n - 2 and mode in (1, 3)              # class (i)
         column_gap = gap == rank and n_good <= 12 and n_rows <= 6 * n + 20   # class (ii)
         assert weak_row or column_gap, (trial, mode, n_good, n_rows, rank, gap, delta)
+        assert delta < 1e-3
+
+
+def test_few_features_on_the_stock_motion_known_exceptions():
+    """The same two classes WITHOUT a degenerate window: the stock motion at the 14-clone window, 3..15 features per update with random
+    type-'1' lengths (a scene with little texture).  Of ~900 tall updates a handful differ from the literal scan by more than 1e-9
+    (measured: 5 — three of class (i), <= 5e-8, inside the 1e-6 bar; two of class (ii), 1.6e-4 and 3.8e-4: five type-'2' features fill
+    columns 0..40, one type-'1' feature of 9 observations carries the rows to position 57, the next feature starts at column 60 — the
+    over-determined type-'2' block's rounding residue sits in the gap, the reference's scan stops at 57 and throws the four later
+    features away).  A generalisation of the rule to a gap at ANY column (drop every feature that starts behind the first gap whenever
+    an over-determined block precedes it) was tried against this sweep and is wrong in 6 % of the stacks: whether residue rows sit in the
+    gap when its column is swept depends on the sweep's row order, which only the sweep itself knows."""
+    synth = O.rv.synth
+    cfg = abi.config_named("A", enable_equalizer=0)
+    n = cfg.max_track_len - 1
+    recs = [r for r in _run(cfg, 4 * n + 30, image=False, seed=3) if (len(r["x1"]) - 26) // 7 == n]
+    rng = np.random.default_rng(103)
+    tall, exceptions = 0, []
+    for trial in range(1500):
+        base = recs[int(rng.integers(0, len(recs)))]
+        x, P = base["x1"].copy(), base["P1"]
+        nf = int(rng.integers(3, 16))
+        mix = ("half", "all2", "all1")[int(rng.integers(0, 3))]
+        ty, ln, me = synth.worst_case_tracks(cfg, x, n_feat=nf, seed=int(rng.integers(1 << 30)), mix=mix)
+        for f in range(nf):
+            if ty[f] == ord("1") and rng.uniform() < 0.5:
+                L = int(rng.integers(2, ln[f] + 1))
+                me[f, :L] = me[f, ln[f] - L: ln[f]].copy()
+                ln[f] = L
+        x2, P2, d = O.update(cfg, x, P, ty, ln, me)
+        if not d["updated"] or d["n_rows"] <= 6 * n:
+            continue
+        tall += 1
+        xi, Pi, di = O.update_global(cfg, x, P, O.update_local(cfg, x, P, ty, ln, me, 0, 1)[None, :])
+        delta = S.state_delta(x2, xi)
+        if di["truncated_at"] >= 0:
+            assert di["truncated_at"] == d["rank"], trial
+        if delta > 1e-9:
+            acc = d["accepted"].astype(bool)
+            exceptions.append((trial, d["n_good"], d["n_rows"], d["rank"], _gap_stop(n, ty[acc], ln[acc]), delta))
+    assert tall > 800
+    assert len(exceptions) <= 8, exceptions                          # measured: 5
+    for trial, n_good, n_rows, rank, gap, delta in exceptions:
+        weak_row = rank >= 6 * n - 3 and delta < 1e-6                # class (i): inside the bar
+        column_gap = gap >= 0 and abs(gap - rank) <= 1 and n_good <= 14   # class (ii) (the gauge of the type-'2' block moves the count by one)
+        assert weak_row or column_gap, (trial, n_good, n_rows, rank, gap, delta)
         assert delta < 1e-3
