@@ -429,3 +429,95 @@ def test_update_on_random_small_and_degenerate_stacks():
             worst = max(worst, delta)
     assert n_upd > 550 and worst <= 1e-9, (n_upd, worst)
     assert worst_repeated < 5e-3 and unstable <= 12, (worst_repeated, unstable)       # measured: 2.7e-4, 4 of ~150
+
+
+def _rand_quat(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    return q * (np.sign(q[3]) if q[3] != 0 else 1.0)
+
+
+def _rand_state(rng, n):
+    x = np.zeros(26 + 7 * n)
+    x[0:4], x[4:7] = _rand_quat(rng), rng.standard_normal(3)
+    g = rng.standard_normal(3)
+    x[7:10], x[10:14] = g / np.linalg.norm(g), _rand_quat(rng)
+    x[14:17], x[17:20], x[20:23], x[23:26] = rng.standard_normal(3) * 0.1, rng.standard_normal(3), rng.standard_normal(3) * 0.01, rng.standard_normal(3) * 0.1
+    for c in range(n):
+        x[26 + 7 * c: 30 + 7 * c], x[30 + 7 * c: 33 + 7 * c] = _rand_quat(rng), rng.standard_normal(3)
+    return x
+
+
+def test_propagate_and_augment_compose_on_random_states():
+    """PreIntegrator::propagate and the System.cc:279-365 block on random states: any window length 0..10, random attitudes / biases / clone
+    poses, covariances of every scale (1e-8 .. 1), 1..29 IMU samples with rates from 1e-7 rad/s (the small-angle branch) to 10 rad/s and
+    sample periods 2.5 .. 50 ms; augmentation and composition with and without a new clone, window full or not.  Observed 2e-15 / 1e-16."""
+    cfg = abi.config_named("B")
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _ in range(150):
+        n = int(rng.integers(0, 11))
+        x, d = _rand_state(rng, n), 24 + 6 * n
+        A = rng.standard_normal((d, d))
+        P = A @ A.T * 10.0 ** rng.integers(-8, 0)
+        m = int(rng.integers(1, 30))
+        imu = np.zeros(m, dtype=abi.IMU_DTYPE)
+        for i in range(m):
+            imu[i]["w"] = rng.standard_normal(3) * (10.0 ** rng.integers(-7, 1))
+            imu[i]["a"] = rng.standard_normal(3) * 5 + [0, 0, 9.8]
+            imu[i]["dt"] = [0.005, 0.0025, 0.01, 0.05][int(rng.integers(0, 4))]
+            imu[i]["t"] = 0.005 * (i + 1)
+        xo, Po = O.propagate(cfg, x, P, imu)
+        xr, Pr = R.propagate(cfg, x, P, imu)
+        worst = max(worst, S.state_delta(xo, xr), float(np.max(np.abs(Po - Pr)) / max(1e-300, np.max(np.abs(Po)))))
+    assert worst <= STAGE_TOL, worst
+    worst = 0.0
+    for _ in range(150):
+        n = int(rng.integers(0, cfg.max_track_len))
+        x, d = _rand_state(rng, n), 24 + 6 * n
+        A = rng.standard_normal((d, d))
+        P = A @ A.T * 1e-3
+        P = 0.5 * (P + P.T)
+        for aug in (0, 1):
+            xo, Po, ppo, pqo = O.augment_compose(cfg, x, P, aug)
+            xr, Pr, ppr, pqr = R.augment_compose(cfg, x, P, aug)
+            assert len(xo) == len(xr)
+            worst = max(worst, S.state_delta(xo, xr), float(np.max(np.abs(Po - Pr)) / np.max(np.abs(Po))), float(np.max(np.abs(ppo - ppr))))
+    assert worst <= STAGE_TOL, worst
+
+
+def test_ransac_on_random_flows():
+    """Ransac::FindInliers on 150 random two-view geometries (33..219 points, 20 % outliers, 10 % of the points lost beforehand, 1..24 gyro
+    samples incl. rates of 1e-8 rad/s: the small-angle branch of the rotation prior), both error metrics, a different rand() seed each time:
+    the 16 index pairs, the winner, the count and the output flags are identical."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(2)
+    runs = 0
+    for t in range(150):
+        N = int(rng.integers(33, 220))
+        p1 = np.column_stack([rng.uniform(-0.6, 0.6, (N, 2)), np.ones(N)])
+        ang = rng.standard_normal(3) * 0.02
+        X = p1 * rng.uniform(1, 10, N)[:, None]
+        X2 = (Rot.from_rotvec(ang).as_matrix() @ X.T).T + rng.standard_normal(3) * 0.05
+        p2 = X2 / X2[:, 2:3]
+        out = rng.uniform(size=N) < 0.2
+        p2[out, :2] += rng.standard_normal((int(out.sum()), 2)) * 0.05
+        flags = (rng.uniform(size=N) < 0.9).astype(np.uint8)
+        if flags.sum() < 32:
+            continue
+        m = int(rng.integers(1, 25))
+        scale = 1e-6 if t % 7 == 0 else 1.0
+        imu = np.zeros(m, dtype=abi.IMU_DTYPE)
+        for i in range(m):
+            imu[i]["w"] = (ang / (m * 0.005) + rng.standard_normal(3) * 0.01) * scale
+            imu[i]["a"], imu[i]["dt"], imu[i]["t"] = [0, 0, 9.8], 0.005, 0.005 * (i + 1)
+        for samp in (1, 0):
+            cfg = abi.config_named("B", use_sampson=samp)
+            nr, fr, pairs, votes = R.ransac(cfg, p1, p2, imu, flags, seed=1 + t)
+            st = np.zeros(35, np.int32)
+            O.lib().orc_srand(O._p(st, O.ip), 1 + t)
+            no, fo, winner, pairs_o, _ = O.ransac(cfg, p1, p2, imu, flags, st)
+            assert nr == no and np.array_equal(fr, fo), (t, samp)
+            assert np.array_equal(pairs, np.asarray(pairs_o).reshape(16, 2)) and int(np.argmax(votes)) == winner, (t, samp)
+            runs += 1
+    assert runs > 250
