@@ -521,3 +521,40 @@ def test_ransac_on_random_flows():
             assert np.array_equal(pairs, np.asarray(pairs_o).reshape(16, 2)) and int(np.argmax(votes)) == winner, (t, samp)
             runs += 1
     assert runs > 250
+
+
+TRACKER_STRESS = [
+    ("drops-30", lambda: abi.config_named("B"), dict(seed=1, drop_prob=0.3)),
+    ("drops-50-fast", lambda: abi.config_named("B"), dict(seed=2, drop_prob=0.5, motion_scale=2.5)),
+    ("cfgA-fast", lambda: abi.config_named("A"), dict(seed=3, drop_prob=0.15, motion_scale=3.0)),
+    ("60-features-big-cells", lambda: abi.config_named("B", n_features=60, block_x=250, block_y=200), dict(seed=4, drop_prob=0.1)),
+    ("lengths-6..9", lambda: abi.config_named("B", min_track_len=6, max_track_len=9), dict(seed=5, drop_prob=0.25)),
+    ("cfgC-400-features", lambda: abi.config_named("C"), dict(seed=6, drop_prob=0.2)),
+]
+
+
+@pytest.mark.parametrize("name,mk,kw", TRACKER_STRESS, ids=[c[0] for c in TRACKER_STRESS])
+def test_tracker_bookkeeping_under_stress(name, mk, kw):
+    """Tracker::track + FindNewer / ChessGrid with many lost features (free slots churn), fast motion (features leave the image), few
+    features in large cells, short tracking-length limits, 400 features: tables and emitted tracks bit-identical frame by frame.  A
+    sequence stops where a frame has 17..31 RANSAC candidates: there the reference's SetPointPair never returns."""
+    cfg = mk()
+    seq = O.rv.synth.SynthSequence(cfg, duration=(38 + 94) / 20.0, **kw)
+    to, tr = O.Tracker(cfg), R.Tracker(cfg)
+    drv = O.rv.synth.DirectTrackDriver(seq)
+    emitted, frames = 0, 0
+    for k in range(39, 39 + 90):
+        inp = drv.inputs(k)
+        if 16 < int(np.count_nonzero(inp["status"])) < 32:
+            break
+        to.track_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        tr.track_points(inp["tracked"], inp["status"], inp["imu"], inp["cand"])
+        po, ho = to.get_points()
+        pr, hr = tr.get_points()
+        assert np.array_equal(po, pr) and np.array_equal(ho, hr), k
+        a, b = to.get_tracks(), tr.get_tracks()
+        assert _tracks_equal(a, b), k
+        emitted += len(a[0])
+        frames += 1
+        drv.after(po)
+    assert frames >= 20 and emitted > 200, (frames, emitted)
