@@ -358,6 +358,8 @@ FREE_RUNS = [
     ("images-min-dist-20", lambda: _small(min_dist=20), 40, True, {}, 12),
     ("images-min-track-5", lambda: _small(min_track_len=5), 50, True, {}, 20),
     ("images-another-seed", lambda: _small(), 50, True, {"seed": 2}, 20),
+    ("images-full-size-752x480", lambda: abi.config_named("B"), 45, True, {}, 25),
+    ("images-full-size-fast-motion", lambda: abi.config_named("B"), 30, True, {"seed": 5, "motion_scale": 2.0}, 15),
 ]
 
 
