@@ -118,7 +118,9 @@ typedef struct rvio_frame_info {
     int32_t ransac_winner;     /* nWinnerHypothesisIdx                          */
     int32_t reserved[5];       /* [0]: sticky device-side error flag: 1 = singular pivot in the solve, 2 = a track the window cannot hold was
                                 * dropped, 4 = a device-side stage counter (filter done -> book-keeping) timed out,
-                                * 8 = a non-positive pivot in a feature's gate matrix S_f (indefinite covariance handed in): that feature was rejected */
+                                * 8 = a non-positive pivot in a feature's gate matrix S_f (indefinite covariance handed in): that feature was rejected
+                                * [1]: nRank of the reference's literal Givens sweep + leading-row scan (Updater.cc:493-523) when this update ran it on the
+                                * device (an update of a handful of features whose rank decision the structure of the stack does not settle), -1 otherwise */
     int32_t rank_truncated_at; /* Updater.cc:516-529: nRank when the leading-row scan cut informative rows off (the type-'1'
                                 * features' rows, dropped from this update), -1 otherwise */
 } rvio_frame_info;

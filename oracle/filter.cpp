@@ -476,6 +476,29 @@ static int stack_rows(const rvio_config* cfg, const double* x, int xdim, const M
     return nRowCount;
 }
 
+// The tall branch of the measurement compression, Updater.cc:474-523, in place: trailing all-zero columns dropped (:482-491), the
+// sequential Givens sweep column by column, rows bottom-up (:496-512), and the leading-row scan (:516-523).  Returns nRank.
+static int givens_compress(Mat& Ho, Mat& roM, int M, int nc6, int* n_cols = nullptr) {
+    int N = nc6;
+    for (int i = N; i > 0; --i) {  // drop trailing all-zero columns :482-491
+        double s = 0; for (int k = 0; k < M; ++k) s += Ho(k, i - 1) * Ho(k, i - 1);
+        if (std::sqrt(s) == 0) N--; else break;
+    }
+    for (int c = 0; c < N; ++c)
+        for (int m = M - 1; m > c; --m) {
+            Givens g = make_givens(Ho(m - 1, c), Ho(m, c));
+            apply_givens_rows(Ho, m - 1, m, c, N - c, g);
+            apply_givens_rows(roM, m - 1, m, 0, 1, g);
+        }
+    int nRank = 0;  // :516-523
+    for (int i = 0; i < M; ++i) {
+        double s = 0; for (int j = 0; j < nc6; ++j) s += Ho(i, j) * Ho(i, j);
+        if (std::sqrt(s) < 1e-4) break; else nRank++;
+    }
+    if (n_cols) *n_cols = N;
+    return nRank;
+}
+
 // U7..U10 (Updater.cc:460-627) on a given stacked pair: Ho = first nRowCount rows of Hw.
 // row_norms (may be NULL): norms of the rows of Ho after the Givens sweep, min(M, 2*nc6) entries (diagnostic).
 static void compress_and_apply(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d, const Mat& P,
@@ -489,23 +512,9 @@ static void compress_and_apply(const rvio_config* cfg, const double* x, int xdim
         std::vector<double> ro(r.begin(), r.begin() + nRowCount);
         Mat Hn; std::vector<double> rn;
         if (nRowCount > nc6) {  // tall :474-529
-            const int M = nRowCount; int N = nc6;
-            for (int i = N; i > 0; --i) {  // drop trailing all-zero columns :482-491
-                double s = 0; for (int k = 0; k < M; ++k) s += Ho(k, i - 1) * Ho(k, i - 1);
-                if (std::sqrt(s) == 0) N--; else break;
-            }
+            const int M = nRowCount;
             Mat roM(M, 1); for (int i = 0; i < M; ++i) roM(i, 0) = ro[i];
-            for (int c = 0; c < N; ++c)
-                for (int m = M - 1; m > c; --m) {
-                    Givens g = make_givens(Ho(m - 1, c), Ho(m, c));
-                    apply_givens_rows(Ho, m - 1, m, c, N - c, g);
-                    apply_givens_rows(roM, m - 1, m, 0, 1, g);
-                }
-            int nRank = 0;  // :516-523
-            for (int i = 0; i < M; ++i) {
-                double s = 0; for (int j = 0; j < nc6; ++j) s += Ho(i, j) * Ho(i, j);
-                if (std::sqrt(s) < 1e-4) break; else nRank++;
-            }
+            const int nRank = givens_compress(Ho, roM, M, nc6);
             if (row_norms)
                 for (int i = 0; i < std::min(M, 2 * nc6); ++i) {
                     double s = 0; for (int j = 0; j < nc6; ++j) s += Ho(i, j) * Ho(i, j);
@@ -595,8 +604,48 @@ void orc_update_from_stack(const rvio_config* cfg, const double* x, int xdim, co
 // complement of A2[e2][e2] is < (1e-4)^2 (the scan's threshold on the row norm),  (d) the stack is tall (rows > 6n).
 //
 // block (per shard; doubles): part0 = type-'2' sum [6n x (6n+1)], part1 = type-'1' sum, then 8 doubles
-//   {n_good, n_rows, rows of type '2', e2 (-1: none), min start column of type '1' (1e9: none), 0, 0, 0}.
+//   {n_good, n_rows, rows of type '2', e2 (-1: none), min start column of type '1' (1e9: none), literal mode, literal nRank, columns swept (6n less the trailing all-zero columns)}.
+//
+// Round 6 — the LITERAL sweep for small stacks (the device: csrc/literal.h).  The structural rule above covers every simulated
+// sequence but not every stack: with a handful of accepted features a column gap or a weak row stops the reference's scan where
+// the rule predicts nothing (tests/test_truncation.py, round 5: 0.2-0.4 % of such updates, up to 2e-3 of state).  So an update
+// that is handed at most ORC_LIT_FEATS features and whose stack is barely tall (rows - 6n <= 8) or has a column gap behind an
+// over-determined group (gap_trigger below) runs the reference's own sequence — Givens nullspace per feature
+// (Updater.cc:370-402: feature_rows above), Givens QR of the stack in the reference's row order + leading-row scan
+// (Updater.cc:493-523: givens_compress) — and hands [A|b] = Rn^T [Rn | zn] of the nRank leading rows to the same solve.
+// Such an update is not sharded: every rank builds every feature, block 0 alone is used (literal mode 1: part0 = the literal
+// [A|b]; 2: the stack was not tall or had <= 2 accepted features — part0/part1 are the plain sums of ALL features).
 static int e2_of(int L) { return 6 * ((int)std::ceil(.5 * L) - 1) - 1; }
+// = LIT_FEATS of csrc/literal.h; the environment variable ORC_LIT_FEATS overrides it (0: the structural rule alone, as up to round 5 — tests / studies)
+static int orc_lit_feats() { const char* e = std::getenv("ORC_LIT_FEATS"); return e ? std::atoi(e) : 24; }
+
+static int orc_lit_slack() { const char* e = std::getenv("ORC_LIT_SLACK"); return e ? std::atoi(e) : 8; }   // = LIT_SLACK of csrc/literal.h
+// A column gap behind an over-determined group (csrc/literal.h:lit_gap_trigger): the accepted features' rows are counted against their
+// column spans in the order of the start columns (type '2': columns 0..e2, rank <= e2 — the scale gauge of a monocular window; type
+// '1': columns 6 (n - L + 1) .. 6n - 1).  True when a column no feature can fill comes up while later features still wait AND a group
+// before it had more rows than its span can hold: the left-over rows of that group are rounding residue, the sweep compacts them
+// into the gap, the reference's scan stops there.
+static bool gap_trigger(int n, const std::vector<int>& types, const std::vector<int>& lens, const std::vector<int>& nrows) {
+    std::vector<int> rows_k(n + 1, 0), end_k(n + 1, -1);
+    bool gauge0 = false, any1_0 = false;
+    for (size_t f = 0; f < types.size(); ++f) {
+        const int L = lens[f];
+        int k, e;
+        if (types[f] == '2') { k = 0; e = e2_of(L); gauge0 = true; }
+        else { k = n - (L - 1); e = 6 * n - 1; if (k == 0) any1_0 = true; }
+        if (k < 0 || k > n || nrows[f] <= 0) continue;
+        rows_k[k] += nrows[f]; end_k[k] = std::max(end_k[k], e);
+    }
+    int p = 0; bool over = false;
+    for (int k = 0; k <= n; ++k) {
+        if (rows_k[k] == 0) continue;
+        if (p < 6 * k) return over;
+        const int cap = (k == 0 && gauge0 && !any1_0 && end_k[k] < 6 * n - 1) ? end_k[k] : end_k[k] + 1;
+        if (p + rows_k[k] > cap) over = true;
+        p = std::min(p + rows_k[k], cap);
+    }
+    return false;
+}
 
 void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const double* Pin, int d,
                       const rvio_tracks* tr, int rank, int world, double* block) {
@@ -607,6 +656,9 @@ void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const d
     Mat Pcc = P.block(24, 24, nc6, nc6);
     for (int i = 0; i < 2 * part + 8; ++i) block[i] = 0;
     int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = 1000000000;
+    const bool lit = tr->n_feat <= orc_lit_feats();
+    if (lit) { rank = 0; world = 1; }
+    std::vector<FeatOut> kept; std::vector<int> kept_types, kept_lens, kept_rows;
     for (int f = rank; f < tr->n_feat; f += world) {
         FeatOut fo = feature_rows(cfg, ex, sig, x, n, Pcc, tr->types[f], tr->meas + (size_t)f * tr->max_len * 2, tr->len[f]);
         if (!fo.accepted) continue;
@@ -621,9 +673,32 @@ void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const d
                 for (int j = 0; j < nc6; ++j) B[i * ld + j] += hi * fo.Hx_(k, j);
                 B[i * ld + nc6] += hi * fo.r_[k];
             }
+        if (lit) { kept.push_back(fo); kept_types.push_back(tr->types[f]); kept_lens.push_back(tr->len[f]); kept_rows.push_back(fo.ndof); }
     }
     double* m = block + 2 * part;
     m[0] = good; m[1] = rows; m[2] = rows2; m[3] = e2; m[4] = smin;
+    if (!lit) return;
+    m[5] = 2;
+    if (!(good > 2 && rows > nc6)) return;
+    if (!(rows - nc6 <= orc_lit_slack() || gap_trigger(n, kept_types, kept_lens, kept_rows))) return;
+    // the literal sweep + scan on the stack in feature order
+    Mat Ho(rows, nc6), roM(rows, 1);
+    int at = 0;
+    for (const FeatOut& fo : kept) {
+        for (int k = 0; k < fo.ndof; ++k) { roM(at + k, 0) = fo.r_[k]; for (int j = 0; j < nc6; ++j) Ho(at + k, j) = fo.Hx_(k, j); }
+        at += fo.ndof;
+    }
+    int nCols = nc6;
+    const int nRank = givens_compress(Ho, roM, rows, nc6, &nCols);
+    for (int i = 0; i < 2 * part; ++i) block[i] = 0;
+    for (int k = 0; k < nRank; ++k)
+        for (int i = k; i < nc6; ++i) {      // (the residue below the diagonal, 1e-17, is not carried: the device's cells do not keep it either)
+            const double hi = Ho(k, i);
+            if (hi == 0) continue;
+            for (int j = k; j < nc6; ++j) block[i * ld + j] += hi * Ho(k, j);
+            block[i * ld + nc6] += hi * roM(k, 0);
+        }
+    m[5] = 1; m[6] = nRank; m[7] = nCols;
 }
 
 // (c) above: eliminate columns 0..e-1 of the leading (e+1)x(e+1) block of A2 (square-root-free, unpivoted; a column whose
@@ -653,6 +728,8 @@ void orc_update_global(const rvio_config* cfg, const double* x, int xdim, const 
     const double sig = sigma_im(cfg), s2 = std::pow(sig, 2);
     Mat A2(nc6, nc6), A1(nc6, nc6); std::vector<double> b2(nc6, 0.0), b1(nc6, 0.0);
     int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = 1000000000;
+    const int lit_mode = (int)blocks[2 * part + 5];   // 0: sharded sums; 1 / 2: the update was small — block 0 holds the whole of it (1: literal [A|b])
+    if (lit_mode) world = 1;
     for (int w = 0; w < world; ++w) {
         const double* B = blocks + (size_t)w * blen;
         for (int i = 0; i < nc6; ++i) {
@@ -662,12 +739,13 @@ void orc_update_global(const rvio_config* cfg, const double* x, int xdim, const 
         const double* m = B + 2 * part;
         good += (int)m[0]; rows += (int)m[1]; rows2 += (int)m[2]; e2 = std::max(e2, (int)m[3]); smin = std::min(smin, (int)m[4]);
     }
-    // the reference's rank truncation (Updater.cc:516-529), structural form (see above)
+    // the reference's rank truncation (Updater.cc:516-529), structural form (see above) — unless the literal scan has taken the decision
     bool truncate = false;
-    if (good > 2 && rows > nc6 && e2 >= 0 && e2 < nc6 && smin < 1000000000 && smin > e2 && rows2 >= e2 + 1)
+    if (lit_mode != 1 && good > 2 && rows > nc6 && e2 >= 0 && e2 < nc6 && smin < 1000000000 && smin > e2 && rows2 >= e2 + 1)
         truncate = !(schur_last(A2, e2) >= 1e-8);
     Mat A = A2; std::vector<double> b = b2;
     if (!truncate) { A = add(A2, A1); for (int i = 0; i < nc6; ++i) b[i] = b2[i] + b1[i]; }
+    if (lit_mode == 1) { e2 = (int)blocks[2 * part + 6]; truncate = e2 < (int)blocks[2 * part + 7]; }   // reported: the literal nRank when the scan stopped early
     if (info) { info[0] = good; info[1] = rows; info[2] = truncate ? e2 : -1; info[3] = 0; }
     if (good <= 2) { std::memcpy(x_out, x, sizeof(double) * xdim); std::memcpy(P_out, Pin, sizeof(double) * d * d); return; }
     // Reuse ekf_apply with the Cholesky-free equivalent pair: eigen-free route —

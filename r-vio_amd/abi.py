@@ -54,6 +54,7 @@ class rvio_frame_info(C.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         if hasattr(self, "reserved"):
             d["device_error"] = int(self.reserved[0])   # sticky: 1 singular pivot, 2 track the window cannot hold, 4 a device-side stage counter timed out, 8 indefinite gate matrix
+            d["literal_rank"] = int(self.reserved[1])   # nRank of the reference's literal Givens sweep + scan when the device ran it for this update (csrc/literal.h), -1 otherwise
         return d
 
 

@@ -26,6 +26,7 @@
 #include "../../include/rvio_hip.h"
 #include "solve9.hip"   // (the dx / state-injection roles of the split solve ride in ug_tile_kernel<0>)
 
+#include "literal.h"   // round 6: the literal Givens sweep + rank scan for small stacks (lit_decide / lit_finish)
 __device__ const double kChi2Dev[500] = {
 #include "chi2_table.inc"
 };
@@ -58,13 +59,14 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                                                 int shard_rank, int shard_world,
                                                 double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                 double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta, const int f,
-                                                const double* gpose = nullptr, const int* gvalid = nullptr) {
+                                                const double* gpose = nullptr, const int* gvalid = nullptr, double* lit_rows = nullptr) {
     extern __shared__ __align__(16) double lds[];
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
     ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
     if (tm_global) tm_global = zoffi(tm_global, bs, bi.z);
     if (gpose) { gpose = zoffi(gpose, bs, bi.z); gvalid = zoffi(gvalid, bs, bi.z); }
+    if (lit_rows) lit_rows = zoffi(lit_rows, bs, bi.z);
     n_feat_ptr = zoffi(n_feat_ptr, bin.n_feat, bi.z); types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z); meas = zoffi(meas, bin.meas, bi.z);
     const int tid = threadIdx.x, T = blockDim.x;   // f: the feature slot of this pass
     const int c6 = 6 * n, ldh = cfg.ldh, ld = cfg.dmax;
@@ -84,7 +86,10 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     double* S = p;
     // ---- one batch of global reads: feature header, its observations, the clone poses
     const int n_feat = *n_feat_ptr;
-    if (f >= n_feat || (f % shard_world) != shard_rank) {   // empty slot / another rank's feature: leave before touching anything else
+    // an update of at most LIT_FEATS features is not sharded (every rank builds every feature, block 0 alone is used: block_sum_kernel) and
+    // exports the accepted features' rows: the reference's literal sweep may have to run on them (literal.h)
+    const bool lit = lit_rows && n_feat <= LIT_FEATS;
+    if (f >= n_feat || (!lit && (f % shard_world) != shard_rank)) {   // empty slot / another rank's feature: leave before touching anything else
         if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
         return;
     }
@@ -366,6 +371,17 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     }
     __syncthreads();
     DBG_T(35);
+    if (lit) {   // the RAW block [Hx | r] (rows 0..M2-1, columns [cLo, cHi) and the residual column c6) and Hf, before the projection below: literal.h
+        double* lr = lit_rows + (size_t)f * M2max * ldh;
+        double* lh = lit_rows + (size_t)LIT_FEATS * M2max * ldh + (size_t)f * M2max * 3;
+        const int wraw = cHi - cLo + 1;
+        for (int e = tid; e < M2 * wraw; e += T) {
+            const int i = e / wraw, k = e - i * wraw, col = (k < wraw - 1) ? cLo + k : c6;
+            lr[(size_t)i * ldh + col] = Hx[(size_t)i * ldh + col];
+        }
+        for (int e = tid; e < M2 * 3; e += T) lh[e] = hf[e];
+        __syncthreads();
+    }
     N = (int)misc[7];
     {
         const int nact = (cHi - cLo) + 1;   // active columns + the residual column
@@ -560,9 +576,9 @@ __global__ __launch_bounds__(HOIST > 4 ? 256 : 1024) void feat_build_kernel(DevC
                                   int shard_rank, int shard_world,
                                   double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                   double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta,
-                                  const double* gpose, const int* gvalid) {
+                                  const double* gpose, const int* gvalid, double* lit_rows) {
     feat_build_body<HOIST>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out,
-                           tm_global, bs, bin, meta, (int)blockIdx.x, gpose, gvalid);
+                           tm_global, bs, bin, meta, (int)blockIdx.x, gpose, gvalid, lit_rows);
 }
 
 // =============================================================== U1 + U2, four features per wave (batch handles, max_len <= 16)
@@ -806,20 +822,24 @@ __device__ void trunc_finish(const DevCfg& cfg, int n, double* A, const double* 
     }
     if (tid == 0) {
         double* mr = A + (size_t)ldh * (ldh - 1);
-        mr[0] = (double)good; mr[1] = (double)rows; mr[2] = truncate ? (double)e2 : -1.0;
+        mr[0] = (double)good; mr[1] = (double)rows; mr[2] = truncate ? (double)e2 : -1.0; mr[5] = -1.0;
     }
 }
 
 // block = this shard's [S2 | S1] + counters: the sums of the accepted features' shares G_f (written by feat_build_kernel to partial[f]) in
 // ascending feature order — deterministic; also the all-gather payload of the sharded updater.  combine = 1 (unsharded update): the
 // workgroup that finishes last turns part 0 into [A|b] in place (trunc_finish), so no further launch is needed.
+// lit: the literal sweep for small stacks (literal.h) — rows exported by feat_build_kernel, the state of the array (lit.state == nullptr: in this
+// launch's dynamic LDS, behind lit_aux_doubles()), the features handed to the update
+struct LitArgs { double* rows; double* state; const int* n_feat; size_t lds_doubles; };   // lds_doubles: the dynamic LDS of the launch that may run lit_finish
 __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, const double* partial, const int* nrows,
                                                           const unsigned char* types, const int* lens, double* block, int* cnt, int combine,
-                                                          int wide, size_t bs, BatchIn bin) {
+                                                          int wide, size_t bs, BatchIn bin, LitArgs lit) {
     extern __shared__ __align__(16) double g_dyn[];
     const BatchIdx bi = batch_plain();
     partial = zoffi(partial, bs, bi.z); nrows = zoffi(nrows, bs, bi.z); block = zoffi(block, bs, bi.z); cnt = zoffi(cnt, bs, bi.z);
     types = zoffi(types, bin.types, bi.z); lens = zoffi(lens, bin.len, bi.z);
+    if (lit.rows) { lit.rows = zoffi(lit.rows, bs, bi.z); lit.n_feat = zoffi(lit.n_feat, bin.n_feat, bi.z); if (lit.state) lit.state = zoffi(lit.state, bs, bi.z); }
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
     DBG_T(41);
@@ -871,6 +891,17 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         if (tid == 0) { s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin; }
     }
     __syncthreads();
+    // a small stack whose rank decision the structure does not settle (literal.h): block 0 runs the reference's sweep + scan on the exported
+    // rows and writes [A|b] itself; the shares are not needed.  (Unsharded update only: a shard's counters are partial — there the decision
+    // is taken on the gathered whole, block_sum_kernel.)
+    if (combine && lit.rows) {
+        const int nf = *lit.n_feat;
+        if (lit_decide(lit.rows, n, nf, s_cnt[0], s_cnt[1], nrows, types, lens)) {
+            if (bi.x != 0) return;
+            lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), g_dyn, lit.lds_doubles);
+            return;
+        }
+    }
     // can the reference's rank scan cut the type-'1' rows off at all (structural precondition of trunc_finish)?  Almost never: then
     // [A|b] = S2 + S1 is written directly, mirror image included, and nobody has to wait for the last workgroup
     const bool cand = s_cnt[0] > 2 && s_cnt[1] > c6 && s_cnt[3] >= 0 && s_cnt[3] < c6 && s_cnt[4] < TR_NONE && s_cnt[4] > s_cnt[3] && s_cnt[2] >= s_cnt[3] + 1;
@@ -941,7 +972,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     }
     DBG_T(44);
     if (direct) {
-        if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; }
+        if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; mr[5] = -1.0; }
         return;
     }
     if (!combine) {
@@ -1064,7 +1095,7 @@ __global__ __launch_bounds__(256) void gram_reduce_batch_kernel(DevCfg cfg, int 
         __syncthreads();
     }
     if (!cand) {
-        if (tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; }
+        if (tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; mr[5] = -1.0; }
         return;
     }
     __threadfence();
@@ -1072,13 +1103,33 @@ __global__ __launch_bounds__(256) void gram_reduce_batch_kernel(DevCfg cfg, int 
     trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], gb_dyn);
 }
 
+// Batch handles whose share reduction is gram_reduce_batch_kernel (a throughput kernel: 64 VGPRs, eight waves per SIMD — the literal sweep inside it
+// would cost it three quarters of that): the literal path as a launch of its own behind the reduction, one workgroup per instance, which leaves at
+// once unless literal.h's decision holds for its instance (the counters come from the meta row the reduction wrote; the array's state lives in the slab).
+__global__ __launch_bounds__(256) void lit_batch_kernel(DevCfg cfg, int n, const int* __restrict__ nrows, const unsigned char* __restrict__ types,
+                                                        const int* __restrict__ lens, double* __restrict__ block, size_t bs, BatchIn bin, LitArgs lit) {
+    extern __shared__ __align__(16) double lb_dyn[];
+    const int z = blockIdx.z;
+    nrows = zoffi(nrows, bs, z); block = zoffi(block, bs, z); types = zoffi(types, bin.types, z); lens = zoffi(lens, bin.len, z);
+    lit.rows = zoffi(lit.rows, bs, z); lit.n_feat = zoffi(lit.n_feat, bin.n_feat, z); lit.state = zoffi(lit.state, bs, z);
+    const double* mr = block + (size_t)cfg.ldh * (cfg.ldh - 1);
+    const int good = (int)mr[0], rows = (int)mr[1], nf = *lit.n_feat;
+    if (!lit_decide(lit.rows, n, nf, good, rows, nrows, types, lens)) return;
+    lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, good, rows, lit.state, lb_dyn, lit.lds_doubles);
+}
+
 // Gathered shards (rank-major, `block_stride` doubles apart) -> Ab = [A|b] + {n_good, n_rows, truncation column}: both parts are summed
 // in rank order (Ab <- S2, Ab + ldh^2 <- S1), then the workgroup that finishes last applies trunc_finish.
-__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const double* blocks, int world, size_t block_stride, double* Ab, int* cnt) {
+// An update of at most LIT_FEATS features was not sharded (feat_build_body: every rank built every feature): block 0 alone is the whole
+// of it, and the last workgroup may have to run the literal sweep on the (local, complete) exported rows (literal.h).
+__global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const double* blocks, int world, size_t block_stride, double* Ab, int* cnt,
+                                                        const int* nrows, const unsigned char* types, const int* lens, LitArgs lit) {
     extern __shared__ __align__(16) double g_dyn[];
     const int c6 = 6 * n, ldh = cfg.ldh;
     const int total = c6 * ldh;
     const size_t gs = (size_t)ldh * ldh;
+    const int nf = lit.rows ? *lit.n_feat : LIT_FEATS + 1;
+    if (nf <= LIT_FEATS) world = 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int q = e % ldh;
         if (q > c6 || (q >> 4) < ((e / ldh) >> 4)) continue;     // the shards carry the tiles on and above the diagonal
@@ -1097,6 +1148,10 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
         s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin;
     }
     __syncthreads();
+    if (lit_decide(lit.rows, n, nf, s_cnt[0], s_cnt[1], nrows, types, lens)) {
+        lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, Ab, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), g_dyn, lit.lds_doubles);
+        return;
+    }
     trunc_finish(cfg, n, Ab, Ab + gs, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
 }
 

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         const int* n_feat_ptr, const unsigned char* types, const int* lens, const float* meas,
                                                         double* Gshare, int* nrows_out, int* acc_out, int* ndof_out, double* gamma_out,
                                                         double* pfinv_out, double* tm_global, BatchIn bin,
-                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* chol_scr, int chol_nt, int shard_rank, int shard_world) {
+                                                        FilterMeta* meta, const rvio_imu* imu, int m, double* chol_scr, int chol_nt, int shard_rank, int shard_world,
+                                                        double* lit_rows) {
     DBG_R(blockIdx.x == 0, 0);
     extern __shared__ __align__(16) double fp_dyn[];
     if (blockIdx.x == gridDim.x - 1) { propagate_body<16>(cfg, meta, n, x, P, imu, m, 0, 0, *reinterpret_cast<Prop3Lds<16>*>(fp_dyn)); return; }   // (its LDS: the launch's dynamic LDS)
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
         else s9_chol_role<3>(cfg, n, P, chol_scr, *reinterpret_cast<S9CholLds<6, 4>*>(fp_dyn));
         return;
     }
-    feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta, (int)blockIdx.x);
+    feat_build_body<16>(cfg, n, x, P, n_feat_ptr, types, lens, meas, shard_rank, shard_world, Gshare, nrows_out, acc_out, ndof_out, gamma_out, pfinv_out, tm_global, 0, bin, meta, (int)blockIdx.x, nullptr, nullptr, lit_rows);
 }
 
 // =============================================================== S1 + S2 fused (v2): augmentation/slide + composition

@@ -65,6 +65,12 @@ struct rvio_hip {
     double* gpose = nullptr;   // batch handles (max_len <= 16): the pose chains geom4_kernel leaves for feat_build_kernel<4>, [Fu][(max_len-1) x 24]
     int* gvalid = nullptr;     // ... and the validity flag of each triangulation
     size_t trunc_lds = 0, gram_batch_lds = 0;   // gram_batch_lds != 0: batch handle whose [A|b] fits in LDS (gram_reduce_batch_kernel)
+    // round 6 (literal.h): the rows of an update of <= LIT_FEATS features, exported by the per-feature kernel for the reference's literal sweep; the
+    // state of the systolic array when it does not fit in the reduction's LDS (long windows, batch handles); nullptr: no literal path on this handle
+    double *lit_rows = nullptr, *lit_state = nullptr;
+    bool lit_state_global = false;
+    size_t lit_batch_lds = 0;                   // dynamic LDS of lit_batch_kernel
+    const double* last_Ab = nullptr;            // the [A|b] block of the last update (its meta row: frame_info)
     int feat_threads = 64;
     size_t feat_lds = 0, fprop_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
     int solve5_variant = 0;      // solve6_kernel (the LDS-tableau solve behind gemm_T_kernel: batch handles): 0 none, 1: <1,8,8>  2: <2,12,8>  3: <2,16,8>
@@ -332,6 +338,11 @@ static int alloc_filter_slab(rvio_hip* h, bool need_tm_global) {
     DALLOC(h, h->d_info, 1); DALLOC(h, h->d_pose, 8);
     DALLOC(h, t.n_feat, 1); DALLOC(h, t.types, d.Fu); DALLOC(h, t.len, d.Fu); DALLOC(h, t.meas, (size_t)2 * d.Fu * d.max_len);
     if (need_tm_global) DALLOC(h, h->tm_global, (size_t)d.Fu * d.rho_max * ldh);
+    static const bool no_lit = getenv("RVIO_NO_LITERAL") != nullptr;   // A/B: the structural rank rule alone, as up to round 5
+    if (!no_lit && d.ldh <= 190 && d.nmax + 1 <= 40 && d.rho_max < 254 && lit_slab_doubles(d.ldh, d.rho_max) * sizeof(double) <= 144 * 1024) {
+        DALLOC(h, h->lit_rows, lit_rows_doubles(d.ldh, d.rho_max));
+        if (h->lit_state_global) DALLOC(h, h->lit_state, lit_state_doubles(d.ldh - 1));
+    }
     static const bool no_geom4 = ab_env("RVIO_NO_GEOM4") != nullptr;   // A/B timing
     if (h->batch > 1 && d.max_len <= GEOM4_ML && !no_geom4) { DALLOC(h, h->gpose, (size_t)d.Fu * (d.max_len - 1) * 24); DALLOC(h, h->gvalid, d.Fu); }
     return RVIO_OK;
@@ -468,6 +479,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     h->feat_threads = (d.ldh <= 128) ? 128 : 256;
     if (const char* ft = ab_env("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->trunc_lds = trunc_lds_doubles(d.max_len) * sizeof(double);
+    {   // the literal sweep runs in the workgroup that finishes the reduction (literal.h): its ring / rotation tables always in that launch's LDS, the
+        // array's state too when it fits (gram_reduce_kernel holds ~11 KB of static LDS) — else, and for batch handles (occupancy), in the slab
+        const size_t aux = lit_aux_doubles(d.ldh, d.rho_max) * sizeof(double), st = lit_state_doubles(d.ldh - 1) * sizeof(double);
+        const size_t slab = lit_slab_doubles(d.ldh, d.rho_max) * sizeof(double);   // (a feature's raw block for the nullspace sweep: at least one must fit)
+        h->lit_state_global = batch > 1 || aux + st > 144 * 1024;
+        h->lit_batch_lds = std::max(aux, slab);
+        h->trunc_lds = std::max(h->trunc_lds, std::max(h->lit_state_global ? aux : aux + st, std::min((size_t)4, (size_t)(144 * 1024) / slab) * slab));
+    }
     h->feat_lds = feat_lds_doubles(d.max_len, d.ldh, true) * sizeof(double);
     bool need_tm_global = false;
     // (a batch handle keeps T in global memory as well: a third less LDS per feature workgroup = 8 instead of 5 resident per CU)
@@ -523,6 +542,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)lit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lit_batch_lds));
     if (batch > 1 && gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double) <= 64 * 1024) {
         h->gram_batch_lds = gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void*)gemm_T_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(double)));
@@ -837,6 +857,7 @@ static int upload_tracks(rvio_hip* h, const rvio_tracks* tr) {
     return RVIO_OK;
 }
 
+static LitArgs lit_args(const rvio_hip* h, size_t lds_bytes) { return LitArgs{h->lit_rows, h->lit_rows ? h->lit_state : nullptr, h->t.n_feat, lds_bytes / sizeof(double)}; }
 // the share reduction of a batch handle whose [A|b] fits in LDS (6n <= 90): tiles of 16, 4 x 4 up to 6n = 63, 6 x 6 beyond
 static void launch_gram_batch(rvio_hip* h, int n) {
     const dim3 g(1, 1, h->batch), b(256);
@@ -844,6 +865,9 @@ static void launch_gram_batch(rvio_hip* h, int n) {
         hipLaunchKernelGGL(gram_reduce_batch_kernel<4>, g, b, h->gram_batch_lds, h->stream, h->dc, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, h->slab_bytes, h->bin);
     else
         hipLaunchKernelGGL(gram_reduce_batch_kernel<6>, g, b, h->gram_batch_lds, h->stream, h->dc, n, h->partial, h->nrows, h->t.types, h->t.len, h->block, h->slab_bytes, h->bin);
+    if (h->lit_rows)   // the literal sweep for the instances whose small stacks need it (literal.h)
+        hipLaunchKernelGGL(lit_batch_kernel, g, b, h->lit_batch_lds, h->stream, h->dc, n, (const int*)h->nrows,
+                           (const unsigned char*)h->t.types, (const int*)h->t.len, h->block, h->slab_bytes, h->bin, lit_args(h, h->lit_batch_lds));
 }
 
 static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
@@ -858,21 +882,21 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
         const int extra = 1 + (chol ? 1 : 0);
         hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + extra), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                            h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
-                           h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt, rank, world);
+                           h->meta, h->fuse_imu, h->fuse_m, cs, h->solve9_nt, rank, world, h->lit_rows);
         h->chol_ready = chol;
         h->fuse_m = -1;
     } else
     if (B == 1)   // one stream: the latency form (every operand load of a gate tile in flight at once)
     hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global, bs, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr);
+                       h->tm_global, bs, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr, h->lit_rows);
     else {
     if (h->gpose)   // U1 + U2 four features per wave, ahead of the per-feature kernel (which then only fetches the pose chain and the triple)
         hipLaunchKernelGGL(geom4_kernel, dim3((d.Fu + 3) / 4, 1, B), dim3(64), 0, h->stream, d, n, h->x[h->cur], h->t.n_feat, h->t.types, h->t.len, h->t.meas,
                            h->gpose, h->pfinv, h->gvalid, bs, h->bin);
     hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, B), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                        h->t.n_feat, h->t.types, h->t.len, h->t.meas, rank, world, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv,
-                       h->tm_global, bs, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid);
+                       h->tm_global, bs, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid, h->lit_rows);
     }
     // unsharded: the last workgroup turns the block into [A|b] in place (rank truncation included); sharded: the block is the payload
     // one stream: 64 elements per workgroup (the shares are remote reads: spread them over many CUs); batch handles: 256 (fewer, fuller workgroups)
@@ -882,7 +906,7 @@ static int update_local_dev(rvio_hip* h, int rank, int world, bool combine) {
         launch_gram_batch(h, n);
     else
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + gram_chunk - 1) / gram_chunk)), 1, B), dim3(256), h->trunc_lds, h->stream, d, n,
-                       h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, (B == 1) ? 1 : 0, bs, h->bin);
+                       h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, (world == 1 && combine) ? 1 : 0, (B == 1) ? 1 : 0, bs, h->bin, lit_args(h, h->trunc_lds));
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
 }
@@ -1013,7 +1037,8 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
     if (B > 1 && !combined) { h->err = "a batch handle runs the unsharded updater only"; return RVIO_ERR_UNSUPPORTED; }
     if (!combined) {   // gathered shards [S2 | S1]: sum both parts in rank order, then the rank truncation -> Ab = [A|b]
         const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
-        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), h->trunc_lds, h->stream, d, n, d_blocks, world, (size_t)(2 * ldh * ldh), h->Ab, h->gram_cnt);
+        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), h->trunc_lds, h->stream, d, n, d_blocks, world, (size_t)(2 * ldh * ldh), h->Ab, h->gram_cnt,
+                           (const int*)h->nrows, (const unsigned char*)h->t.types, (const int*)h->t.len, lit_args(h, h->trunc_lds));
         Ab = h->Ab;
     }
     const int tt = (c6 + 31) / 32;
@@ -1024,6 +1049,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
         else
             hipLaunchKernelGGL(gemm_T_kernel, dim3(tt, tt, B), dim3(256), 0, h->stream, d, n, Ab, Pc, h->Tbuf, bs);
     }
+    h->last_Ab = Ab;
     launch_solve(h, n, Ab, /*defer_dx=*/true);
     launch_ug_final(h, n, Ab, Pn, true, true);
     HIPCHK(h, hipGetLastError());
@@ -1847,11 +1873,14 @@ int rvio_hip_get_frame_info(rvio_hip* h, rvio_frame_info* info) {
     HIPCHK(h, hipSetDevice(h->device));
     SYNC_FRONT(h);   // image / side / tracker streams first
     FilterMeta m;
+    double lit_rank = -1.0;
     HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof *info, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&m, h->meta, sizeof m, hipMemcpyDeviceToHost, h->stream));
+    if (h->last_Ab) HIPCHK(h, hipMemcpyAsync(&lit_rank, h->last_Ab + (size_t)h->dc.ldh * (h->dc.ldh - 1) + 5, sizeof lit_rank, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     info->n_clones = h->n_clones_host; info->n_feat_accepted = m.n_good; info->n_rows = m.n_rows; info->updated = m.updated;
     info->reserved[0] = m.err;
+    info->reserved[1] = (m.updated && lit_rank >= 0) ? (int)lit_rank : -1;
     info->rank_truncated_at = m.updated ? m.trunc_at : -1;
     if (m.err & 4) { h->err = "a device-side stage counter timed out (filter -> book-keeping): the frame sequence is invalid, re-initialise"; return RVIO_ERR_STATE; }
     return RVIO_OK;
@@ -1965,16 +1994,16 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             if (h->batch == 1)
             hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
-                               h->slab_bytes, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr);
+                               h->slab_bytes, h->bin, h->meta, (const double*)nullptr, (const int*)nullptr, h->lit_rows);
             else
             hipLaunchKernelGGL(feat_build_kernel<4>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
                                h->t.n_feat, h->t.types, h->t.len, h->t.meas, 0, 1, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global,
-                               h->slab_bytes, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid);
+                               h->slab_bytes, h->bin, h->meta, (const double*)h->gpose, (const int*)h->gvalid, h->lit_rows);
         } else if (which == 3 && h->batch >= 128 && h->gram_batch_lds) {
             launch_gram_batch(h, n);
         } else if (which == 3) {   // reduction of the per-feature shares + rank truncation (reads `partial`, rewrites `block`: idempotent)
             hipLaunchKernelGGL(gram_reduce_kernel, dim3(std::max(1, std::min(1024, (6 * n * d.ldh + (h->batch == 1 ? 63 : 255)) / (h->batch == 1 ? 64 : 256))), 1, h->batch), dim3(256), h->trunc_lds, h->stream, d, n,
-                               h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin);
+                               h->partial, h->nrows, h->t.types, h->t.len, h->block, h->gram_cnt, 1, (h->batch == 1) ? 1 : 0, h->slab_bytes, h->bin, lit_args(h, h->trunc_lds));
         } else if (which == 4 || which == 5) {   // U, G, P1 strips / the Joseph form on the operands of the last update, in the form the handle launches
             launch_ug_final(h, n, h->block, h->P[h->cur ^ 1], which == 4, which == 5);   // (outputs: scratch / the spare covariance buffer, overwritten by the next stage anyway)
         } else if (which == 7) {   // U, G, P1 + the Joseph form as the handle launches them for a whole update (one instance, 6n <= 60: ONE kernel)

@@ -1,0 +1,236 @@
+"""Round 6: the reference's measurement compression LITERALLY on the device (csrc/literal.h: sequential Givens QR in the reference's row
+order as a systolic array + the leading-row rank scan, Updater.cc:493-529) for the small stacks whose rank decision the structure of the
+stack does not settle — replayed against the reference's OWN Updater::update (oracle/_ref/libref.so, the reference's sources compiled
+unmodified) on the random sweeps that exposed the failure class in round 5:
+
+  * tests/test_truncation.py::sweep_few    1500 stacks, stock motion, 14-clone window, 3..15 features (round 5: 1.6e-4 and 3.8e-4)
+  * tests/test_truncation.py::sweep_wider  1500 stacks, hand-degenerate 10-clone windows, 3..100 features (round 5: up to 2e-4)
+  * the 600 stacks of tests/test_ref_pins.py::test_update_on_random_small_and_degenerate_stacks
+
+Bar: 1e-9 per state for every update outside the windows of exactly repeated relative poses (there the reference disagrees with itself
+by up to 3e-4: tests/test_ref_pins.py) and 1e-6 inside that class — EXCEPT where the reference's own result is decided by rounding noise:
+a stack whose Gram matrix is singular before its last column (the scale gauge of the type-'2' block) leaves the rows of R behind the
+dependent column as a mixture whose angle is makeGivens(residue, residue) — +-1 ulp on the entries of the stacked Hw moves the
+reference's nRank by one and its state by 4e-8 .. 9e-8 in exactly the updates where the device sits 2e-8 away (_reference_noise; three
+of 912 tall updates of the stock-motion sweep).  There the device is held to 4 x the reference's own last-bit noise, measured per case."""
+import numpy as np
+import pytest
+
+import oracle as O
+import ref as R
+import scenarios as S
+import test_truncation as TT
+
+abi, rv = O.abi, O.rv
+pytestmark = pytest.mark.gpu
+
+
+def _reference_update(cfg, x, P, ty, ln, me):
+    """the reference's own Updater::update when libref is on the box, else its restatement (pinned to it <= 1e-9: tests/test_ref_pins.py)"""
+    xo, Po, dg = O.update(cfg, x, P, ty, ln, me)
+    if R.available():
+        xr, Pr, d = R.update(cfg, x, P, ty, ln, me)
+        return xr, Pr, bool(d["updated"]), d["n_cloud"], dg
+    return xo, Po, bool(dg["updated"]), dg["n_good"], dg
+
+
+def _reference_noise(cfg, x, P, ty, ln, me, draws=12):
+    """how far the reference's literal result moves when every non-zero entry of the stacked Hw moves by +-1 ulp (less than two correct
+    implementations of U1-U4 differ by): (max state delta over the draws, the set of nRank values seen)"""
+    Hw, r, ng = O.update_stack(cfg, x, P, ty, ln, me)
+    x0, _, d0 = O.update_from_stack(cfg, x, P, Hw, r, ng)
+    rng = np.random.default_rng(1)
+    worst, ranks = 0.0, {d0["rank"]}
+    for _ in range(draws):
+        up = rng.integers(0, 2, Hw.shape) > 0
+        Hp = np.where(Hw != 0, np.nextafter(Hw, np.where(up, np.inf, -np.inf)), 0.0)
+        xp, _, dp = O.update_from_stack(cfg, x, P, Hp, r, ng)
+        worst = max(worst, S.state_delta(xp, x0))
+        ranks.add(dp["rank"])
+    return worst, ranks
+
+
+def _replay(sweep, excused=lambda mode: False):
+    """every stack of the sweep through rvio_hip_set_state + rvio_hip_update; returns counters and the exceptions > 1e-9"""
+    from rvio_amd import hip
+    handles = {}
+    out = dict(updates=0, tall=0, literal=0, worst=0.0, worst_P=0.0, worst_excused=0.0, exceptions=[], rank_mismatch=[], noise_decided=[], rounding_level=[])
+    for trial, mode, cfg, n, x, P, ty, ln, me in sweep:
+        key = (cfg.max_track_len, cfg.n_features)
+        if key not in handles:
+            handles[key] = hip.RvioHip(cfg)
+        h = handles[key]
+        xr, Pr, upd, n_acc, dg = _reference_update(cfg, x, P, ty, ln, me)
+        h.set_state(x, P)
+        h.update(ty, ln, me)
+        xd, Pd = h.get_state()
+        info = h.frame_info()
+        assert info["device_error"] == 0, (trial, info)
+        assert bool(info["updated"]) == upd, trial
+        if not upd:
+            continue
+        assert info["n_feat_accepted"] == n_acc, trial
+        out["updates"] += 1
+        tall = dg["n_rows"] > 6 * n
+        out["tall"] += tall
+        lit_rank = info["literal_rank"]
+        if lit_rank >= 0:
+            out["literal"] += 1
+            assert tall and len(ln) <= 24, trial
+            if lit_rank != dg["rank"]:      # acceptable only where the reference's own nRank moves under last-bit noise
+                out["rank_mismatch"].append((trial, mode, lit_rank, dg["rank"], sorted(_reference_noise(cfg, x, P, ty, ln, me, draws=24)[1])))
+        delta, delta_P = S.state_delta(xd, xr), float(np.max(np.abs(Pd - Pr)) / np.max(np.abs(Pr)))
+        if excused(mode):
+            out["worst_excused"] = max(out["worst_excused"], delta, delta_P)
+        else:
+            out["worst"] = max(out["worst"], delta)
+            out["worst_P"] = max(out["worst_P"], delta_P)
+            if delta > 1e-9 or delta_P > 1e-8:       # per-state 1e-9 (the stage-parity bar of this suite); covariance 1e-8 relative to its largest entry
+                noise, ranks = _reference_noise(cfg, x, P, ty, ln, me)
+                rec = (trial, mode, dg["n_good"], dg["n_rows"], dg["rank"], lit_rank, delta, delta_P, noise, sorted(ranks))
+                if delta <= 4 * noise and delta_P <= 1e-8:      # the reference itself moves that much under last-bit noise: parity is not defined more finely
+                    out["noise_decided"].append(rec)
+                elif lit_rank < 0 and delta <= 1e-8 and delta_P <= 1e-8:
+                    # no rank decision involved (information form, many rows): the rounding of another order of summation in a stack of hundreds of
+                    # rows — measured 1.1e-9 .. 2.9e-9 in 4 of ~3600 random stacks, the largest two on windows with every relative translation zero
+                    out["rounding_level"].append(rec)
+                else:
+                    out["exceptions"].append(rec)
+    for h in handles.values():
+        h.close()
+    return out
+
+
+def test_few_features_on_the_stock_motion_against_the_reference(gpu_required):
+    """1500 stacks of 3..15 features on the stock motion at the 14-clone window: zero exceptions > 1e-9 (round 5: 1.6e-4 / 3.8e-4 where a column
+    gap stops the reference's scan), and where the literal sweep ran, its nRank is the reference's"""
+    o = _replay(TT.sweep_few(1500))
+    print("sweep_few:", o)
+    assert o["tall"] > 800 and o["literal"] > 20, o
+    assert o["exceptions"] == [] and len(o["noise_decided"]) <= 6 and len(o["rounding_level"]) <= 3, o
+    assert all(q[2] in q[4] for q in o["rank_mismatch"]), o     # nRank differs only where the reference's own does
+
+
+def test_wider_random_sweep_against_the_reference(gpu_required):
+    """1500 stacks on hand-degenerate windows (duplicated clones, zero relative translations, exactly repeated relative poses), 3..100 features,
+    every length mix: zero exceptions > 1e-9 outside the repeated-pose windows (mode 3), <= 1e-6 inside"""
+    o = _replay(TT.sweep_wider(1500), excused=lambda mode: mode == 3)
+    print("sweep_wider:", o)
+    assert o["tall"] > 1300 and o["literal"] > 20, o
+    assert o["exceptions"] == [] and len(o["noise_decided"]) <= 6 and len(o["rounding_level"]) <= 3, o
+    assert o["worst_excused"] < 1e-6, o
+
+
+def _sweep_ref_pins():
+    """the 600 stacks of tests/test_ref_pins.py::test_update_on_random_small_and_degenerate_stacks"""
+    synth = rv.synth
+    cfg = abi.config_named("B", enable_equalizer=0)
+    n, Fu = cfg.max_track_len - 1, abi.fu(cfg)
+    recs = [r for r in TT._run(cfg, 4 * n + 30, image=False, seed=3) if (len(r["x1"]) - 26) // 7 == n]
+    rng = np.random.default_rng(7)
+    for trial in range(600):
+        base = recs[int(rng.integers(0, len(recs)))]
+        x, P = base["x1"].copy(), base["P1"]
+        mode = trial % 4
+        if mode == 1:
+            a = int(rng.integers(0, n - 2))
+            for c in range(a, int(rng.integers(a + 1, n))):
+                x[26 + 7 * c: 33 + 7 * c] = [0, 0, 0, 1, 0, 0, 0]
+        elif mode == 3:
+            for c in range(n):
+                x[26 + 7 * c: 33 + 7 * c] = [0, 0, 0, 1, 0.02, 0.01, 0.0]
+        nf = int(rng.integers(3, (16 if trial % 2 else Fu + 1)))
+        mix = ("half", "all2", "all1")[int(rng.integers(0, 3))]
+        ty, ln, me = synth.worst_case_tracks(cfg, x, n_feat=nf, seed=int(rng.integers(1 << 30)), mix=mix)
+        for f in range(nf):
+            if ty[f] == ord("1") and rng.uniform() < 0.5:
+                L = int(rng.integers(2, ln[f] + 1))
+                me[f, :L] = me[f, ln[f] - L: ln[f]].copy()
+                ln[f] = L
+        yield trial, mode, cfg, n, x, P, ty, ln, me
+
+
+def test_the_600_stacks_of_the_reference_pin(gpu_required):
+    """the sweep on which the reference's sources and their restatement were compared in round 5: the device against the reference on the same
+    stacks — <= 1e-9 outside the repeated-pose windows; inside them the reference's two builds end up to 3e-4 apart, the device stays within
+    5e-3 of the compiled sources like the restatement does"""
+    o = _replay(_sweep_ref_pins(), excused=lambda mode: mode == 3)
+    print("ref_pins sweep:", o)
+    assert o["updates"] > 550 and o["exceptions"] == [] and len(o["noise_decided"]) <= 4 and len(o["rounding_level"]) <= 4, o
+    assert o["worst_excused"] < 5e-3, o
+
+
+def _literal_cases(cfg_name, count):
+    """stacks of the sweeps that take the literal path (by the oracle mirror's decision)"""
+    got = []
+    for rec in (TT.sweep_few(400) if cfg_name == "A" else TT.sweep_wider(1500)):
+        trial, mode, cfg, n, x, P, ty, ln, me = rec
+        if mode == 3 or len(ln) > 24:
+            continue
+        blk = O.update_local(cfg, x, P, ty, ln, me, 0, 1)
+        if blk[-8 + 5] == 1 and _reference_noise(cfg, x, P, ty, ln, me, draws=6)[0] < 1e-11:      # (not one the reference's own rounding decides)
+            got.append(rec)
+            if len(got) == count:
+                break
+    return got
+
+
+def test_literal_path_in_every_launch_form(gpu_required):
+    """the same literal stacks through the other launch forms that reach lit_finish: the whole-frame path (feat_prop_kernel: propagate fused
+    into the per-feature launch), a batch handle (gram_reduce_batch_kernel / the array's state in the slab), and the sharded updater
+    (update_local at world 3 + update_global: block_sum_kernel; an update this small is not sharded — block 0 is the whole of it)"""
+    import torch
+    from rvio_amd import hip
+
+    class DA:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    for name in ("B", "A"):
+        cases = _literal_cases(name, 6)
+        assert len(cases) >= 4, len(cases)
+        cfg = cases[0][2]
+        Fu, ML = abi.fu(cfg), cfg.max_track_len
+        h = hip.RvioHip(cfg)
+        hb = hip.RvioHip(cfg, batch=128)   # (>= 128 instances: gram_reduce_batch_kernel)
+        for k, (trial, mode, _, n, x, P, ty, ln, me) in enumerate(cases):
+            xr, Pr, upd, n_acc, dg = _reference_update(cfg, x, P, ty, ln, me)
+            # sharded entry points, three ranks on one handle
+            h.set_state(x, P)
+            blocks = []
+            for rk in range(3):
+                ptr, nd = h.update_local(ty, ln, me, rk, 3)
+                h.sync()
+                blocks.append(torch.as_tensor(DA(ptr, nd), device="cuda").clone())
+            gathered = torch.cat(blocks).contiguous()
+            torch.cuda.synchronize()
+            h.update_global(gathered.data_ptr(), 3)
+            xs, Ps = h.get_state()
+            info = h.frame_info()
+            assert info["literal_rank"] == dg["rank"], (name, trial, info)
+            assert S.state_delta(xs, xr) <= 1e-9, (name, trial)
+            # batch handle: the same stack in all 128 instances through the whole-frame entry (an empty IMU batch: propagate is the identity;
+            # augmentation / composition follow the update, so the reference side applies them too)
+            nf = len(ln)
+            types, lens, meas = np.zeros((128, Fu), np.uint8), np.zeros((128, Fu), np.int32), np.zeros((128, Fu, ML, 2), np.float32)
+            types[:, :nf], lens[:, :nf], meas[:, :nf] = ty, ln, me[:, :ML]
+            hb.set_state(x, P)           # (every instance)
+            dn = torch.full((128,), nf, dtype=torch.int32, device="cuda")
+            d = [torch.from_numpy(a_).cuda() for a_ in (types, lens, meas)]
+            dimu = torch.zeros(64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            do_augment = k > 0            # System.cc:280: nImageCountAfterInit > 1 (both handles see their first frame at the first case)
+            hb.frame_tracks_dev(dimu.data_ptr(), 0, 0, dn.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+            hb.sync()
+            xa, Pa = O.augment_compose(cfg, xr, Pr, do_augment)[:2]
+            # the plain handle through the whole-frame path as well (feat_prop_kernel: propagate fused into the per-feature launch)
+            h.set_state(x, P)
+            dn1 = torch.full((1,), nf, dtype=torch.int32, device="cuda")
+            h.frame_tracks_dev(dimu.data_ptr(), 0, 0, dn1.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+            h.sync()
+            assert h.frame_info()["literal_rank"] == dg["rank"], (name, trial)
+            assert S.state_delta(h.get_state()[0], xa) <= 1e-9, (name, trial)
+            for i in (0, 127):
+                xb, Pb = hb.get_state_at(i)
+                assert S.state_delta(xb, xa) <= 1e-9, (name, trial, i)
+        h.close()
+        hb.close()
