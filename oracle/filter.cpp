@@ -619,7 +619,10 @@ static int e2_of(int L) { return 6 * ((int)std::ceil(.5 * L) - 1) - 1; }
 // = LIT_FEATS of csrc/literal.h; the environment variable ORC_LIT_FEATS overrides it (0: the structural rule alone, as up to round 5 — tests / studies)
 static int orc_lit_feats() { const char* e = std::getenv("ORC_LIT_FEATS"); return e ? std::atoi(e) : 24; }
 
-static int orc_lit_slack() { const char* e = std::getenv("ORC_LIT_SLACK"); return e ? std::atoi(e) : 8; }   // = LIT_SLACK of csrc/literal.h
+// = LIT_SPARE of csrc/literal.h: a gap only stops the scan when the stack has few rows to spare (rows - 6n small) — with many, informative rows
+// move up into the gap and the residue ends at the bottom (every exception found: rows - 6n <= 21; the stock sequence's one trigger: 390)
+static int orc_lit_spare() { const char* e = std::getenv("ORC_LIT_SPARE"); return e ? std::atoi(e) : 48; }
+static int orc_lit_slack() { const char* e = std::getenv("ORC_LIT_SLACK"); return e ? std::atoi(e) : 0; }   // = LIT_SLACK of csrc/literal.h (0: the barely-tall trigger is off)
 // A column gap behind an over-determined group (csrc/literal.h:lit_gap_trigger): the accepted features' rows are counted against their
 // column spans in the order of the start columns (type '2': columns 0..e2, rank <= e2 — the scale gauge of a monocular window; type
 // '1': columns 6 (n - L + 1) .. 6n - 1).  True when a column no feature can fill comes up while later features still wait AND a group
@@ -636,13 +639,17 @@ static bool gap_trigger(int n, const std::vector<int>& types, const std::vector<
         if (k < 0 || k > n || nrows[f] <= 0) continue;
         rows_k[k] += nrows[f]; end_k[k] = std::max(end_k[k], e);
     }
-    int p = 0; bool over = false;
+    const bool only2 = gauge0 && !any1_0 && rows_k[0] > 0;     // a type-'2' block alone at column 0
+    int p = 0, done = 0; bool over = false;
     for (int k = 0; k <= n; ++k) {
         if (rows_k[k] == 0) continue;
-        if (p < 6 * k) return over;
-        const int cap = (k == 0 && gauge0 && !any1_0 && end_k[k] < 6 * n - 1) ? end_k[k] : end_k[k] + 1;
+        if (p < 6 * k) {
+            if (!(only2 && done == 1)) return over;   // (the gap right behind a lone type-'2' block is the structural rule's own constellation, conditions (a)-(d) above: the count goes on behind it)
+        }
+        const int cap = (k == 0 && only2 && end_k[0] < 6 * n - 1) ? end_k[0] : end_k[k] + 1;
         if (p + rows_k[k] > cap) over = true;
         p = std::min(p + rows_k[k], cap);
+        ++done;
     }
     return false;
 }
@@ -680,7 +687,7 @@ void orc_update_local(const rvio_config* cfg, const double* x, int xdim, const d
     if (!lit) return;
     m[5] = 2;
     if (!(good > 2 && rows > nc6)) return;
-    if (!(rows - nc6 <= orc_lit_slack() || gap_trigger(n, kept_types, kept_lens, kept_rows))) return;
+    if (!(rows - nc6 <= orc_lit_slack() || (rows - nc6 <= orc_lit_spare() && gap_trigger(n, kept_types, kept_lens, kept_rows)))) return;
     // the literal sweep + scan on the stack in feature order
     Mat Ho(rows, nc6), roM(rows, 1);
     int at = 0;

