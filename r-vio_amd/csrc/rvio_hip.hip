@@ -916,7 +916,7 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
     double *xin = h->x[h->cur], *xout = h->x[h->cur ^ 1], *Pc = h->P[h->cur];
     const dim3 gb(1, 1, h->batch);
     if (h->solve9_nt) {   // blocked SPD factorisations on the matrix cores (solve9.hip): one workgroup, one launch
-        if (h->chol_async) (void)hipStreamWaitEvent(h->stream, h->evL, 0);   // the factor that started behind the last augment / compose
+        if (h->chol_async && hipStreamWaitEvent(h->stream, h->evL, 0) != hipSuccess) { h->chol_async = false; h->chol_ready = false; }   // the factor that started behind the last augment / compose (a failed wait: the solve factors Pcc itself)
         const bool pre = h->chol_ready || h->chol_async;   // L, G of the clone block are in the slab already (role workgroup of this update's per-feature / propagate launch; stream_l)
         h->chol_ready = false; h->chol_async = false;
         switch (h->solve9_nt) {
@@ -2060,7 +2060,10 @@ int rvio_hip_debug_poison(rvio_hip* h, int what) {
         HIPCHK(h, fill(h->partial, sizeof(double) * d.Fu * ldh * ldh));
         HIPCHK(h, fill(h->block, sizeof(double) * 2 * ldh * ldh)); HIPCHK(h, fill(h->Ab, sizeof(double) * 2 * ldh * ldh));
         HIPCHK(h, fill(h->Tbuf, sizeof(double) * ldh * ldh)); HIPCHK(h, fill(h->W, sizeof(double) * ldh * ldh));
-        if (h->S9scr) HIPCHK(h, hipMemsetAsync(h->S9scr, 0xff, sizeof(double) * S9_SLAB_DOUBLES(h->solve9_nt), h->stream));   // (solve9 reads only tiles it wrote in the same launch)
+        if (h->S9scr) {   // the slab holds the Cholesky factor a PRE solve would read (role workgroup / stream_l): it goes with the slab — the next solve factors Pcc itself
+            HIPCHK(h, hipMemsetAsync(h->S9scr, 0xff, sizeof(double) * S9_SLAB_DOUBLES(h->solve9_nt), h->stream));
+            h->chol_ready = false; h->chol_async = false;   // (drain_all above has waited for stream_l)
+        }
         HIPCHK(h, fill(h->U, sizeof(double) * dm * ldh)); HIPCHK(h, fill(h->G, sizeof(double) * dm * ldh));
         HIPCHK(h, fill(h->Pt1, sizeof(double) * PP));
         HIPCHK(h, fill(h->gamma, sizeof(double) * d.Fu)); HIPCHK(h, fill(h->pfinv, sizeof(double) * 3 * d.Fu));
