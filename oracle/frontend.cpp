@@ -204,7 +204,10 @@ inline int der(const Level& L, int x, int y, int c) { return (x < 0 || y < 0 || 
 // float_acc = true (orc_klt_float, measurement only): the accumulators as OpenCV's SCALAR path holds them — float, every integer product
 // converted and added in row-major window order (lkpyramid.cpp LKTrackerInvoker, acctype = itemtype = float without SIMD).  It is one of the
 // build-dependent orders the header of this file speaks of; tests/test_opencv_distance.py reports how far the exact-sum definition sits from it.
+// (measurement only: iteration counts of the calls so far — [points, iterations summed, largest per point, restages a 32 x 32 staged region would need])
+static long long g_lk_stat[4] = {0, 0, 0, 0};
 void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox, float* oy, unsigned char* st, bool float_acc = false) {
+    long long its_pt = 0;
     const int maxLevel = (int)std::min(P.lv.size(), N.lv.size()) - 1;
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2 = 0.01 * 0.01;
@@ -245,9 +248,12 @@ void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox,
         D = 1.f / D;
         float npx = nx - 7.f, npy = ny - 7.f;
         float pdx = 0, pdy = 0;
+        int jxl = ipx - 8, jyl = ipy - 8;
         for (int j = 0; j < maxCount; ++j) {
             int inx = cv_floor(npx), iny = cv_floor(npy);
             if (inx < -kWin || inx >= J.w || iny < -kWin || iny >= J.h) { if (level == 0) *st = 0; break; }
+            ++its_pt;
+            if (inx - jxl < 0 || inx - jxl > 15 || iny - jyl < 0 || iny - jyl > 15) { jxl = inx - 8; jyl = iny - 8; ++g_lk_stat[3]; }
             a = npx - inx; b = npy - iny;
             iw00 = cv_round((1.f - a) * (1.f - b) * (1 << 14));
             iw01 = cv_round(a * (1.f - b) * (1 << 14));
@@ -278,7 +284,9 @@ void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox,
         }
     }
     *ox = nx; *oy = ny;
+    g_lk_stat[0]++; g_lk_stat[1] += its_pt; if (its_pt > g_lk_stat[2]) g_lk_stat[2] = its_pt;
 }
+extern "C" void orc_dbg_lk_stats(long long* out4) { for (int k = 0; k < 4; ++k) { out4[k] = g_lk_stat[k]; g_lk_stat[k] = 0; } }
 
 // cv::undistortPoints without R/P (appendix B.3): 5 fixed-point iterations in double, float I/O
 void undistort(const rvio_config* c, const float* in, int n, float* out) {

@@ -249,22 +249,24 @@ __device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  /
 
 // UndistortAndNormalize of the tracked points + Ransac::FindInliers.  One workgroup, 256 threads.
 // un1: previous-frame normalised coords (mPoints1ForRansac, z = 1), un2: output for this frame.
-// Dynamic LDS: cand[F] ints + used[F] bytes.
+// Dynamic LDS: cand[F] ints + first[F] ints (SetPointPair).
 __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
                                             unsigned char* status, const rvio_imu* imu, int m, int* rng,
                                             rvio_frame_info* info, size_t bs, size_t imu_bs, unsigned char* dsh) {
     __shared__ int s_w[4];
     __shared__ int pairs[16][2];
     DBG_S(blockIdx.z == 0, 2);
+    DBG_U(1);
     n_pts_ptr = zoff(n_pts_ptr, bs); tracked = zoff(tracked, bs); un1 = zoff(un1, bs); un2 = zoff(un2, bs); status = zoff(status, bs);
     imu = zoff(imu, imu_bs); rng = zoff(rng, bs); info = zoff(info, bs);
     __shared__ double hyp[16][9];
     __shared__ double dRs[RVIO_MAX_IMU][9];
+    __shared__ double Rsh[9];
     __shared__ int cnt[16];
     __shared__ int s_rng[36];
     __shared__ int s_winner, s_newout;
     int* cand = (int*)dsh;
-    unsigned char* used = dsh + sizeof(int) * cfg.F;
+    int* first = cand + cfg.F;   // SetPointPair: index of the first draw that produced each candidate position
     const int tid = threadIdx.x, N = *n_pts_ptr;
     // one batch of global reads: RNG state, IMU samples (-> per-sample delta rotations), the points
     if (tid < 35) s_rng[tid] = rng[tid];
@@ -296,27 +298,65 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
         nc += tot;
     }
     if (tid < 16) cnt[tid] = 0;
-    for (int i = tid; i < nc; i += 256) used[i] = 0;
+    for (int i = tid; i < nc; i += 256) first[i] = 0x7fffffff;
     if (tid == 0) { s_winner = 0; s_newout = 0; info->n_tracked_in = N; info->n_klt_ok = nc; info->n_ransac_inliers = 0; info->ransac_winner = 0; }
     __syncthreads();
+    DBG_U(2);
     if (nc < 32) return;   // Ransac.cc:201-205; 17..31 would spin forever in the reference
-    if (tid == 0) {        // SetPointPair, Ransac.cc:50-83 — serial by construction (rand() stream), all in LDS
-        for (int it = 0; it < 16; ++it) {
-            int a, b;
-            do { a = rng_next(s_rng) % nc; } while (used[a]);
-            do { b = rng_next(s_rng) % nc; } while (used[b] || a == b);
-            pairs[it][0] = cand[a]; pairs[it][1] = cand[b];
-            used[a] = 1; used[b] = 1;
+    // SetPointPair, Ransac.cc:50-83: 16 pairs of distinct candidates from the rand() stream —
+    //     do a = rand() % nc while used[a];  do b = rand() % nc while used[b] || a == b;  pair = (a, b), both become used.
+    // A draw is turned down exactly when its value has been drawn before (the first occurrence of a value is always taken: `used` holds
+    // nothing but earlier first occurrences, and so does `a`), so the pairs are the first 32 FIRST OCCURRENCES of the stream in order and the
+    // stream advances to the draw that delivered the 32nd.  glibc's rand() is the additive-feedback generator r[i] = r[i-3] + r[i-31]: one
+    // turn of its 31-word ring is a stride-3 prefix sum, which a wave computes in four shuffle steps — 31 draws at a time instead of a
+    // serial chain through LDS (round 6: 11 us of this one-workgroup kernel, which sits on the tracker's serial chain; now ~1 us).
+    if (tid < 64) {
+        const int lane = tid;
+        if (lane == 0 && !s_rng[33]) rng_seed(s_rng, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        int f = s_rng[31], total = 0, kbase = 0;
+        for (int turn = 0; turn < 4096; ++turn) {
+            unsigned x = 0;
+            int pos = 0;
+            if (lane < 31) {
+                pos = f + lane; if (pos >= 31) pos -= 31;          // draw `lane` of this turn rewrites ring word pos ...
+                x = (unsigned)s_rng[pos];
+                if (lane < 3) { int p2 = pos + 28; if (p2 >= 31) p2 -= 31; x += (unsigned)s_rng[p2]; }   // ... adding the word three behind it: an old one for the first three draws,
+            }
+#pragma unroll
+            for (int d = 3; d < 31; d *= 2) { const unsigned y = (unsigned)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }   // a new one (draw lane - 3) for the others
+            int val = 0;
+            if (lane < 31) { val = (int)((x >> 1) % (unsigned)nc); atomicMin(&first[val], kbase + lane); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const bool acc = lane < 31 && first[val] == kbase + lane;
+            const unsigned long long mk = __ballot(acc);
+            const int rank = total + __popcll(mk & ((1ull << lane) - 1ull));
+            if (acc && rank < 32) pairs[rank >> 1][rank & 1] = cand[val];
+            const int na = __popcll(mk);
+            const bool done = total + na >= 32;
+            int c = 31;                                             // draws of this turn the stream advances by
+            if (done) c = __ffsll((long long)__ballot(acc && rank == 31));
+            if (lane < c && lane < 31) s_rng[pos] = (int)x;
+            f = (f + c) % 31;
+            if (done) break;
+            total += na; kbase += 31;
         }
-        for (int k = 0; k < 35; ++k) rng[k] = s_rng[k];
+        if (lane == 0) { s_rng[31] = f; s_rng[32] = (f + 28) % 31; }   // (the rear index trails the front one by three)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane < 35) rng[lane] = s_rng[lane];
     }
-    __syncthreads();
-    if (tid < 16) {
+    else if (tid < 128) {   // beside the pair selection: the gyro prior R = Rci (dR_m-1 ... dR_0) Ric, a serial product of the per-sample rotations (same for the 16 models)
         const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
         m33 R = eye33();
         for (int s = 0; s < m_lds; ++s) R = mul33(ldm33(dRs[s]), R);
         for (int s = m_lds; s < m; ++s) R = mul33(gyro_dR(s), R);
         R = mul33(mul33(Rci, R), Ric);
+        if (tid == 64) for (int k = 0; k < 9; ++k) Rsh[k] = R.m[k];
+    }
+    __syncthreads();
+    DBG_U(3);
+    if (tid < 16) {
+        const m33 R = ldm33(Rsh);
         // SetRansacModel, Ransac.cc:86-117
         const int ia = pairs[tid][0], ib = pairs[tid][1];
         const d3 A1 = mk3(un1[2 * ia], un1[2 * ia + 1], 1.0), A2 = mk3(un2[2 * ia], un2[2 * ia + 1], 1.0);
@@ -331,6 +371,7 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
         for (int k = 0; k < 9; ++k) hyp[tid][k] = E.m[k];
     }
     __syncthreads();
+    DBG_U(4);
     // CountInliers, Ransac.cc:158-177: thread <-> candidate, all 16 hypotheses
     for (int base = 0; base < nc; base += 256) {
         const int k = base + tid;
@@ -344,6 +385,7 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
         }
     }
     __syncthreads();
+    DBG_U(5);
     if (tid == 0) {
         int best = 0, bi = 0;
         for (int it = 0; it < 16; ++it) if (cnt[it] > best) { best = cnt[it]; bi = it; }
@@ -361,6 +403,7 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     }
     __syncthreads();
     if (tid == 0) { info->n_ransac_inliers = nc - s_newout; info->ransac_winner = s_winner; }
+    DBG_U(6);
 }
 __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
                                                      unsigned char* status, const rvio_imu* imu, int m, int* rng,
@@ -385,11 +428,25 @@ __global__ __launch_bounds__(256) void ransac_kernel(DevCfg cfg, const int* n_pt
 // done / done_target (single instance, run-ahead mode): the device-side counter the filter of frame k-2 bumps when its last kernel has
 // finished (rvio_dev.h StageSync) — the hand-over tables the first kernel rewrites are free then.  A stream-level event in its place costs the
 // FILTER stream a marker packet per frame (~9 us of its serial chain); this costs one poll here.
+// n <= max_len entries of a track history from src to dst, eight loads in flight per step: every load of a chunk is issued before its first
+// store (a load-store pair per element is a dependent global round trip each: ~1 us per observation on a one-workgroup kernel of the serial
+// chain).  dst may be src - shift (the in-place roll of a full track): a chunk reads [k0 + shift, k0 + 8 + shift) and then writes [k0, k0 + 8),
+// which no later chunk reads.
+__device__ __forceinline__ void hist_copy(float2* dst, const float2* src, int n) {
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(k0 + u < n) ? k0 + u : n - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < n) dst[k0 + u] = v[u];
+    }
+}
 __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t, size_t bs,
                                                 const unsigned long long* done, unsigned long long done_target, FilterMeta* meta) {
     DBG_S(blockIdx.z == 0, 3);
     if (done && !stage_wait(done, done_target, meta)) return;   // (timed out: error bit 4 is set, nothing is rewritten)
     DBG_S(blockIdx.z == 0, 4);
+    DBG_U(7);
     tracker_shift(t, (size_t)blockIdx.z * bs);
     __shared__ int s_w[4];
     const int tid = threadIdx.x, Fu = cfg.Fu, ML = cfg.max_len;
@@ -409,27 +466,36 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
     // ---- lost tracks -> type '1' (Tracker.cc:279-303), in feature order
     for (int base = 0; base < N; base += 256) {
         const int i = base + tid;
-        int emit = 0, slot = 0, hl = 0;
-        const bool lost = (i < N) && !t.status[i];
-        if (lost) { slot = t.slot[i]; hl = t.hist_len[slot]; emit = (hl >= cfg.min_len) ? 1 : 0; }
+        // (flag and slot are fetched side by side, the history length right behind: two dependent round trips instead of three)
+        const bool in = i < N;
+        const unsigned char stt = in ? t.status[i] : (unsigned char)1;
+        const int slot = in ? t.slot[i] : 0;
+        const int hl = t.hist_len[slot];
+        const bool lost = in && !stt;
+        const int emit = (lost && hl >= cfg.min_len) ? 1 : 0;
         int tot;
         const int pos = nMeas + block_exscan(emit, &tot, s_w);
         if (emit && pos < Fu) {
             t.types[pos] = '1'; t.len[pos] = hl;
-            for (int k = 0; k < hl; ++k) meas[(size_t)pos * ML + k] = hist[(size_t)slot * ML + k];
+            hist_copy(meas + (size_t)pos * ML, hist + (size_t)slot * ML, hl);
         }
         if (lost) t.hist_len[slot] = 0;
         nMeas = (nMeas + tot < Fu) ? nMeas + tot : Fu;
     }
+    DBG_U(8);
     // ---- tracked features (Tracker.cc:305-342): type '2' at max length, history roll, new order
     int nIn = 0;
     const int keep = ML - ((ML + 1) / 2 - 1);   // mnMaxTrackingLength-(ceil(.5*max)-1), Tracker.cc:326
     for (int base = 0; base < N; base += 256) {
         const int i = base + tid;
-        const bool trk = (i < N) && t.status[i];
-        int slot = 0, hl = 0, full = 0;
-        float2 pt = make_float2(0, 0), pu = make_float2(0, 0);
-        if (trk) { slot = t.slot[i]; hl = t.hist_len[slot]; full = (hl == ML) ? 1 : 0; pt = tr2[i]; pu = un2[i]; }
+        const bool in = i < N;
+        const int ii = in ? i : 0;
+        const unsigned char stt = in ? t.status[i] : (unsigned char)0;
+        const int slot = t.slot[ii];
+        const float2 pt = tr2[ii], pu = un2[ii];
+        int hl = t.hist_len[slot];
+        const bool trk = in && stt;
+        const int full = (trk && hl == ML) ? 1 : 0;
         int tot2, totT;
         const int pos2 = nMeas + block_exscan(full, &tot2, s_w);
         const int posT = nIn + block_exscan(trk ? 1 : 0, &totT, s_w);
@@ -439,10 +505,10 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
                 int shift = 1;
                 if (pos2 < Fu) {
                     t.types[pos2] = '2'; t.len[pos2] = hl;
-                    for (int k = 0; k < hl; ++k) meas[(size_t)pos2 * ML + k] = hs[k];
+                    hist_copy(meas + (size_t)pos2 * ML, hs, hl);
                     shift = ML - keep;
                 }
-                for (int k = 0; k + shift < hl; ++k) hs[k] = hs[k + shift];
+                hist_copy(hs, hs + shift, hl - shift);
                 hl -= shift;
             }
             hs[hl] = pu;
@@ -453,6 +519,7 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
         nIn += totT;
     }
     if (tid == 0) { t.mid[0] = 0; t.mid[1] = nIn; t.mid[2] = nMeas; *t.n_feat = nMeas; t.info->n_feat_update = nMeas; }
+    DBG_U(9);
 }
 // hand (single instance, run-ahead mode): the counter the gate in front of this frame's filter polls — the Updater's input is complete
 __global__ __launch_bounds__(256) void bookkeep_a_kernel(DevCfg cfg, TrackerDev t, size_t bs,
@@ -495,6 +562,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
     extern __shared__ __align__(16) unsigned char dsh[];
     if (corners && !stage_wait(corners, corners_target, meta)) return;   // (timed out: error bit 4 is set)
     DBG_S(blockIdx.z == 0, 6);
+    DBG_U(10);
     tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
     __shared__ int s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, ML = cfg.max_len;
@@ -535,6 +603,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
     }
     for (int i = tid; i < nIn; i += 256) tfs[i] = ((const float2*)t.tmp_feats)[i];   // the survivors, in the order the first half gave them
     __syncthreads();
+    DBG_U(11);
     // ---- refill (Tracker.cc:344-387) through FindNewer/ChessGrid (FeatureDetector.cc:78-150)
     int nNew = 0;
     if (nIn < F && nc > 0) {
@@ -563,6 +632,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
             t.cand_acc[c] = 0;
         }
         __syncthreads();
+        DBG_U(12);
         // one wave per grid cell: gather the cell's tracked points, then walk its candidates in detector order
         float2* cp = cellp + (size_t)wv * F;
         for (int cell = wv; cell < cells; cell += 4) {
@@ -599,6 +669,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
             }
         }
         __syncthreads();
+        DBG_U(13);
         // accepted candidates keep detector order; the k-th accepted takes the k-th free slot
         const int room = F - nIn;
         for (int base = 0; base < nc; base += 256) {
@@ -610,6 +681,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
             nNew = (nNew + tot < room) ? nNew + tot : room;
         }
         __syncthreads();
+        DBG_U(14);
         int nFree = 0;
         for (int base = 0; base < F; base += 256) {
             const int s = base + tid;
@@ -629,10 +701,12 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
         }
     }
     __syncthreads();
+    DBG_U(15);
     const int nOut = nIn + nNew;
     for (int i = tid; i < nOut; i += 256) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
     DBG_S(blockIdx.z == 0, 5);
     if (tid == 0) { *t.n_pts = nOut; t.info->n_tracked_out = nOut; }
+    DBG_U(16);
 }
 
 // direct-track mode: the caller supplies vFeatsTracked / vInlierFlag (the KLT result)

@@ -1377,7 +1377,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
     static const bool no_ra_fuse = ab_env("RVIO_NO_FUSED_RANSAC") != nullptr;
     const bool fused = h->use_det && h->runahead && !no_ra_fuse;
     if (!fused)
-    hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
+    hipLaunchKernelGGL(ransac_kernel, dim3(1, 1, B), dim3(256), (size_t)8 * h->dc.F + 16, h->side, h->dc, h->t.n_pts, h->t.tracked, h->t.un1, h->t.un2,
                        h->t.status, d_imu, m, h->rng, h->d_info, bs, h->imu_bs);
     h->tail = h->ts;
     h->handover_evt = false;
@@ -1395,7 +1395,7 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             unsigned long long* hand = nullptr;
             if (h->dev_sync) { hand = &h->stage_sync->handover; h->stage_tgt.handover++; }
             if (fused)
-                hipLaunchKernelGGL(ransac_book_a_kernel, dim3(1, 1, B), dim3(256), (size_t)5 * h->dc.F + 16, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
+                hipLaunchKernelGGL(ransac_book_a_kernel, dim3(1, 1, B), dim3(256), (size_t)8 * h->dc.F + 16, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
                                    done, done_target, h->meta, hand);
             else
             hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, hand);
@@ -2179,6 +2179,13 @@ int rvio_hip_debug_ring3(rvio_hip* h, long long* out512) {
     int rc = rvio_hip_sync(h);
     if (rc != RVIO_OK) return rc;
     HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring3), sizeof(long long) * 512));
+    return RVIO_OK;
+}
+int rvio_hip_debug_clocks2(rvio_hip* h, long long* out64) {
+    if (!h || !out64) return RVIO_ERR_INVALID;
+    const int rc = drain_all(h);
+    if (rc != RVIO_OK) return rc;
+    HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg2), sizeof(long long) * 64));
     return RVIO_OK;
 }
 int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {
