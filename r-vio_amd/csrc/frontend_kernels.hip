@@ -237,6 +237,32 @@ __device__ int block_exscan(int v, int* total, int* s_w) {
     return base + inc - v;
 }
 
+// the same for a workgroup of blockDim.x / 64 <= 16 waves (s_w: 16 ints)
+__device__ int block_exscan_n(int v, int* total, int* s_w) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) { const int sv = s_w[w]; if (w < wv) base += sv; tot += sv; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+// The largest double T with !(sqrt(T) > m): for every s >= 0 (and NaN), (sqrt(s) > m) == (s > T) — sqrt is monotonic, so the comparison of the
+// rounded root with m flips at ONE double, found here with the same sqrt by stepping up from m * m (exact for a float m; <= 2 steps: the
+// roots of the doubles just above m^2 round back to m).  Lets a serial loop compare squared distances without changing a single decision.
+__device__ __forceinline__ double sqrt_gt_threshold(double m) {
+    if (!(m >= 0)) return -1.0;   // sqrt(s) > m holds for every s >= 0
+    double T = m * m;
+    for (int it = 0; it < 8; ++it) {
+        const double nx = __longlong_as_double(__double_as_longlong(T) + 1);
+        if (sqrt(nx) > m) break;
+        T = nx;
+    }
+    return T;
+}
+
 __device__ __forceinline__ double sampson_err(d3 p1, d3 p2, const m33& E) {  // Ransac.cc:250-258
     const d3 F1 = mv33(E, p1), F2 = mv33(tr33(E), p2);
     const double num = F2.x * p1.x + F2.y * p1.y + F2.z * p1.z;
@@ -253,7 +279,7 @@ __device__ __forceinline__ double algebraic_err(d3 p1, d3 p2, const m33& E) {  /
 __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_ptr, const float* tracked, const float* un1, float* un2,
                                             unsigned char* status, const rvio_imu* imu, int m, int* rng,
                                             rvio_frame_info* info, size_t bs, size_t imu_bs, unsigned char* dsh) {
-    __shared__ int s_w[4];
+    __shared__ int s_w[16];
     __shared__ int pairs[16][2];
     DBG_S(blockIdx.z == 0, 2);
     DBG_U(1);
@@ -267,7 +293,7 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     __shared__ int s_winner, s_newout;
     int* cand = (int*)dsh;
     int* first = cand + cfg.F;   // SetPointPair: index of the first draw that produced each candidate position
-    const int tid = threadIdx.x, N = *n_pts_ptr;
+    const int tid = threadIdx.x, T = blockDim.x, N = *n_pts_ptr;   // T: 256 .. 1024 threads (a multiple of 256)
     // one batch of global reads: RNG state, IMU samples (-> per-sample delta rotations), the points
     if (tid < 35) s_rng[tid] = rng[tid];
     // GetRotation, Ransac.cc:120-155 (raw gyro, no bias removal): per-sample dR
@@ -286,19 +312,19 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
         const m33 dR = gyro_dR(s);
         for (int k = 0; k < 9; ++k) dRs[s][k] = dR.m[k];
     }
-    for (int i = tid; i < N; i += 256) undistort_pt(cfg, tracked[2 * i], tracked[2 * i + 1], &un2[2 * i], &un2[2 * i + 1]);
+    for (int i = tid; i < N; i += T) undistort_pt(cfg, tracked[2 * i], tracked[2 * i + 1], &un2[2 * i], &un2[2 * i + 1]);
     // ordered compaction of candidate indices (status != 0)
     int nc = 0;
-    for (int base = 0; base < N; base += 256) {
+    for (int base = 0; base < N; base += T) {
         const int i = base + tid;
         const int fl = (i < N && status[i]) ? 1 : 0;
         int tot;
-        const int pos = block_exscan(fl, &tot, s_w);
+        const int pos = block_exscan_n(fl, &tot, s_w);
         if (fl) cand[nc + pos] = i;
         nc += tot;
     }
     if (tid < 16) cnt[tid] = 0;
-    for (int i = tid; i < nc; i += 256) first[i] = 0x7fffffff;
+    for (int i = tid; i < nc; i += T) first[i] = 0x7fffffff;
     if (tid == 0) { s_winner = 0; s_newout = 0; info->n_tracked_in = N; info->n_klt_ok = nc; info->n_ransac_inliers = 0; info->ransac_winner = 0; }
     __syncthreads();
     DBG_U(2);
@@ -372,16 +398,19 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     }
     __syncthreads();
     DBG_U(4);
-    // CountInliers, Ransac.cc:158-177: thread <-> candidate, all 16 hypotheses
-    for (int base = 0; base < nc; base += 256) {
-        const int k = base + tid;
-        d3 p1 = mk3(0, 0, 1), p2 = mk3(0, 0, 1);
-        if (k < nc) { const int idx = cand[k]; p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0); p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0); }
-        for (int it = 0; it < 16; ++it) {
-            m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[it][q];
-            const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
-            const unsigned long long bal = __ballot((k < nc) && (dist < cfg.inlier_thr));
-            if ((tid & 63) == 0 && bal) atomicAdd(&cnt[it], __popcll(bal));
+    // CountInliers, Ransac.cc:158-177: thread <-> candidate; the T / 256 groups of 256 threads split the 16 hypotheses among them
+    {
+        const int G = T >> 8, g = tid >> 8, kk = tid & 255, HG = 16 / G;   // (G = 1, 2 or 4)
+        for (int base = 0; base < nc; base += 256) {
+            const int k = base + kk;
+            d3 p1 = mk3(0, 0, 1), p2 = mk3(0, 0, 1);
+            if (k < nc) { const int idx = cand[k]; p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0); p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0); }
+            for (int it = g * HG; it < (g + 1) * HG; ++it) {
+                m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[it][q];
+                const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
+                const unsigned long long bal = __ballot((k < nc) && (dist < cfg.inlier_thr));
+                if ((tid & 63) == 0 && bal) atomicAdd(&cnt[it], __popcll(bal));
+            }
         }
     }
     __syncthreads();
@@ -394,7 +423,7 @@ __device__ __forceinline__ void ransac_body(const DevCfg& cfg, const int* n_pts_
     __syncthreads();
     {
         m33 E; for (int q = 0; q < 9; ++q) E.m[q] = hyp[s_winner][q];
-        for (int k = tid; k < nc; k += 256) {
+        for (int k = tid; k < nc; k += T) {
             const int idx = cand[k];
             const d3 p1 = mk3(un1[2 * idx], un1[2 * idx + 1], 1.0), p2 = mk3(un2[2 * idx], un2[2 * idx + 1], 1.0);
             const double dist = cfg.use_sampson ? sampson_err(p1, p2, E) : algebraic_err(p1, p2, E);
@@ -448,8 +477,8 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
     DBG_S(blockIdx.z == 0, 4);
     DBG_U(7);
     tracker_shift(t, (size_t)blockIdx.z * bs);
-    __shared__ int s_w[4];
-    const int tid = threadIdx.x, Fu = cfg.Fu, ML = cfg.max_len;
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, T = blockDim.x, Fu = cfg.Fu, ML = cfg.max_len;
     const int N = *t.n_pts;
     const int first = *t.first;
     float2* hist = (float2*)t.hist;
@@ -464,7 +493,7 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
         return;
     }
     // ---- lost tracks -> type '1' (Tracker.cc:279-303), in feature order
-    for (int base = 0; base < N; base += 256) {
+    for (int base = 0; base < N; base += T) {
         const int i = base + tid;
         // (flag and slot are fetched side by side, the history length right behind: two dependent round trips instead of three)
         const bool in = i < N;
@@ -474,7 +503,7 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
         const bool lost = in && !stt;
         const int emit = (lost && hl >= cfg.min_len) ? 1 : 0;
         int tot;
-        const int pos = nMeas + block_exscan(emit, &tot, s_w);
+        const int pos = nMeas + block_exscan_n(emit, &tot, s_w);
         if (emit && pos < Fu) {
             t.types[pos] = '1'; t.len[pos] = hl;
             hist_copy(meas + (size_t)pos * ML, hist + (size_t)slot * ML, hl);
@@ -486,7 +515,7 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
     // ---- tracked features (Tracker.cc:305-342): type '2' at max length, history roll, new order
     int nIn = 0;
     const int keep = ML - ((ML + 1) / 2 - 1);   // mnMaxTrackingLength-(ceil(.5*max)-1), Tracker.cc:326
-    for (int base = 0; base < N; base += 256) {
+    for (int base = 0; base < N; base += T) {
         const int i = base + tid;
         const bool in = i < N;
         const int ii = in ? i : 0;
@@ -497,8 +526,8 @@ __device__ __forceinline__ void bookkeep_a_body(const DevCfg& cfg, TrackerDev t,
         const bool trk = in && stt;
         const int full = (trk && hl == ML) ? 1 : 0;
         int tot2, totT;
-        const int pos2 = nMeas + block_exscan(full, &tot2, s_w);
-        const int posT = nIn + block_exscan(trk ? 1 : 0, &totT, s_w);
+        const int pos2 = nMeas + block_exscan_n(full, &tot2, s_w);
+        const int posT = nIn + block_exscan_n(trk ? 1 : 0, &totT, s_w);
         if (trk) {
             float2* hs = hist + (size_t)slot * ML;
             if (full) {
@@ -557,15 +586,15 @@ __global__ __launch_bounds__(256) void ransac_book_a_kernel(DevCfg cfg, TrackerD
 }
 
 // corners / corners_target (single instance, run-ahead mode): the counter stage_signal_kernel bumps behind this frame's cornerSubPix
-__global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
-                                                         const unsigned long long* corners, unsigned long long corners_target, FilterMeta* meta) {
-    extern __shared__ __align__(16) unsigned char dsh[];
+__device__ __forceinline__ void bookkeep_b_body(const DevCfg& cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
+                                                const unsigned long long* corners, unsigned long long corners_target, FilterMeta* meta, unsigned char* dsh) {
     if (corners && !stage_wait(corners, corners_target, meta)) return;   // (timed out: error bit 4 is set)
     DBG_S(blockIdx.z == 0, 6);
     DBG_U(10);
     tracker_shift(t, (size_t)blockIdx.z * bs); cand = zoff(cand, bs); if (n_cand_dev) n_cand_dev = zoff(n_cand_dev, bs);
-    __shared__ int s_w[4];
+    __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, F = cfg.F, ML = cfg.max_len;
+    const int T = blockDim.x, nwv = T >> 6;   // 4 waves for batch handles, up to 16 for one stream: the cell walk below is one wave per grid cell
     float2* tfs = (float2*)dsh;
     float2* cds = tfs + F;
     short* cid_t = (short*)(cds + F);
@@ -578,12 +607,12 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
     float2* tu = (float2*)t.tmp_un;
     if (n_cand_dev) n_cand = *n_cand_dev;
     const int nc = n_cand < F ? n_cand : F;
-    for (int c = tid; c < nc; c += 256) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
+    for (int c = tid; c < nc; c += T) cds[c] = make_float2(cand[2 * c], cand[2 * c + 1]);
     if (first) {
         // first image, Tracker.cc:204-234: seed every slot with a detector corner
         __syncthreads();
         const int n0 = nc;
-        for (int i = tid; i < F; i += 256) {
+        for (int i = tid; i < F; i += T) {
             if (i < n0) {
                 float ux, uy;
                 undistort_pt(cfg, cds[i].x, cds[i].y, &ux, &uy);
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
         }
         return;
     }
-    for (int i = tid; i < nIn; i += 256) tfs[i] = ((const float2*)t.tmp_feats)[i];   // the survivors, in the order the first half gave them
+    for (int i = tid; i < nIn; i += T) tfs[i] = ((const float2*)t.tmp_feats)[i];   // the survivors, in the order the first half gave them
     __syncthreads();
     DBG_U(11);
     // ---- refill (Tracker.cc:344-387) through FindNewer/ChessGrid (FeatureDetector.cc:78-150)
@@ -610,7 +639,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
         const int cells = cfg.grid_cols * cfg.grid_rows;
         const float W = (float)cfg.W, H = (float)cfg.H, offX = cfg.off_x, offY = cfg.off_y;
         // grid cell of every tracked point and candidate (-1: outside / too close to a block edge)
-        for (int i = tid; i < nIn; i += 256) {
+        for (int i = tid; i < nIn; i += T) {
             const float2 p = tfs[i];
             int cell = -1;
             if (!(p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY))) {
@@ -619,7 +648,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
             }
             cid_t[i] = (short)cell;
         }
-        for (int c = tid; c < nc; c += 256) {
+        for (int c = tid; c < nc; c += T) {
             const float2 p = cds[c];
             int cell = -1;
             if (!(p.x <= offX || p.y <= offY || p.x >= (W - offX) || p.y >= (H - offY))) {
@@ -634,8 +663,9 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
         __syncthreads();
         DBG_U(12);
         // one wave per grid cell: gather the cell's tracked points, then walk its candidates in detector order
+        const double d2max = sqrt_gt_threshold((double)cfg.min_dist);
         float2* cp = cellp + (size_t)wv * F;
-        for (int cell = wv; cell < cells; cell += 4) {
+        for (int cell = wv; cell < cells; cell += nwv) {
             int cn = 0;
             for (int base = 0; base < nIn; base += 64) {
                 const int i = base + lane;
@@ -659,8 +689,7 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
                         bool cl = false;
                         if (q < cn) {
                             const float dx = p.x - cp[q].x, dy = p.y - cp[q].y;
-                            const double dist = sqrt((double)dx * dx + (double)dy * dy);
-                            cl = !(dist > (double)cfg.min_dist);
+                            cl = !((double)dx * dx + (double)dy * dy > d2max);    // == !(sqrt(.) > min_dist), see sqrt_gt_threshold
                         }
                         if (__ballot(cl)) { close = true; break; }
                     }
@@ -672,22 +701,22 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
         DBG_U(13);
         // accepted candidates keep detector order; the k-th accepted takes the k-th free slot
         const int room = F - nIn;
-        for (int base = 0; base < nc; base += 256) {
+        for (int base = 0; base < nc; base += T) {
             const int c = base + tid;
             const int ac = (c < nc) ? t.cand_acc[c] : 0;
             int tot;
-            const int k = nNew + block_exscan(ac, &tot, s_w);
+            const int k = nNew + block_exscan_n(ac, &tot, s_w);
             if (ac && k < room) tfs[nIn + k] = cds[c];
             nNew = (nNew + tot < room) ? nNew + tot : room;
         }
         __syncthreads();
         DBG_U(14);
         int nFree = 0;
-        for (int base = 0; base < F; base += 256) {
+        for (int base = 0; base < F; base += T) {
             const int s = base + tid;
             const int fr = (s < F && t.hist_len[s] == 0) ? 1 : 0;
             int tot;
-            const int k = nFree + block_exscan(fr, &tot, s_w);
+            const int k = nFree + block_exscan_n(fr, &tot, s_w);
             if (fr && k < nNew) {
                 float ux, uy;
                 const float2 p = tfs[nIn + k];
@@ -703,12 +732,35 @@ __global__ __launch_bounds__(256) void bookkeep_b_kernel(DevCfg cfg, TrackerDev 
     __syncthreads();
     DBG_U(15);
     const int nOut = nIn + nNew;
-    for (int i = tid; i < nOut; i += 256) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
+    for (int i = tid; i < nOut; i += T) { feats[i] = tfs[i]; un1[i] = tu[i]; t.slot[i] = t.tmp_slot[i]; }
     DBG_S(blockIdx.z == 0, 5);
     if (tid == 0) { *t.n_pts = nOut; t.info->n_tracked_out = nOut; }
     DBG_U(16);
 }
 
+__global__ __launch_bounds__(1024) void bookkeep_b_kernel(DevCfg cfg, TrackerDev t, const float* cand, int n_cand, const int* n_cand_dev, size_t bs,
+                                                          const unsigned long long* corners, unsigned long long corners_target, FilterMeta* meta) {
+    extern __shared__ __align__(16) unsigned char dsh[];
+    bookkeep_b_body(cfg, t, cand, n_cand, n_cand_dev, bs, corners, corners_target, meta, dsh);
+}
+// (round 6) RANSAC and BOTH halves of book-keeping in one launch, for one stream in run-ahead mode: the hand-over counter is bumped between the
+// halves exactly where the two-kernel form bumps it, the refill half polls the detector's counter as before — one launch boundary (~8 us) less
+// on the tracker's serial chain, and up to 16 waves: the 16 RANSAC models are counted by four groups of threads, the ChessGrid walked a cell per wave.
+// Dynamic LDS: max(RANSAC's 8 F + 16, book-keeping's) — the two stages use it one after the other.
+__global__ __launch_bounds__(1024) void ransac_book_kernel(DevCfg cfg, TrackerDev t, const rvio_imu* imu, int m, int* rng, size_t bs, size_t imu_bs,
+                                                           const unsigned long long* done, unsigned long long done_target, FilterMeta* meta,
+                                                           unsigned long long* hand, const float* cand, const int* n_cand_dev,
+                                                           const unsigned long long* corners, unsigned long long corners_target) {
+    extern __shared__ __align__(16) unsigned char dsh_rb[];
+    ransac_body(cfg, t.n_pts, t.tracked, t.un1, t.un2, t.status, imu, m, rng, t.info, bs, imu_bs, dsh_rb);
+    __threadfence_block();
+    __syncthreads();
+    bookkeep_a_body(cfg, t, bs, done, done_target, meta);
+    if (hand) stage_signal(hand);
+    __threadfence();        // the refill half reads what the hand-over half wrote through global memory (tmp_feats, tmp_un, tmp_slot, mid, hist_len)
+    __syncthreads();
+    bookkeep_b_body(cfg, t, cand, 0, n_cand_dev, bs, corners, corners_target, meta, dsh_rb);
+}
 // direct-track mode: the caller supplies vFeatsTracked / vInlierFlag (the KLT result)
 __global__ void load_points_kernel(const int* n_pts_ptr, const float* in_xy, const unsigned char* in_st, float* tracked, unsigned char* status) {
     const int N = *n_pts_ptr;

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,7 @@ struct rvio_hip {
     const double* last_Ab = nullptr;            // the [A|b] block of the last update (its meta row: frame_info)
     int feat_threads = 64;
     size_t feat_lds = 0, fprop_lds = 0, ug_lds = 0, book_lds = 0, jb_lds = 0;
+    int book_waves = 4;
     int solve5_variant = 0;      // solve6_kernel (the LDS-tableau solve behind gemm_T_kernel: batch handles): 0 none, 1: <1,8,8>  2: <2,12,8>  3: <2,16,8>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
@@ -418,6 +421,18 @@ static bool profiler_serialises() {
     return e && *e && std::strcmp(e, "0") != 0 && std::strcmp(e, "False") != 0 && std::strcmp(e, "false") != 0;
 }
 
+// The dynamic-LDS limit of a kernel is a property of the PROCESS, not of a handle: a later handle with a smaller need (a shorter window, a
+// smaller cornerSubPix half-window) must not lower it under an earlier live handle's launches — the limit only ever goes up.
+static hipError_t lds_attr(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::map<const void*, int> limit;
+    std::lock_guard<std::mutex> lk(mu);
+    int& cur = limit[fn];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 static int create_impl(const rvio_config* cfg, int device, int batch, bool front_end, rvio_hip** out) {
     if (!cfg || !out) return RVIO_ERR_INVALID;
     *out = nullptr;
@@ -538,16 +553,16 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
         HIPCHK(h, hipMemcpy2DAsync(t.first, h->slab_bytes, ones.data(), sizeof(int), sizeof(int), (size_t)batch, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)feat_build_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->feat_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)block_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->trunc_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)lit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lit_batch_lds));
+    HIPCHK(h, lds_attr((const void*)feat_build_kernel<16>, (int)h->feat_lds));
+    HIPCHK(h, lds_attr((const void*)feat_build_kernel<4>, (int)h->feat_lds));
+    HIPCHK(h, lds_attr((const void*)gram_reduce_kernel, (int)h->trunc_lds));
+    HIPCHK(h, lds_attr((const void*)block_sum_kernel, (int)h->trunc_lds));
+    HIPCHK(h, lds_attr((const void*)lit_batch_kernel, (int)h->lit_batch_lds));
     if (batch > 1 && gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double) <= 64 * 1024) {
         h->gram_batch_lds = gram_batch_lds_doubles(d.max_len, d.ldh) * sizeof(double);
-        HIPCHK(h, hipFuncSetAttribute((const void*)gemm_T_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(double)));
-        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
-        HIPCHK(h, hipFuncSetAttribute((const void*)gram_reduce_batch_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->gram_batch_lds));
+        HIPCHK(h, lds_attr((const void*)gemm_T_lds_kernel, 2 * 64 * 65 * (int)sizeof(double)));
+        HIPCHK(h, lds_attr((const void*)gram_reduce_batch_kernel<4>, (int)h->gram_batch_lds));
+        HIPCHK(h, lds_attr((const void*)gram_reduce_batch_kernel<6>, (int)h->gram_batch_lds));
     }
     // propagate rides in the per-feature launch: its workgroup builds no feature, so its buffers (Prop3Lds<16>, 86 KB) and the per-feature footprint
     // share the launch's dynamic LDS — max of the two, which fits one CU for every window (rounds 2-4: static + dynamic, the SUM: long windows
@@ -557,9 +572,14 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     if (batch == 1 && c6m <= 96) h->fprop_lds = std::max(h->fprop_lds, c6m <= 64 ? sizeof(S9CholLds<4, 4>) : sizeof(S9CholLds<6, 4>));
     h->fprop_lds = std::max(h->fprop_lds, sizeof(Prop3Lds<16>));
     h->fuse_ok = batch == 1 && !ab_env("RVIO_NO_FUSED_PROPAGATE") && h->fprop_lds <= 160 * 1024;
-    if (h->fuse_ok) HIPCHK(h, hipFuncSetAttribute((const void*)feat_prop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fprop_lds));
-    h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)4 * d.F * 8 + 16;
-    HIPCHK(h, hipFuncSetAttribute((const void*)bookkeep_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->book_lds));
+    if (h->fuse_ok) HIPCHK(h, lds_attr((const void*)feat_prop_kernel, (int)h->fprop_lds));
+    // the refill half of book-keeping walks the ChessGrid one wave per cell with a per-wave list of the cell's points (F float2 each): as many
+    // waves as the 160 KB of LDS hold for one stream (16 at F <= 800: 20 cells -> two rounds instead of five), 4 for batch handles (occupancy)
+    h->book_waves = 4;
+    if (h->batch == 1) for (int nwv = 16; nwv > 4; nwv /= 2) if ((((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)nwv * d.F * 8 + 16 <= (size_t)150 * 1024) { h->book_waves = nwv; break; }
+    h->book_lds = (((size_t)20 * d.F + 7) & ~(size_t)7) + (size_t)h->book_waves * d.F * 8 + 16;
+    HIPCHK(h, lds_attr((const void*)bookkeep_b_kernel, (int)h->book_lds));
+    HIPCHK(h, lds_attr((const void*)ransac_book_kernel, (int)h->book_lds));
     {
         {   // fully unrolled solve kernel: variants <column chunks, rows per wave> for c6 <= 126
             int rpw = 0, nch = 0, nw = 8;
@@ -575,7 +595,7 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if ((batch == 1 || (c6m <= 64 && S9_BATCH)) && c6m <= 192 && !ab_env("RVIO_SOLVE7")) {
                 h->solve9_nt = (c6m <= 64) ? 4 : (c6m <= 96) ? 6 : (c6m <= 128) ? 8 : 12;
                 DALLOC(h, h->S9scr, S9_SLAB_DOUBLES(h->solve9_nt) * (size_t)batch);
-                if (h->solve9_nt == 4) HIPCHK(h, hipFuncSetAttribute((const void*)solve9_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(S9SmallLds)));
+                if (h->solve9_nt == 4) HIPCHK(h, lds_attr((const void*)solve9_small_kernel, (int)sizeof(S9SmallLds)));
             }
             // batch handles: throughput, not latency — solve6 keeps four instances resident per CU (33 KB of LDS against 112 KB) and the
             // multi-workgroup gemm_T_kernel costs nothing there (measured at B = 2048: 2.67 ms per batched frame against 3.09)
@@ -585,16 +605,16 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
             if (h->solve7_variant == 1)
             {
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve7_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+                HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 16, 4>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+                HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 8, 8>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
+                HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 4, 16>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
             }
             if (h->solve5_variant) {
                 h->solve5_lds = (size_t)(nw * rpw) * (64 * nch + 1) * sizeof(double);
                 const int lds = (int)std::max(h->solve5_lds, (size_t)1024);
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<1, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 12, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HIPCHK(h, hipFuncSetAttribute((const void*)solve6_kernel<2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(h, lds_attr((const void*)solve6_kernel<1, 8, 8>, lds));
+                HIPCHK(h, lds_attr((const void*)solve6_kernel<2, 12, 8>, lds));
+                HIPCHK(h, lds_attr((const void*)solve6_kernel<2, 16, 8>, lds));
             }
         }
         const size_t c6t = (c6m + 15) / 16;
@@ -602,13 +622,13 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             const size_t ls = c6m + 1, dmx = 24 + c6m;
             h->jb_lds = (3 * dmx * ls + std::max((size_t)c6m * ls, (size_t)JB_TL_DOUBLES)) * sizeof(double);
             if (h->jb_lds > 160 * 1024) h->jb_lds = 0;
-            else HIPCHK(h, hipFuncSetAttribute((const void*)joseph_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->jb_lds));
+            else HIPCHK(h, lds_attr((const void*)joseph_batch_kernel, (int)h->jb_lds));
         }
         h->ug_lds = 2 * 16 * (c6t * 16 + 1) * sizeof(double);
-        HIPCHK(h, hipFuncSetAttribute((const void*)ug_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ug_lds));
-        HIPCHK(h, hipFuncSetAttribute((const void*)ug_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(UGL_LDS_DOUBLES * sizeof(double))));
-        HIPCHK(h, hipFuncSetAttribute((const void*)final_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FNL_LDS_DOUBLES * sizeof(double))));
-        HIPCHK(h, hipFuncSetAttribute((const void*)joseph_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(JL_LDS_DOUBLES * sizeof(double))));
+        HIPCHK(h, lds_attr((const void*)ug_kernel, (int)h->ug_lds));
+        HIPCHK(h, lds_attr((const void*)ug_lds_kernel, (int)(UGL_LDS_DOUBLES * sizeof(double))));
+        HIPCHK(h, lds_attr((const void*)final_lds_kernel, (int)(FNL_LDS_DOUBLES * sizeof(double))));
+        HIPCHK(h, lds_attr((const void*)joseph_lds_kernel, (int)(JL_LDS_DOUBLES * sizeof(double))));
     }
     if (batch > 1 && !h->solve5_variant && !h->solve7_variant) { h->err = "batched filter: clone window too long for the unrolled solve kernel (6n <= 126)"; return RVIO_ERR_UNSUPPORTED; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1199,14 +1219,14 @@ static int detector_init(rvio_hip* h) {
     }
     HIPCHK(h, hipMemcpyAsync(const_cast<float*>(q.spmask), hm.data(), sizeof(float) * hm.size(), hipMemcpyHostToDevice, h->stream));   // one copy, shared by all instances
     HIPCHK(h, hipStreamSynchronize(h->stream));   // (hm is a local)
-    if (spw > 15) HIPCHK(h, hipFuncSetAttribute((const void*)subpix_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)subpix_wide_lds(spw)));
+    if (spw > 15) HIPCHK(h, lds_attr((const void*)subpix_wide_kernel, (int)subpix_wide_lds(spw)));
     std::vector<int> minkey((size_t)h->batch, (int)0x80000000);
     for (DetDev* qq : {&h->dets[0], &h->dets[1], &h->dets[2]})
         HIPCHK(h, hipMemcpy2DAsync(qq->maxkey, h->slab_bytes ? h->slab_bytes : sizeof(int), minkey.data(), sizeof(int), sizeof(int), (size_t)(h->det_in_slab ? h->batch : 1),
                                    hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFuncSetAttribute((const void*)neigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEIGH_LDS));
-    HIPCHK(h, hipFuncSetAttribute((const void*)greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GREEDY_LDS));
+    HIPCHK(h, lds_attr((const void*)neigh_kernel, (int)NEIGH_LDS));
+    HIPCHK(h, lds_attr((const void*)greedy_kernel, (int)GREEDY_LDS));
     h->det_ready = true;
     return RVIO_OK;
 }
@@ -1394,6 +1414,16 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             h->tail = h->side;
             unsigned long long* hand = nullptr;
             if (h->dev_sync) { hand = &h->stage_sync->handover; h->stage_tgt.handover++; }
+            // one stream, device-side counters: RANSAC and both halves of book-keeping are ONE launch (the refill half polls the detector's counter inside it)
+            static const bool no_book_fuse = ab_env("RVIO_NO_FUSED_BOOK") != nullptr;   // A/B timing
+            if (fused && h->dev_sync && !no_book_fuse) {
+                const int cix = ab_env("RVIO_DBG_ONE_CORNERS") ? 0 : h->ic;
+                h->gate_pending = true; h->gate_target = h->stage_tgt.handover;
+                hipLaunchKernelGGL(ransac_book_kernel, dim3(1, 1, B), dim3(64 * h->book_waves), h->book_lds, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
+                                   done, done_target, h->meta, hand, xy, nout, &h->stage_sync->corners[cix], h->stage_tgt.corners[cix]);
+                HIPCHK(h, hipGetLastError());
+                return RVIO_OK;
+            }
             if (fused)
                 hipLaunchKernelGGL(ransac_book_a_kernel, dim3(1, 1, B), dim3(256), (size_t)8 * h->dc.F + 16, h->tail, h->dc, h->t, d_imu, m, h->rng, bs, h->imu_bs,
                                    done, done_target, h->meta, hand);
@@ -1412,10 +1442,10 @@ static int post_klt_dev(rvio_hip* h, const rvio_imu* d_imu, int m, const float* 
             HIPCHK(h, hipStreamWaitEvent(h->ts, h->evD1, 0));
             hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1, 1, B), dim3(256), 0, h->tail, h->dc, h->t, bs, done, done_target, h->meta, (unsigned long long*)nullptr);
         }
-        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1, 1, B), dim3(256), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs, corners, corners_target, h->meta);
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1, 1, B), dim3(64 * h->book_waves), h->book_lds, h->tail, h->dc, h->t, xy, 0, nout, bs, corners, corners_target, h->meta);
     } else {
         hipLaunchKernelGGL(bookkeep_a_kernel, dim3(1), dim3(256), 0, h->ts, h->dc, h->t, (size_t)0, (const unsigned long long*)nullptr, 0ull, h->meta, (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1), dim3(256), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0,
+        hipLaunchKernelGGL(bookkeep_b_kernel, dim3(1), dim3(64 * h->book_waves), h->book_lds, h->ts, h->dc, h->t, d_cand, n_cand, (const int*)nullptr, (size_t)0,
                            (const unsigned long long*)nullptr, 0ull, h->meta);
     }
     HIPCHK(h, hipGetLastError());
@@ -2085,7 +2115,7 @@ int rvio_hip_debug_poison(rvio_hip* h, int what) {
     }
     if (what & 2) {
         static bool attr = false;
-        if (!attr) { HIPCHK(h, hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        if (!attr) { HIPCHK(h, lds_attr((const void*)lds_poison_kernel, 160 * 1024)); attr = true; }
         hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(256), 160 * 1024, h->stream, 0x7ff4dead00000000ull, (int*)nullptr);
         HIPCHK(h, hipGetLastError());
     }
