@@ -32,6 +32,7 @@ abi, synth = rv.abi, rv.synth
 
 K0 = 38  # last stationary frame of the synthetic sequence (t = 1.9 s)
 PARITY_FRAMES = 141   # frames of the free-running device-vs-CPU comparison
+ROOFLINE_FRAMES = 141  # frames the stage latencies and the roofline candidates are measured after (fixed: independent of --steps)
 PEAK_F64_ = 78.6      # TFLOP/s FP64 (vector == matrix), public MI355X spec
 CPU_WARM, CPU_TIMED = 50, 300   # the CPU baseline is p50 / p95 over >= 300 frames after 50 warm-up frames
 
@@ -394,7 +395,15 @@ def main():
         # (also at N>1: the per-kernel roofline is a property of one GPU; the other ranks wait in the barrier below)
         x_single = None
         try:
-            out.update(latency_pass(cfg, torch, fs, wi, ai, ni, device=local_rank, name=args.config))
+            # The stage latencies and the roofline candidates are measured on a FIXED prefix of the sequence (ROOFLINE_FRAMES frames: window full,
+            # the same operands whatever --steps says) so that the object does not change identity between a 20-step and a 200-step run; the
+            # sharded comparison below needs the state after the timed run's own frames and keeps them.
+            if sharded or fs.n == ROOFLINE_FRAMES:
+                fl_ = fs
+            else:
+                li_ = long_inputs()
+                fl_ = FrameSet(torch, cfg, *[a_[:ROOFLINE_FRAMES] if a_ is not None else None for a_ in li_])
+            out.update(latency_pass(cfg, torch, fl_, wi, ai, ni, device=local_rank, name=args.config))
             x_single = out.pop("x_final")
         except Exception as e:   # noqa: BLE001
             out["latency_pass"] = {"error": repr(e)[:300]}
@@ -434,7 +443,9 @@ def main():
                   "achieved": top["achieved_tflops_fp64"], "peak": top["achieved_tflops_fp64"] / top["frac_fp64_peak"] if top["frac_fp64_peak"] else None, "unit": "TFLOP/s",
                   "frac": top["frac_fp64_peak"], "by": "W_filter of SURVEY.md 8(d) (algorithmic FP64 work of the frames run) / wall time of the timed batched frames",
                   "ms_per_batched_frame": top["ms_per_batched_frame"], "traffic": None}
-            mc = os.path.join(ROOT, "profiles", "r05_batched_mfma_util.json")
+            mc = os.path.join(ROOT, "profiles", "r06_batched_mfma_util.json")
+            if not os.path.exists(mc):
+                mc = os.path.join(ROOT, "profiles", "r05_batched_mfma_util.json")
             if os.path.exists(mc):   # the matrix pipe's own counter (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64, its own pass): committed, cannot be read live
                 try:
                     with open(mc) as f:
@@ -443,7 +454,7 @@ def main():
                         a = cm["mfma_flop_per_batched_frame"] / (top["ms_per_batched_frame"] * 1e-3) / 1e12
                         rb["by_mfma_counter"] = {"mfma_flop_per_batched_frame": cm["mfma_flop_per_batched_frame"], "achieved": a, "unit": "TFLOP/s", "frac": a / PEAK_F64_,
                                                  "what": "FP64 MFMA flop the matrix pipe itself counted for one batched frame (committed rocprofv3 --pmc pass, "
-                                                         "profiles/r05_batched_mfma_util.json) / the frame time measured live here"}
+                                                         "profiles/%s) / the frame time measured live here" % os.path.basename(mc)}
                     else:
                         rb["by_mfma_counter"] = {"skipped": "committed counters are for %s instances" % cm.get("instances")}
                 except Exception as e:   # noqa: BLE001
@@ -487,6 +498,11 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
     if rank == 0:
+        # the driver keeps the head of the line: the contract's keys first, then the objects the review reads — roofline, cpu_baseline, the drop-in
+        # call on host buffers (PCIe inclusive) and the update at the defined full load — then everything else in the order it was measured
+        head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "host_buffers", "update_at_load", "p50_ekf_update_ms", "timed_run_parity"]
+        out = dict([(k, out[k]) for k in head if k in out] + [(k, v) for k, v in out.items() if k not in head])
         print(json.dumps(out), flush=True)
 
 
@@ -572,14 +588,21 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     PEAK_F64 = 78.6   # TFLOP/s, FP64 vector == FP64 matrix on MI355X (public spec; not in the measured tables of the guide)
     t_solve = h.time_kernel(0, 50) * 1e-6
     t_klt = h.time_kernel(1, 50) * 1e-6
-    t_feat = h.time_kernel(2, 50) * 1e-6
+    try:
+        t_feat = h.time_kernel(8, 50) * 1e-6       # feat_prop_kernel itself, as the pipelined frame launches it (state put aside and restored)
+        feat_in_situ = True
+    except Exception:   # noqa: BLE001  (a window whose fused launch does not fit LDS: the per-feature workgroups in a launch of their own)
+        t_feat = h.time_kernel(2, 50) * 1e-6
+        feat_in_situ = False
     t_subpix = h.time_kernel(6, 50) * 1e-6
+    t_greedy = h.time_kernel(9, 50) * 1e-6
     # (rvio_hip.hip: the blocked SPD solve; at 6n <= 64 behind the Cholesky role its all-LDS form; at 6n > 96 its split form — six launches)
     solve_name = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel" if c6 <= 96 else "solve9_prod_kernel<0..3> + solve9_sweep_kernel + solve9_dx_kernel"
     solve_match = "solve9_small_kernel" if c6 <= 64 else "solve9_kernel" if c6 <= 96 else "solve9_sweep_kernel"
-    # solve: T = s2 I + A Pcc on the matrix cores, then the in-place Gauss-Jordan of T (c6 = 6n columns, register tableau).  Algorithmic
-    # FP64 work per launch = 2 c6^3 (the product) + c6 steps x c6 rows x (c6+1) columns x 2 flops (the 2r^3 term of U8)
-    fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1)
+    # solve: the work SURVEY.md 8d prices for U8 — T = s2 I + A Pcc (2 c6^3) and the inverse of T (c6 steps x c6 rows x (c6 + 1) columns x 2 flops).  The
+    # kernel timed here runs BEHIND the Cholesky role (the factor of the clone block rides in the per-feature launch / on a queue of its own,
+    # off the chain), so the flops of that factor, c6^3 / 3, are taken out of the numerator: the figure prices what the timed kernel does.
+    fl_solve = 2.0 * c6 ** 3 + 2.0 * c6 * c6 * (c6 + 1) - c6 ** 3 / 3.0
     # per-feature stage (U1-U5): the gate term of W_filter for the tracks the last frame handed over, sum_f 2 rho (6n)^2 + 2 rho^2 (6n) + 4/3 rho^3
     ty_l, ln_l, _ = h.get_tracks()
     fl_feat = 0.0
@@ -589,48 +612,57 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
     it_l = 10
     by_klt = F * 4 * (16 * 16 * 5) + F * 4 * it_l * 16 * 16     # B_klt of SURVEY.md 8d, it_l = 10: template + it_l bilinear windows per level
     by_subpix = F * (4.0 * 17 * 17) * 5                          # cornerSubPix: a 17x17 float window re-sampled per iteration, ~5 iterations per corner
+    n_cand_l = int(h.frame_info().get("n_tracked_in", F))
     cands = [
         {"bound": "mfma", "kernel": "%s (W = (s2 I + A Pcc)^-1, dx, state injection%s)" % (solve_name, "; one workgroup" if c6 <= 96 else "; avg_us = the six launches together"),
          "match": solve_match, "launched_by_timed_path": solve_name,
          "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_solve * 1e6,
-         "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles; 6n <= 96: one workgroup on ONE CU (0.31 TFLOP/s of the chip's %.1f), the Cholesky of the "
-                 "clone block rides in the per-feature launch; 6n > 96: the four product phases are chip-wide launches, the sweep one workgroup, the Cholesky factor runs beside the "
-                 "filter chain on a queue of its own; latency bound: %d 16 x 16 in-wave factorisations in sequence; algorithmic work = that of the LU inverse"
-                 % (PEAK_F64, (c6 + 15) // 16)},
+         "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles; 6n <= 96: one workgroup on ONE CU (%.2f TFLOP/s of the chip's %.1f), the Cholesky of the "
+                 "clone block rides in the per-feature launch (off the chain: NOT in avg_us, and its c6^3 / 3 flops are not in `achieved`); 6n > 96: the four product phases are "
+                 "chip-wide launches, the sweep one workgroup, the Cholesky factor runs beside the filter chain on a queue of its own; latency bound: %d 16 x 16 in-wave "
+                 "factorisations in sequence" % (PEAK_F64 / 256.0, PEAK_F64, (c6 + 15) // 16)},
         {"bound": "hbm", "kernel": "klt_kernel3 (4-level pyramidal LK, one wave per feature)", "match": "klt_kernel3", "launched_by_timed_path": "klt_kernel3 (forward match)",
          "achieved": by_klt / t_klt / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_klt * 1e6,
          "note": "timed matching the current image back onto the previous one from the current feature positions (the forward match's displacements, "
                  "reversed): the frame's own inputs are gone once book-keeping has moved the features"},
-        {"bound": "mfma", "kernel": "the per-feature workgroups of feat_prop_kernel (U1-U5, FP64 MFMA gate; %d features handed over by the last frame)" % len(ln_l), "match": "feat_",
-         "launched_by_timed_path": "feat_prop_kernel: these workgroups + propagate as one more workgroup of the same launch; timed here as feat_build_kernel<16> = the same "
-                                   "workgroups in a launch of their own (propagate mutates P in place and cannot be repeated)",
+        {"bound": "mfma", "kernel": "feat_prop_kernel (U1-U5 per feature with the FP64 MFMA gate, %d features handed over by the last frame, + PreIntegrator::propagate and the Cholesky role as "
+                                    "two more workgroups)" % len(ln_l) if feat_in_situ else
+                                    "the per-feature workgroups of feat_prop_kernel in a launch of their own (feat_build_kernel<16>; %d features)" % len(ln_l), "match": "feat_",
+         "launched_by_timed_path": "feat_prop_kernel" + ("" if feat_in_situ else " (timed as feat_build_kernel<16>: the fused launch of this window does not fit LDS)"),
          "achieved": (fl_feat / t_feat / 1e12) if fl_feat > 0 else None, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_feat * 1e6},
     ]
-    detector = {"bound": "hbm", "kernel": "subpix_kernel (cornerSubPix, 4 waves per corner; detector = section 8(f))", "match": "subpix_kernel",
-                "achieved": by_subpix / t_subpix / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_subpix * 1e6}
-    for c in cands + [detector]:
+    det = [{"bound": "hbm", "kernel": "subpix_kernel (cornerSubPix, 4 waves per corner; detector = section 8(f))", "match": "subpix_kernel", "launched_by_timed_path": "subpix_kernel",
+            "achieved": by_subpix / t_subpix / 1e9, "peak": 8000.0, "unit": "GB/s", "avg_us": t_subpix * 1e6},
+           {"bound": "hbm", "kernel": "greedy_kernel (goodFeaturesToTrack's min-distance selection as a priority-ordered maximal independent set, ONE workgroup; detector = section 8(f))",
+            "match": "greedy_kernel", "launched_by_timed_path": "greedy_kernel",
+            "achieved": None, "peak": 8000.0, "unit": "GB/s", "avg_us": t_greedy * 1e6,
+            "note": "a serial selection over the candidate lists in LDS: no bytes or flops worth pricing (latency of the rounds); listed because it is one of the longest kernels "
+                    "of the image chain, which runs two frames deep beside the chains that set the period"}]
+    for c in cands + det:
         c["frac"] = None if c["achieved"] is None else c["achieved"] / c["peak"]
         # HBM-side bytes per launch: PMC counters cannot be read live, so this is the committed rocprofv3 --pmc result OF THIS CONFIGURATION
-        # (profiles/r04_pmc_traffic_cfg<name>.json, else r03_: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
+        # (profiles/r06_pmc_traffic_cfg<name>.json, else an earlier round's: FETCH_SIZE + WRITE_SIZE as reported, separate passes) or null
         c["traffic"], c["traffic_unit"] = pmc_traffic(name, c.pop("match"))
     cands.sort(key=lambda c: -c["avg_us"])
-    res["roofline"] = dict(cands[0], dominant_by="rule: the largest live average (HIP events, 50 launches on the handle's stream, rvio_hip_debug_time_kernel) among the three "
-                                                  "longest section-8(a) kernels the timed frame launches — KLT, the per-feature stage, the solve; all three are listed "
-                                                  "(roofline + roofline_other) with their own fractions, so a flip between two close averages changes the order, not the content",
+    res["roofline"] = dict(cands[0], dominant_by="rule: the largest live average (HIP events, 50 launches on the handle's stream, rvio_hip_debug_time_kernel) among the section-8(a) "
+                                                  "kernels of the frame, each launched in the very form the pipelined frame launches it (feat_prop_kernel itself, not its parts), on the "
+                                                  "operands left after frame %d of the stock sequence — a FIXED state (window full), independent of --steps, so the object names the "
+                                                  "same kernel in a 20-step and in a 200-step run up to timing noise between near-equal candidates; every candidate is listed "
+                                                  "(roofline + roofline_other) with its own fraction" % (fs.n - 1),
                            context="a single 752x480 stream offers 51 MFLOP and 3.7 MB per frame (SURVEY.md 8d), i.e. <<1% of either roof by construction; "
                                    "update_at_load.roofline prices the whole update at full load, batched_filter / batched_streams the same kernels with the chip full")
-    res["roofline_other"] = cands[1:] + [detector]
+    res["roofline_other"] = cands[1:] + det
     h.close()
     return res
 
 
 def pmc_traffic(cfg_name, kernel_substr):
     """(bytes per launch, source) of a kernel from the committed rocprofv3 --pmc summary of THIS configuration, or (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic_cfg%s.json" % cfg_name)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_cfg%s.json" % cfg_name)
-    if not os.path.exists(path):      # (configurations whose PMC pass was not repeated this round keep last round's: same kernels)
-        path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg%s.json" % cfg_name)
+    path = None
+    for rnd in ("r06", "r05", "r04", "r03"):      # (configurations whose PMC pass was not repeated this round keep an earlier round's: same kernels)
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_cfg%s.json" % (rnd, cfg_name))
+        if os.path.exists(path):
+            break
     try:
         with open(path) as fh:
             e = [v for k, v in json.load(fh).items() if kernel_substr in k]

@@ -33,6 +33,8 @@
 // [A|b] = Rn^T [Rn | zn] of the nRank leading rows goes to the same solve as ever.
 #pragma once
 
+// (experiments only: rvio_hip_debug_literal_force — every update the literal sweep CAN take (<= LIT_FEATS features, > 2 accepted, tall) takes it)
+__device__ int g_lit_force = 0;
 #define LIT_FEATS 24      // an update handed more features than this never takes the literal path (M <= LIT_FEATS * rho_max rows)
 #define LIT_SLACK 0       // "barely tall" (rows - 6n <= LIT_SLACK) as a second trigger: 0 = off — see the header
 #define LIT_SPARE 48      // the gap trigger applies to stacks with few rows to spare only: rows - 6n <= LIT_SPARE (see lit_decide)
@@ -115,6 +117,7 @@ __device__ inline bool lit_decide(const double* lit_rows, int n, int n_feat, int
     const int c6 = 6 * n;
     if (!lit_rows || n_feat > LIT_FEATS || good <= 2 || rows <= c6) return false;     // (uniform: no barrier below is skipped by a part of the workgroup)
     if (rows - c6 <= LIT_SLACK) return true;
+    if (__hip_atomic_load(&g_lit_force, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;   // (uniform)
     // a gap stops the scan only when the stack has few rows to spare: with many, informative rows move up into the gap and the residue of the
     // over-determined group ends at the bottom (every exception of the sweeps: rows - 6n <= 21; the one trigger on the stock sequence: 390 spare
     // rows, literal result = information form to 1e-16 — and 0.8 ms of sweep)

@@ -158,6 +158,7 @@ struct rvio_hip {
     bool slab_mode = false;
     int batch = 1;
     const rvio_imu* fuse_imu = nullptr;   // whole-frame path: propagate of this frame rides in the per-feature launch (feat_prop_kernel)
+    const rvio_imu* time_imu = nullptr; int time_m = 0;   // the IMU batch of the last fused frame (rvio_hip_debug_time_kernel(8) only: the caller's buffer)
     int fuse_m = -1;                      // >= 0 while such a propagate is pending
     bool fuse_ok = false;
     bool one_stream = false;
@@ -831,6 +832,7 @@ static int ensure_imu_capacity(rvio_hip* h, int m) {
 static int propagate_dev(rvio_hip* h, const rvio_imu* d_imu, int m, size_t imu_bs = 0, hipStream_t st = nullptr) {   // imu_bs = 0: every instance integrates the same samples
     static const bool prop_b = ab_env("RVIO_NO_PROP_B") == nullptr;   // A/B timing
     if (!st) st = h->stream;
+    h->time_imu = d_imu; h->time_m = m;   // (rvio_hip_debug_time_kernel(8))
     if (h->batch > 8 && prop_b)
         hipLaunchKernelGGL(propagate_kernel3b, dim3(1, 1, h->batch), dim3(256), 0, st, h->dc, h->meta, h->n_clones_host, h->x[h->cur], h->P[h->cur], d_imu, m,
                            h->slab_bytes, imu_bs);
@@ -1702,6 +1704,7 @@ static int frame_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
         return RVIO_OK;
     }
     if (fuse) { h->fuse_imu = d_imu; h->fuse_m = m; }   // consumed by the per-feature launch of this frame's update (same condition: it runs)
+    if (fuse) { h->time_imu = d_imu; h->time_m = m; }
     rc = frame_tail_dev(h, d_imu, m, /*propagated=*/true);
     h->fuse_m = -1;
     const double t4 = dbg_host ? now() : 0;
@@ -2002,14 +2005,32 @@ int rvio_hip_debug_tracked(rvio_hip* h, int n, float* xy, float* un_xy) {
 int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us) {
     if (!h || !avg_us || iters < 1) return RVIO_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream_t));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    { const int rcd = drain_all(h); if (rcd != RVIO_OK) return rcd; }   // (every queue of the handle: the run-ahead image chains too)
     const DevCfg& d = h->dc;
     const int n = h->n_clones_host;
     hipEvent_t e0, e1;
+    double *bx = nullptr, *bP = nullptr;
+    if (which == 8) {   // (the fused launch propagates in place: the state is put aside and restored behind the timed launches)
+        if (h->batch > 1 || !h->fuse_ok || !h->time_imu || n < 1) return RVIO_ERR_UNSUPPORTED;
+        HIPCHK(h, hipMalloc(&bx, sizeof(double) * d.xdmax)); HIPCHK(h, hipMalloc(&bP, sizeof(double) * d.dmax * d.dmax));
+        HIPCHK(h, hipMemcpyAsync(bx, h->x[h->cur], sizeof(double) * d.xdmax, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(bP, h->P[h->cur], sizeof(double) * d.dmax * d.dmax, hipMemcpyDeviceToDevice, h->stream));
+    }
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int it = 0; it < iters; ++it) {
+        if (which == 8) {
+            // feat_prop_kernel exactly as the pipelined frame launches it: the per-feature workgroups of the last hand-over table + PreIntegrator::propagate on the
+            // IMU batch of the last frame (the caller's device buffer must still be alive) + at 6n <= 96 the Cholesky role
+            const bool chol = h->solve9_nt && h->solve9_nt <= 6;
+            hipLaunchKernelGGL(feat_prop_kernel, dim3(d.Fu + 1 + (chol ? 1 : 0)), dim3(256), h->fprop_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
+                               h->t.n_feat, h->t.types, h->t.len, h->t.meas, h->partial, h->nrows, h->acc, h->ndof, h->gamma, h->pfinv, h->tm_global, h->bin,
+                               h->meta, h->time_imu, h->time_m, chol ? h->S9scr : (double*)nullptr, h->solve9_nt, 0, 1, h->lit_rows);
+        } else if (which == 9) {   // the detector's selection kernel (one workgroup: priority-ordered maximal independent set) on the candidates of the last detector call
+            if (h->batch > 1 || !h->det_ready) return RVIO_ERR_UNSUPPORTED;
+            const DetDev q = [&] { DetDev v = h->dets[h->det_set_last]; v.xy = h->det_xy2[h->dslot]; v.n_out = h->det_nout + h->dslot; return v; }();
+            hipLaunchKernelGGL(greedy_kernel, dim3(1, 1, 1), dim3(GREEDY_T), GREEDY_LDS, h->stream, q, h->slab_bytes);
+        } else
         if (which == 0) {
             h->chol_ready = h->solve9_nt && (h->solve9_nt <= 6 || h->stream_l) && !ab_env("RVIO_S9_FULL");   // (time what the chain sees: the Cholesky factor rides in the per-feature launch / runs on its own queue; the slab holds the factor of the last update)
             launch_solve(h, n, h->block);
@@ -2049,10 +2070,16 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         } else return RVIO_ERR_INVALID;
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
+    if (which == 8) {
+        HIPCHK(h, hipMemcpyAsync(h->x[h->cur], bx, sizeof(double) * d.xdmax, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->P[h->cur], bP, sizeof(double) * d.dmax * d.dmax, hipMemcpyDeviceToDevice, h->stream));
+        h->chol_ready = false;
+    }
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (bx) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(bx); (void)hipFree(bP); }
     *avg_us = ms * 1e3f / iters;
     HIPCHK(h, hipGetLastError());
     return RVIO_OK;
@@ -2209,6 +2236,15 @@ int rvio_hip_debug_ring3(rvio_hip* h, long long* out512) {
     int rc = rvio_hip_sync(h);
     if (rc != RVIO_OK) return rc;
     HIPCHK(h, hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_ring3), sizeof(long long) * 512));
+    return RVIO_OK;
+}
+// experiments (tools/at_rest_literal.py): every update the literal sweep can take takes it (process-wide switch)
+int rvio_hip_debug_literal_force(rvio_hip* h, int on) {
+    if (!h) return RVIO_ERR_INVALID;
+    const int rc = drain_all(h);
+    if (rc != RVIO_OK) return rc;
+    const int v = on ? 1 : 0;
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_lit_force), &v, sizeof v));
     return RVIO_OK;
 }
 int rvio_hip_debug_clocks2(rvio_hip* h, long long* out64) {

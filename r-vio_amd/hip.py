@@ -359,7 +359,7 @@ class RvioHip:
         return xy, un
 
     def time_kernel(self, which, iters=20):
-        """average device time (us) of one hot kernel: 0 solve, 1 KLT, 2 per-feature build, 3 share reduction, 4 U/G/P1, 5 Joseph form, 6 cornerSubPix, 7 U/G/P1 + Joseph form as launched (HIP events, handle stream)"""
+        """average device time (us) of one hot kernel: 0 solve, 1 KLT, 2 per-feature build, 3 share reduction, 4 U/G/P1, 5 Joseph form, 6 cornerSubPix, 7 U/G/P1 + Joseph form as launched, 8 feat_prop_kernel as the pipelined frame launches it (state restored), 9 the detector's greedy selection (HIP events, handle stream)"""
         us = C.c_float(0)
         self._ck(self.L.rvio_hip_debug_time_kernel(self.h, int(which), int(iters), C.byref(us)), "debug_time_kernel")
         return float(us.value)

@@ -1,11 +1,18 @@
 set -u
-mkdir -p gpurun_out/r06d
+mkdir -p gpurun_out/r06f
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 200 python tools/chain_clocks.py 200 > gpurun_out/r06d/chain_clocks.txt 2>&1
-RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 200 python tools/chain_clocks.py 25 > gpurun_out/r06d/chain_clocks_25.txt 2>&1
-timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/r06d/kt -o k -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-streams --no-latency --batch '' --batch-streams '' > gpurun_out/r06d/bench_prof.json 2>/dev/null
-DB=$(find gpurun_out/r06d/kt -name "*.db" | head -1)
-python tools/timeline.py $DB 0 100000 > gpurun_out/r06d/timeline_driver.txt 2>&1
-python tools/rocpd_stats.py $DB gpurun_out/r06d/kernel_stats_driver.md > /dev/null
-rm -rf gpurun_out/r06d/kt
-cat gpurun_out/r06d/chain_clocks.txt
+timeout 600 python tools/at_rest_literal.py > gpurun_out/r06f/at_rest_literal.txt 2>&1
+grep -v amdgpu gpurun_out/r06f/at_rest_literal.txt
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06f/bench_driver.json 2> gpurun_out/r06f/bench_driver.err
+tail -c 300 gpurun_out/r06f/bench_driver.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r06f/bench_driver.json').read().strip().splitlines()[-1])
+print(list(d.keys())[:22])
+print(d['value'], d['ms_per_step'])
+r=d['roofline']; print(r['kernel'][:60], r['avg_us'], r['frac'])
+for c in d['roofline_other']: print('  ', c['kernel'][:60], c['avg_us'], c['frac'])
+print(d.get('latency_ms_p50'), d.get('p50_ekf_update_ms'))
+print(d.get('host_buffers'))
+print(d.get('timed_run_parity'), d.get('parity',{}).get('max_state_delta'))
+PY
