@@ -61,6 +61,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                                                 double* pfinv_out, double* tm_global, size_t bs, BatchIn bin, FilterMeta* meta, const int f,
                                                 const double* gpose = nullptr, const int* gvalid = nullptr, double* lit_rows = nullptr) {
     extern __shared__ __align__(16) double lds[];
+    DBG_P0();
     const BatchIdx bi = batch_plain();
     x = zoffi(x, bs, bi.z); P = zoffi(P, bs, bi.z); Gshare = zoffi(Gshare, bs, bi.z); nrows_out = zoffi(nrows_out, bs, bi.z); acc_out = zoffi(acc_out, bs, bi.z);
     ndof_out = zoffi(ndof_out, bs, bi.z); gamma_out = zoffi(gamma_out, bs, bi.z); pfinv_out = zoffi(pfinv_out, bs, bi.z);
@@ -113,9 +114,9 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     const double sig = cfg.sigma_im, sig2 = sig * sig;
     const m33 Ric = ldm33(cfg.Ric), Rci = ldm33(cfg.Rci);
     const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
-    DBG_T(30);
+    DBG_T(30); DBG_P(30);
     __syncthreads();
-    DBG_T(31);
+    DBG_T(31); DBG_P(31);
 
     // ---- U1 relative-pose chain (Updater.cc:114-141).  R(q_i) for every clone in parallel (lane <-> clone), the chain
     // R_I(i) = R(q_i) R_I(i-1), t_I(i) = R(q_i) (t_I(i-1) - p_i) as a short serial product of 3x3 matrices, then the
@@ -159,7 +160,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         }
     }
     __syncthreads();
-    DBG_T(32);
+    DBG_T(32); DBG_P(32);
 
     // ---- U2 inverse-depth LM triangulation (Updater.cc:143-269): lane i <-> observation i
     double phi = 0, psi = 0, rho = 0;
@@ -252,7 +253,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         if (lane == 0) { misc[0] = phi; misc[1] = psi; misc[2] = rho; misc[3] = valid ? 1.0 : 0.0; }
     }
     __syncthreads();
-    DBG_T(33);
+    DBG_T(33); DBG_P(33);
     phi = misc[0]; psi = misc[1]; rho = misc[2]; valid = misc[3] != 0.0;
     if (tid == 0) { pfinv_out[3 * f] = phi; pfinv_out[3 * f + 1] = psi; pfinv_out[3 * f + 2] = rho; }
     if (!valid) {
@@ -312,7 +313,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { o[a * 6 + b] = left.m[3 * a + b]; o[a * 6 + 3 + b] = right.m[3 * a + b]; }
     }
     __syncthreads();
-    DBG_T(34);
+    DBG_T(34); DBG_P(34);
     {   // all (i, j<i) 2x6 blocks, flattened over the workgroup
         const int nitems = (Lu * (Lu - 1) / 2) * 12;
         for (int e = tid; e < nitems; e += T) {
@@ -370,7 +371,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         }
     }
     __syncthreads();
-    DBG_T(35);
+    DBG_T(35); DBG_P(35);
     if (lit) {   // the RAW block [Hx | r] (rows 0..M2-1, columns [cLo, cHi) and the residual column c6) and Hf, before the projection below: literal.h
         double* lr = lit_rows + (size_t)f * M2max * ldh;
         double* lh = lit_rows + (size_t)LIT_FEATS * M2max * ldh + (size_t)f * M2max * 3;
@@ -396,7 +397,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         }
     }
     __syncthreads();
-    DBG_T(36);
+    DBG_T(36); DBG_P(36);
     // ---- U5 Mahalanobis gate (Updater.cc:404-422) on rows N..M2-1
     const int rr = M2 - N;             // nDOF
     const double* Hn = Hx + (size_t)N * ldh;
@@ -433,7 +434,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         }
     }
     __syncthreads();
-    DBG_T(37);
+    DBG_T(37); DBG_P(37);
     // S = Tm Hn^T + sig2 I  (lower triangle stands for the symmetrised matrix .5 (S + S^T), Updater.cc:418)
     const int lds_s = rhomax + 1;
     {
@@ -466,7 +467,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         for (int j = tid; j < rr; j += T) S[rr * lds_s + j] = Hn[(size_t)j * ldh + c6];   // residual as an extra row
     }
     __syncthreads();
-    DBG_T(38);
+    DBG_T(38); DBG_P(38);
     // gamma = |r^T S^-1 r| by a square-root-free L D L^T of S with the residual row appended (reference:
     // colPivHouseholderQr().solve, Updater.cc:420).  Columns stay unscaled (S[i][k] = l_ik d_k), so the residual row
     // carries w = L^-1 r and gamma = sum_k w_k^2 / d_k.  Thread <-> element (i, j) of the lower triangle (+ residual row):
@@ -529,7 +530,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         }
         if (tid == 0) misc[8] = fabs(gsum);
     }
-    DBG_T(39);
+    DBG_T(39); DBG_P(39);
     __syncthreads();
     gam = misc[8];
     const bool accept = gam < kChi2Dev[rr - 1];
@@ -567,7 +568,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
             }
         }
     }
-    DBG_T(40);
+    DBG_T(40); DBG_P(40);
 }
 
 template <int HOIST>

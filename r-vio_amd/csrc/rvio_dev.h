@@ -75,6 +75,7 @@ __device__ __forceinline__ BatchIdx batch_plain() { return {(int)blockIdx.x, (in
 struct BatchIn { size_t imu, n_feat, types, len, meas; };
 
 __device__ long long g_dbg[64];
+__device__ long long g_dbg3[64];   // (round 6) feat_build_body's phases over all workgroups: sums [0..15], counts [32..47] (DBG_P)
 __device__ long long g_dbg2[64];   // (round 6) phase stamps of the side chain's kernels: klt_kernel3 workgroup 0, RANSAC, both halves of book-keeping (tools/side_phase_clocks.py)
 // (instrumented build only) start stamps of the filter chain's stages, one row of 8 per frame in a ring of 64 frames, on the constant
 // 100 MHz clock all CUs share: tools/chain_clocks.py turns them into the in-situ timeline of the pipelined run
@@ -92,11 +93,17 @@ __device__ long long g_ring3[64 * 8];   // the image chain of frame `tag` (CLAHE
 #define DBG_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dbg[i] = clock64(); } while (0)
 #define DBG_W(cond, i) do { if (cond) g_dbg[i] = wall_clock64(); } while (0)   /* constant 100 MHz clock: comparable across kernels */
 #define DBG_U(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) g_dbg2[i] = wall_clock64(); } while (0)
+/* per-phase durations over ALL workgroups of a launch (10 ns ticks): g_dbg2[i] = the longest, g_dbg3[i] = the sum, g_dbg3[i + 32] = the count (i < 32 after the offset) */
+#define DBG_P0() long long dbg_prev_ = wall_clock64()
+#define DBG_P(i) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); atomicMax((unsigned long long*)&g_dbg2[i], (unsigned long long)(t_ - dbg_prev_)); \
+                      atomicAdd((unsigned long long*)&g_dbg3[(i) - 30], (unsigned long long)(t_ - dbg_prev_)); atomicAdd((unsigned long long*)&g_dbg3[(i) + 2], 1ull); dbg_prev_ = t_; } } while (0)
 #define DBG_R(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring_frame = g_ring_frame + 1; g_ring[(g_ring_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #define DBG_S(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring2_frame = g_ring2_frame + 1; g_ring2[(g_ring2_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #else
 #define DBG_T(i) do { } while (0)
 #define DBG_U(i) do { } while (0)
+#define DBG_P0() do { } while (0)
+#define DBG_P(i) do { } while (0)
 #define DBG_W(cond, i) do { } while (0)
 #define DBG_R(cond, id) do { } while (0)
 #define DBG_S(cond, id) do { } while (0)

@@ -2254,6 +2254,18 @@ int rvio_hip_debug_clocks2(rvio_hip* h, long long* out64) {
     HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg2), sizeof(long long) * 64));
     return RVIO_OK;
 }
+// the per-phase sums / counts of feat_build_body over all workgroups (DBG_P) into out64, the longest phases (g_dbg2[30..40]) into max64; both cleared
+int rvio_hip_debug_phases(rvio_hip* h, long long* out64, long long* max64) {
+    if (!h || !out64 || !max64) return RVIO_ERR_INVALID;
+    const int rc = drain_all(h);
+    if (rc != RVIO_OK) return rc;
+    static const long long zero[64] = {0};
+    HIPCHK(h, hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg3), sizeof(long long) * 64));
+    HIPCHK(h, hipMemcpyFromSymbol(max64, HIP_SYMBOL(g_dbg2), sizeof(long long) * 64));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_dbg3), zero, sizeof zero));
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_dbg2), zero, sizeof zero));
+    return RVIO_OK;
+}
 int rvio_hip_debug_clocks(rvio_hip* h, long long* out64) {
     if (!h || !out64) return RVIO_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1,18 +1,6 @@
 set -u
-mkdir -p gpurun_out/r06f
+mkdir -p gpurun_out/r06g
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 python tools/at_rest_literal.py > gpurun_out/r06f/at_rest_literal.txt 2>&1
-grep -v amdgpu gpurun_out/r06f/at_rest_literal.txt
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06f/bench_driver.json 2> gpurun_out/r06f/bench_driver.err
-tail -c 300 gpurun_out/r06f/bench_driver.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r06f/bench_driver.json').read().strip().splitlines()[-1])
-print(list(d.keys())[:22])
-print(d['value'], d['ms_per_step'])
-r=d['roofline']; print(r['kernel'][:60], r['avg_us'], r['frac'])
-for c in d['roofline_other']: print('  ', c['kernel'][:60], c['avg_us'], c['frac'])
-print(d.get('latency_ms_p50'), d.get('p50_ekf_update_ms'))
-print(d.get('host_buffers'))
-print(d.get('timed_run_parity'), d.get('parity',{}).get('max_state_delta'))
-PY
+RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 300 python tools/feat_phase_clocks.py 120 > gpurun_out/r06g/feat_phase.txt 2>&1
+grep -v amdgpu gpurun_out/r06g/feat_phase.txt
+timeout 900 python -m pytest tests/test_gpu_multi_rccl.py -x -q 2>&1 | tail -5
