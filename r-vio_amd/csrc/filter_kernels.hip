@@ -86,7 +86,18 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     if (tm_global) Tm = tm_global + (size_t)f * rhomax * ldh; else { Tm = p; p += (size_t)rhomax * ldh; }
     double* S = p;
     // ---- one batch of global reads: feature header, its observations, the clone poses
+    // (count, header and observations of slot f go out together — every slot of the tables exists, a slot beyond the count is simply not used —: one
+    //  round trip to L2 instead of three dependent ones at the head of every workgroup, ~0.8 us of the launch)
     const int n_feat = *n_feat_ptr;
+    const unsigned char type = types[f];
+    const int L = lens[f];
+    const float* mz = meas + (size_t)f * cfg.max_len * 2;
+    float mxv = 0, myv = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane < cfg.max_len) { mxv = mz[2 * lane]; myv = mz[2 * lane + 1]; }
+    const bool xpre_on = HOIST > 4 && !gpose && 7 * n <= (int)blockDim.x;    // one stream: the clone states ride in the same batch of loads
+    double xpre = 0;
+    if (xpre_on && (int)threadIdx.x < 7 * n) xpre = x[26 + threadIdx.x];
     // an update of at most LIT_FEATS features is not sharded (every rank builds every feature, block 0 alone is used: block_sum_kernel) and
     // exports the accepted features' rows: the reference's literal sweep may have to run on them (literal.h)
     const bool lit = lit_rows && n_feat <= LIT_FEATS;
@@ -94,21 +105,16 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; }
         return;
     }
-    const unsigned char type = types[f];
-    const int L = lens[f];
     // a track the window cannot hold (caller-provided device tables, or a tracker that outlived a state reset): drop it and say so
     if (L < 2 || L > cfg.max_len || L - 1 > n || (type != '1' && type != '2')) {
         if (tid == 0) { nrows_out[f] = 0; acc_out[f] = 0; ndof_out[f] = 0; gamma_out[f] = 0; atomicOr(&zoffi(meta, bs, bi.z)->err, 2); }
         return;
     }
-    const float* mz = meas + (size_t)f * cfg.max_len * 2;
-    float mxv = 0, myv = 0;
-    const int lane = tid & 63;
-    if (lane < ML) { mxv = mz[2 * lane]; myv = mz[2 * lane + 1]; }
     const int nPh = L - 1;
     // batch handles: U1 + U2 were computed by geom4_kernel, four features per wave (the relative-pose chain and the triangulation are
     // single-wave phases with <= 11 of 64 lanes at work; here they are a third of the kernel's instructions) — fetch the poses and the triple
     if (gpose) { const double* gp = gpose + (size_t)f * (ML - 1) * 24; for (int e = tid; e < nPh * 24; e += T) pose[e] = gp[e]; }
+    else if (xpre_on) { if (tid < 7 * n) xcl[tid] = xpre; }
     else for (int e = tid; e < 7 * n; e += T) xcl[e] = x[26 + e];
     const bool wave0 = tid < 64;
     const double sig = cfg.sigma_im, sig2 = sig * sig;

@@ -15,7 +15,7 @@ for C in ${PMC_CONFIGS:-B}; do
   done
   F=$(find $OUT/pmc_${C}_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_${C}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
   python tools/pmc_traffic.py $F $W --json $OUT/pmc_traffic_cfg$C.json > $OUT/pmc_traffic_cfg$C.md 2>&1
-  cp $OUT/pmc_traffic_cfg$C.json profiles/r05_pmc_traffic_cfg$C.json
+  cp $OUT/pmc_traffic_cfg$C.json profiles/r06_pmc_traffic_cfg$C.json
   rm -rf $OUT/pmc_${C}_FETCH_SIZE $OUT/pmc_${C}_WRITE_SIZE
 done
 # kernel trace of the driver's own command
@@ -34,7 +34,7 @@ eval timeout -k 5 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt 
 python tools/rocpd_stats.py $(find $OUT/kt -name "*.db" | head -1) $OUT/batched_kernel_stats.md --grid-z 2048 > /dev/null; rm -rf $OUT/kt
 eval timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT/pm -o m -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --no-defined-load --batch-streams "''" > /dev/null 2>&1
 python tools/pmc_table.py $(find $OUT/pm -name "*counter_collection.csv" | head -1) --min-workgroups 2048 > $OUT/batched_mfma_counters.md 2>&1
-python tools/mfma_util_json.py $(find $OUT/pm -name "*counter_collection.csv" | head -1) --instances 2048 > $OUT/batched_mfma_util.json 2>/dev/null && cp $OUT/batched_mfma_util.json profiles/r05_batched_mfma_util.json
+python tools/mfma_util_json.py $(find $OUT/pm -name "*counter_collection.csv" | head -1) --instances 2048 > $OUT/batched_mfma_util.json 2>/dev/null && cp $OUT/batched_mfma_util.json profiles/r06_batched_mfma_util.json
 rm -rf $OUT/pm
 # the bench lines
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
@@ -44,4 +44,11 @@ timeout 400 python bench.py --force-sharded --config E --steps 40 --warmup 40 --
 python tools/solve9_probe.py B A C E > $OUT/solve9_probe.txt 2>&1
 for C in ${BENCH_CONFIGS:-}; do timeout 400 python bench.py --config $C --steps 60 --warmup 20 --batch '' --batch-streams '' --no-streams > $OUT/bench_cfg$C.json 2> /dev/null; done
 RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 200 python tools/chain_clocks.py 200 > $OUT/chain_clocks.txt 2>&1
+ls -la $OUT
+RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 200 python tools/side_phase_clocks.py 60 > $OUT/side_phase_clocks.txt 2>&1
+RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 200 python tools/feat_phase_clocks.py 120 > $OUT/feat_phase_clocks.txt 2>&1
+# SQ instruction counters of the batched filter (B = 2048): instructions per feature of the per-feature kernel
+eval timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pq -o q -- python bench.py --no-streams --no-cpu --no-latency --steps 5 --warmup 2 --batch 2048 --no-defined-load --batch-streams "''" > /dev/null 2>&1
+python tools/pmc_table.py $(find $OUT/pq -name "*counter_collection.csv" | head -1) --min-workgroups 2048 > $OUT/batched_sq_counters.md 2>&1
+rm -rf $OUT/pq
 ls -la $OUT
