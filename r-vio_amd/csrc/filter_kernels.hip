@@ -52,6 +52,34 @@ __device__ __forceinline__ double fast_rcp(double v) {
     return fma(fma(-v, y, 1.0), y, y);
 }
 
+// gamma = r^T S^-1 r by the square-root-free L D L^T of S, IN ONE WAVE: lane i holds row i of the lower triangle (lane rr: the residual as an extra
+// row) in NMAX registers, the pivot row's entries reach the other lanes by v_readlane, no LDS traffic and no barrier between the rr pivots
+// (round 6).  The thread-per-element form below it costs a barrier, five LDS loads per element and two reciprocals per pair of pivots on every
+// wave of the workgroup: ~2200 wave-instructions per feature at rr = 17 against ~800 here — a fifth of the per-feature kernel's instructions in
+// the batch, where it is instruction-issue bound, and ~1.5 us of the single stream's serial chain.  Same recurrence (columns unscaled:
+// S[i][k] = l_ik d_k, the residual row carries w = L^-1 r, gamma = sum w_k^2 / d_k); the sums run pivot by pivot instead of two at a time.
+template <int NMAX>
+__device__ __forceinline__ double ldlt_gamma_wave(const double* S, int lds_s, int rr, int lane, bool* bad) {
+    double row[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) row[j] = (lane <= rr && j <= lane && j < rr) ? S[lane * lds_s + j] : 0.0;
+    double gl = 0;
+    bool neg = false;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < rr) {                                // (uniform; fixed trip counts and constant register indices throughout: the rows stay in registers)
+            const double dk = readlane_f64(row[k], k);
+            neg |= !(dk > 0);
+            const double lik = row[k] * fast_rcp(dk > 0 ? dk : 1e-300);      // l_ik (rows i > k); lane rr: w_k / d_k
+            gl += row[k] * lik;                      // lane rr: w_k^2 / d_k
+#pragma unroll
+            for (int j = k + 1; j < NMAX; ++j) row[j] -= lik * readlane_f64(row[k], j);    // S[i][j] -= l_ik S[j][k]   (slots j > i, j >= rr: never read)
+        }
+    }
+    *bad = neg;
+    return readlane_f64(gl, rr);
+}
+
 // HOIST: k-values whose operand loads are in flight before the first MFMA of a gate tile (16: one stream, latency; 4: batch handles, 128 VGPRs)
 template <int HOIST>
 __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double* x, const double* P,
@@ -479,6 +507,18 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     // carries w = L^-1 r and gamma = sum_k w_k^2 / d_k.  Thread <-> element (i, j) of the lower triangle (+ residual row):
     // one rank-1 update step per barrier, every element touched once per step.
     double gam = 0;
+    if (rr <= 20) {       // (tracks of at most 11 observations: every feature of the stock 10-clone window)
+        if (wave0) {
+            bool bad = false;
+            const double g = (rr <= 12) ? ldlt_gamma_wave<12>(S, lds_s, rr, lane, &bad) : ldlt_gamma_wave<20>(S, lds_s, rr, lane, &bad);
+            if (lane == 0) {
+                misc[8] = fabs(g);
+                // S_f = Hn Pcc Hn^T + s2 I is positive definite by construction; a non-positive pivot means the covariance handed in is not.
+                // The feature is rejected (gamma overflows the table) where the reference's pivoted QR would return some finite gamma: say so.
+                if (bad) atomicOr(&zoffi(meta, bs, bi.z)->err, 8);
+            }
+        }
+    } else
     {
         // TWO pivots per barrier: a rank-1 step is latency (an LDS round trip, a reciprocal, a barrier: ~1000 cycles whatever the size), so
         // columns k and k+1 go together.  With a = S[k][k], b = S[k+1][k], c' = S[k+1][k+1] - b^2 / a and u_i = S[i][k+1] - S[i][k] b / a:

@@ -158,14 +158,12 @@ __global__ __launch_bounds__(64) void klt_kernel16(PyrDev prev, PyrDev next, int
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
                 // template pixel (c, r) of the window <-> patch (c + 1, r + 1)
-                // (round 6, as in klt_kernel3: every operand has at most 24 significant bits — bytes, 14-bit weights, 16-bit Scharr responses and
-                //  interpolated values, 13-bit differences — so the full-rate 24-bit multiply-adds are exact; the 32-bit multiplies ran at quarter rate)
-                const int ival = descale(mad24(k16_byte(R1, c + 1), iw00, mad24(k16_byte(R1, c + 2), iw01, mad24(k16_byte(R2, c + 1), iw10, mul24(k16_byte(R2, c + 2), iw11)))), 14 - 5);
+                const int ival = descale(k16_byte(R1, c + 1) * iw00 + k16_byte(R1, c + 2) * iw01 + k16_byte(R2, c + 1) * iw10 + k16_byte(R2, c + 2) * iw11, 14 - 5);
                 const int d00 = dq[c], d01 = dq[c + 1], d10 = dn[c], d11 = dn[c + 1];
-                const int ixv = descale(mad24((short)(d00 & 0xffff), iw00, mad24((short)(d01 & 0xffff), iw01, mad24((short)(d10 & 0xffff), iw10, mul24((short)(d11 & 0xffff), iw11)))), 14);
-                const int iyv = descale(mad24(d00 >> 16, iw00, mad24(d01 >> 16, iw01, mad24(d10 >> 16, iw10, mul24(d11 >> 16, iw11)))), 14);
+                const int ixv = descale((short)(d00 & 0xffff) * iw00 + (short)(d01 & 0xffff) * iw01 + (short)(d10 & 0xffff) * iw10 + (short)(d11 & 0xffff) * iw11, 14);
+                const int iyv = descale((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 + (d11 >> 16) * iw11, 14);
                 Iw[c] = wrow ? (short)ival : 0; Ixw[c] = wrow ? (short)ixv : 0; Iyw[c] = wrow ? (short)iyv : 0;
-                p11 = mad24(Ixw[c], Ixw[c], p11); p12 = mad24(Ixw[c], Iyw[c], p12); p22 = mad24(Iyw[c], Iyw[c], p22);
+                p11 += Ixw[c] * Ixw[c]; p12 += Ixw[c] * Iyw[c]; p22 += Iyw[c] * Iyw[c];
             }
             const long long s11 = k16_row_sum(p11), s12 = k16_row_sum(p12), s22 = k16_row_sum(p22);
             A11 = k16_i64_to_f32(s11) * FLT_SCALE; A12 = k16_i64_to_f32(s12) * FLT_SCALE; A22 = k16_i64_to_f32(s22) * FLT_SCALE;
@@ -212,8 +210,10 @@ __global__ __launch_bounds__(64) void klt_kernel16(PyrDev prev, PyrDev next, int
                     int pb1 = 0, pb2 = 0;
 #pragma unroll
                     for (int c = 0; c < 15; ++c) {
-                        const int diff = descale(mad24(k16_byte(Ja, c), iw00, mad24(k16_byte(Ja, c + 1), iw01, mad24(k16_byte(Jb, c), iw10, mul24(k16_byte(Jb, c + 1), iw11)))), 14 - 5) - Iw[c];
-                        pb1 = mad24(diff, Ixw[c], pb1); pb2 = mad24(diff, Iyw[c], pb2);
+                        // (24-bit multiply-adds through inline assembly, as klt_kernel3 has them, were measured here in round 6 and are SLOWER: 143.7 -> 139.5 k frames/s at 128
+                        //  streams — the compiler folds the byte extraction into the multiply's operand select, which an asm operand forbids)
+                        const int diff = descale(k16_byte(Ja, c) * iw00 + k16_byte(Ja, c + 1) * iw01 + k16_byte(Jb, c) * iw10 + k16_byte(Jb, c + 1) * iw11, 14 - 5) - Iw[c];
+                        pb1 += diff * Ixw[c]; pb2 += diff * Iyw[c];
                     }
                     if (!wrow) { pb1 = 0; pb2 = 0; }
                     const long long sb1 = k16_row_sum(pb1), sb2 = k16_row_sum(pb2);

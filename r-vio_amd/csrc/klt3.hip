@@ -35,8 +35,16 @@ __device__ __forceinline__ long long wave_sum_i32rows(int v) {
 //     once — 10 k instructions = 80 KB, unrolled over the four levels, fetched cold at ~100 cycles per 64-byte line: the levels are loops now
 //     (one copy of the template / iteration / Scharr code, warm from the second level on), and a staged region that lies inside the image —
 //     almost all do — is fetched with ONE unaligned 16-byte load per lane instead of 16 reflected byte loads.
+#ifndef KLT_MUL24
+#define KLT_MUL24 1
+#endif
+#if KLT_MUL24
 __device__ __forceinline__ int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+__device__ __forceinline__ int mul24(int a, int b) { return a * b; }
+__device__ __forceinline__ int mad24(int a, int b, int c) { return a * b + c; }
+#endif
 // exact sum over the wave of values whose 16-lane partial sums fit in int32, rounded ONCE to float like (float)(long long): the four row totals
 // are added as doubles (exact below 2^53) and converted with round-to-nearest-even, which is what the int64 -> float conversion does
 __device__ __forceinline__ float wave_sum_i32rows_f32(int v) {
