@@ -217,7 +217,7 @@ def main():
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
-        nblk = 2 * (6 * (cfg.max_track_len - 1) + 1) ** 2    # [S2 | S1] per rank (rvio_hip_update_local)
+        nblk = abi.shard_payload_doubles(6 * (cfg.max_track_len - 1), cfg.max_track_len)    # a full window's payload per rank (rvio_hip_update_local; the wire format of csrc/rvio_dev.h shard_layout)
         gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda")
 
     def make_frame(h_, fs_, gathered_):
@@ -347,7 +347,7 @@ def main():
             fsE = FrameSet(torch, cfgE, imgsE, imuE, cntE, None, np.zeros_like(ccE))
             hE = hip.RvioHip(cfgE, device=local_rank)
             hE.initialize(*seqE.init_from_static(K0))
-            nblkE = 2 * (6 * (cfgE.max_track_len - 1) + 1) ** 2
+            nblkE = abi.shard_payload_doubles(6 * (cfgE.max_track_len - 1), cfgE.max_track_len)
             gE = torch.zeros(world * nblkE, dtype=torch.float64, device="cuda")
             fE = make_frame(hE, fsE, gE)
             for i in range(1 + WE):

@@ -274,10 +274,13 @@ int rvio_hip_get_pose(rvio_hip* h, double p[3], double q[4]);
 /* Stage A: per-feature build + gate on the features f with f % world == rank,
  * then local compression to this shard's share of the information block
  * [A|b] = Hw^T [Hw | r], kept in two parts (the sum over the type-'2' features and the sum over
- * the type-'1' features, each 6n x (6n+1) doubles row-major inside a (6n_max+1)^2 square) plus
- * five counters, so that stage B can apply the reference's rank truncation (Updater.cc:516-529)
- * to the gathered whole.  *d_block is a device pointer owned by the handle, *n_doubles its
- * length (2 (6n_max+1)^2): this is the payload of the all-gather. */
+ * the type-'1' features) plus five counters, so that stage B can apply the reference's rank
+ * truncation (Updater.cc:516-529) to the gathered whole.  *d_block is a device pointer owned by
+ * the handle, *n_doubles its length: this is the payload of the all-gather, in the wire format of
+ * csrc/rvio_dev.h shard_layout (r-vio_amd/abi.py shard_pack / shard_unpack mirror it): 8 counters, then
+ * the 16 x 16 tiles (256 doubles each) on and above the diagonal of the type-'2' part that a
+ * type-'2' feature can reach, then those of the type-'1' part — 8 + 256 (tiles2 + tiles1) doubles
+ * for the CURRENT window (215 KB at 1600 features / 30 clones; rounds 2-5: 2 (6n_max+1)^2 doubles = 524 KB). */
 int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int world,
                           double** d_block, int* n_doubles);
 /* Stage B: sum `world` gathered blocks (device pointer, rank-major) in rank

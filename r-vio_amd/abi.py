@@ -138,3 +138,72 @@ def as_imu_array(w, a, t, dt):
     arr = np.zeros(len(t), dtype=IMU_DTYPE)
     arr["w"], arr["a"], arr["t"], arr["dt"] = w, a, t, dt
     return arr
+
+
+# ---- wire format of a shard's share of the information block (csrc/rvio_dev.h shard_layout: the all-gather payload of rvio_hip_update_local /
+# rvio_hip_frame_sharded_dev): [8 counters | S2 tiles | S1 tiles], 16 x 16 tiles of 256 doubles, upper triangle only, S2 only where a type-'2'
+# feature can reach.  NumPy mirror for tests and host-side collectives.
+def shard_layout(c6, max_len):
+    ntq, ntp = (c6 >> 4) + 1, (c6 + 15) >> 4
+    hi2 = min(6 * ((max_len + 1) // 2 - 1), c6)
+    t2 = min((hi2 - 1) >> 4 if hi2 > 0 else -1, ntp - 1)
+    x2 = 1 if ntq - 1 > t2 else 0
+    tiles2 = 0 if t2 < 0 else (t2 + 1) * (t2 + 2) // 2 + x2 * (t2 + 1)
+    tiles1 = ntp * ntq - ntp * (ntp - 1) // 2
+    return dict(ntq=ntq, ntp=ntp, t2=t2, x2=x2, tiles2=tiles2, tiles1=tiles1)
+
+
+def shard_payload_doubles(c6, max_len):
+    L = shard_layout(c6, max_len)
+    return 8 + 256 * (L["tiles2"] + L["tiles1"])
+
+
+def _shard_tiles(L):
+    """[(part, pt, qt, offset)] of every carried tile (part 0 = S2, 1 = S1)"""
+    out = []
+    for pt in range(L["t2"] + 1):
+        row = pt * (L["t2"] + 1 + L["x2"]) - pt * (pt - 1) // 2
+        for qt in range(pt, L["t2"] + 1):
+            out.append((0, pt, qt, 8 + 256 * (row + qt - pt)))
+        if L["x2"]:
+            out.append((0, pt, L["ntq"] - 1, 8 + 256 * (row + L["t2"] + 1 - pt)))
+    for pt in range(L["ntp"]):
+        for qt in range(pt, L["ntq"]):
+            out.append((1, pt, qt, 8 + 256 * (L["tiles2"] + pt * L["ntq"] - pt * (pt - 1) // 2 + qt - pt)))
+    return out
+
+
+def shard_pack(parts, counters, c6, max_len):
+    """parts: (2, rows >= c6, cols >= c6 + 1) full-layout S2, S1 (row p, column q; column c6 = the residual); counters: 8 numbers.
+    Returns (payload, live): the wire-format vector and the mask of its entries that carry matrix elements (tile padding excluded)."""
+    L = shard_layout(c6, max_len)
+    pay = np.zeros(shard_payload_doubles(c6, max_len))
+    live = np.zeros(len(pay), bool)
+    pay[:8] = counters
+    live[:8] = True
+    for part, pt, qt, off in _shard_tiles(L):
+        r1, c1 = min(16 * pt + 16, c6), min(16 * qt + 16, c6 + 1)
+        tile = np.zeros((16, 16))
+        mask = np.zeros((16, 16), bool)
+        tile[: r1 - 16 * pt, : c1 - 16 * qt] = parts[part][16 * pt: r1, 16 * qt: c1]
+        mask[: r1 - 16 * pt, : c1 - 16 * qt] = True
+        pay[off: off + 256] = tile.reshape(-1)
+        live[off: off + 256] = mask.reshape(-1)
+    return pay, live
+
+
+def shard_unpack(pay, c6, max_len, ld):
+    """inverse of shard_pack into full-layout (2, ld, ld) matrices with the lower triangle mirrored from the upper one (the residual column has
+    no mirror image), and the 8 counters"""
+    L = shard_layout(c6, max_len)
+    parts = np.zeros((2, ld, ld))
+    for part, pt, qt, off in _shard_tiles(L):
+        r1, c1 = min(16 * pt + 16, c6), min(16 * qt + 16, c6 + 1)
+        parts[part][16 * pt: r1, 16 * qt: c1] = np.asarray(pay[off: off + 256]).reshape(16, 16)[: r1 - 16 * pt, : c1 - 16 * qt]
+    for part in range(2):
+        a = parts[part][:c6, :c6]
+        iu = np.triu_indices(c6, 1)
+        # tiles strictly above the diagonal tile row carry both triangles of nothing: only elements whose TILE lies on or above the diagonal are valid
+        valid = (iu[1] >> 4) >= (iu[0] >> 4)
+        a[(iu[1][valid], iu[0][valid])] = a[(iu[0][valid], iu[1][valid])]
+    return parts, np.array(pay[:8])

@@ -981,12 +981,18 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
             }
         }
     };
+    const ShardLayout SL = shard_layout(c6, cfg.max_len);
     auto store = [&](int e, int q, int pq, int pt, int qt, double a2, double a1) {
         if (direct) {
             const double v = a2 + a1;
             S2[e] = v;
             if (qt > pt && q < c6) S2[(size_t)q * ldh + pq] = v;
-        } else { S2[e] = a2; S1[e] = a1; }
+        } else if (combine) { S2[e] = a2; S1[e] = a1; }
+        else {     // a shard's share in its wire format (rvio_dev.h shard_layout): the tiles that can be non-zero, upper triangle only
+            const int w = (pq & 15) * 16 + (q & 15), o2 = shard_tile2(SL, pt, qt), o1 = shard_tile1(SL, pt, qt);
+            if (o2 >= 0) block[o2 + w] = a2;
+            if (o1 >= 0) block[o1 + w] = a1;
+        }
     };
     if (wide) {
         // one stream: the shares were written by ~100 other CUs, every load is a remote (fabric) round trip and what one CU can keep in
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         return;
     }
     if (!combine) {
-        if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = s_cnt[2]; mr[3] = s_cnt[3]; mr[4] = s_cnt[4]; }
+        if (bi.x == 0 && tid == 0) { double* mr = block; mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = s_cnt[2]; mr[3] = s_cnt[3]; mr[4] = s_cnt[4]; mr[5] = 0; mr[6] = 0; mr[7] = 0; }
         return;
     }
     if (last_block_done(cnt, gridDim.x)) trunc_finish(cfg, n, S2, S1, s_cnt[0], s_cnt[1], s_cnt[2], s_cnt[3], s_cnt[4], g_dyn);
@@ -1177,11 +1183,16 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
     const size_t gs = (size_t)ldh * ldh;
     const int nf = lit.rows ? *lit.n_feat : LIT_FEATS + 1;
     if (nf <= LIT_FEATS) world = 1;
+    const ShardLayout SL = shard_layout(c6, cfg.max_len);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int q = e % ldh;
-        if (q > c6 || (q >> 4) < ((e / ldh) >> 4)) continue;     // the shards carry the tiles on and above the diagonal
+        const int q = e % ldh, pq = e / ldh, pt = pq >> 4, qt = q >> 4;
+        if (q > c6 || qt < pt) continue;     // the shards carry the tiles on and above the diagonal (wire format: rvio_dev.h shard_layout)
+        const int w16 = (pq & 15) * 16 + (q & 15), o2 = shard_tile2(SL, pt, qt), o1 = shard_tile1(SL, pt, qt);
         double a2 = 0, a1 = 0;
-        for (int w = 0; w < world; ++w) { a2 += blocks[(size_t)w * block_stride + e]; a1 += blocks[(size_t)w * block_stride + gs + e]; }
+        for (int w = 0; w < world; ++w) {
+            if (o2 >= 0) a2 += blocks[(size_t)w * block_stride + o2 + w16];
+            a1 += blocks[(size_t)w * block_stride + o1 + w16];
+        }
         Ab[e] = a2; Ab[gs + e] = a1;
     }
     if (!last_block_done(cnt, gridDim.x)) return;
@@ -1189,7 +1200,7 @@ __global__ __launch_bounds__(256) void block_sum_kernel(DevCfg cfg, int n, const
     if (threadIdx.x == 0) {
         int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
         for (int w = 0; w < world; ++w) {
-            const double* mr = blocks + (size_t)w * block_stride + (size_t)ldh * (ldh - 1);
+            const double* mr = blocks + (size_t)w * block_stride;
             good += (int)mr[0]; rows += (int)mr[1]; rows2 += (int)mr[2]; e2 = max(e2, (int)mr[3]); smin = min(smin, (int)mr[4]);
         }
         s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin;

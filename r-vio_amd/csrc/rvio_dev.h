@@ -74,6 +74,40 @@ __device__ __forceinline__ BatchIdx batch_plain() { return {(int)blockIdx.x, (in
 // strides (bytes) of the per-instance inputs of a batched call: IMU samples and the Tracker -> Updater hand-over
 struct BatchIn { size_t imu, n_feat, types, len, meas; };
 
+// ---- wire format of a shard's share of the information block (the all-gather payload of the feature-sharded updater).
+// [8 counters | S2 tiles | S1 tiles], 16 x 16 tiles of 256 doubles (row-major inside a tile), only what can be non-zero and is not a mirror image:
+//   S1 (sum over the type-'1' features, any column range): the tiles (pt, qt) on and above the diagonal, pt < ntp = ceil(6n / 16), qt < ntq = tiles up to the
+//      residual column 6n — row pt of the triangle holds ntq - pt tiles;
+//   S2 (sum over the type-'2' features: full-length tracks, columns [0, 6 (ceil(max_len / 2) - 1)) of the OLDEST clones): the triangle of the tiles up
+//      to t2 + the residual-column tile of each of its rows (x2 = 1 when that tile lies beyond t2).
+// cfg E (6n = 180, 31 observations): 27 + 78 tiles = 215 KB instead of the 2 (6n + 1)^2 doubles = 524 KB of rounds 2-5; cfg B: 31 KB instead of 60 KB.
+struct ShardLayout { int ntq, ntp, t2, x2, tiles2, tiles1; };
+__host__ __device__ inline ShardLayout shard_layout(int c6, int max_len) {
+    ShardLayout L;
+    L.ntq = (c6 >> 4) + 1; L.ntp = (c6 + 15) >> 4;
+    int hi2 = 6 * ((max_len + 1) / 2 - 1);
+    if (hi2 > c6) hi2 = c6;
+    L.t2 = hi2 > 0 ? (hi2 - 1) >> 4 : -1;
+    if (L.t2 > L.ntp - 1) L.t2 = L.ntp - 1;
+    L.x2 = (L.ntq - 1 > L.t2) ? 1 : 0;
+    L.tiles2 = L.t2 < 0 ? 0 : (L.t2 + 1) * (L.t2 + 2) / 2 + L.x2 * (L.t2 + 1);
+    L.tiles1 = L.ntp * L.ntq - L.ntp * (L.ntp - 1) / 2;
+    return L;
+}
+__host__ __device__ inline int shard_payload_doubles(int c6, int max_len) { const ShardLayout L = shard_layout(c6, max_len); return 8 + 256 * (L.tiles2 + L.tiles1); }
+// offset (doubles, from the start of the payload) of tile (pt, qt) of part 2 / part 1, -1 if the tile is not carried (it is zero)
+__host__ __device__ inline int shard_tile2(const ShardLayout& L, int pt, int qt) {
+    if (pt > L.t2 || qt < pt) return -1;
+    const int row = pt * (L.t2 + 1 + L.x2) - pt * (pt - 1) / 2;
+    if (qt <= L.t2) return 8 + 256 * (row + qt - pt);
+    if (L.x2 && qt == L.ntq - 1) return 8 + 256 * (row + L.t2 + 1 - pt);
+    return -1;
+}
+__host__ __device__ inline int shard_tile1(const ShardLayout& L, int pt, int qt) {
+    if (pt >= L.ntp || qt < pt || qt >= L.ntq) return -1;
+    return 8 + 256 * (L.tiles2 + pt * L.ntq - pt * (pt - 1) / 2 + qt - pt);
+}
+
 __device__ long long g_dbg[64];
 __device__ long long g_dbg3[64];   // (round 6) feat_build_body's phases over all workgroups: sums [0..15], counts [32..47] (DBG_P)
 __device__ long long g_dbg2[64];   // (round 6) phase stamps of the side chain's kernels: klt_kernel3 workgroup 0, RANSAC, both halves of book-keeping (tools/side_phase_clocks.py)

@@ -1059,7 +1059,7 @@ static int update_global_dev(rvio_hip* h, const double* d_blocks, int world, boo
     if (B > 1 && !combined) { h->err = "a batch handle runs the unsharded updater only"; return RVIO_ERR_UNSUPPORTED; }
     if (!combined) {   // gathered shards [S2 | S1]: sum both parts in rank order, then the rank truncation -> Ab = [A|b]
         const int eg = std::max(1, std::min(64, (int)((c6 * ldh + 255) / 256)));
-        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), h->trunc_lds, h->stream, d, n, d_blocks, world, (size_t)(2 * ldh * ldh), h->Ab, h->gram_cnt,
+        hipLaunchKernelGGL(block_sum_kernel, dim3(eg), dim3(256), h->trunc_lds, h->stream, d, n, d_blocks, world, (size_t)shard_payload_doubles(c6, d.max_len), h->Ab, h->gram_cnt,
                            (const int*)h->nrows, (const unsigned char*)h->t.types, (const int*)h->t.len, lit_args(h, h->trunc_lds));
         Ab = h->Ab;
     }
@@ -1100,7 +1100,7 @@ int rvio_hip_update_local(rvio_hip* h, const rvio_tracks* tracks, int rank, int 
     if (tracks) { int rc = upload_tracks(h, tracks); if (rc != RVIO_OK) return rc; }
     int rc = update_local_dev(h, rank, world, false);
     if (d_block) *d_block = h->block;
-    if (n_doubles) *n_doubles = 2 * h->dc.ldh * h->dc.ldh;
+    if (n_doubles) *n_doubles = shard_payload_doubles(6 * h->n_clones_host, h->dc.max_len);
     return rc;
 }
 int rvio_hip_update_global(rvio_hip* h, const double* d_blocks, int world) {
@@ -1789,13 +1789,13 @@ int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, co
     if (!h || !d_img || world < 1 || rank < 0 || rank >= world || (!comm && world > 1)) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t nblk = 2 * (size_t)h->dc.ldh * h->dc.ldh;
+    const size_t nblk_max = (size_t)shard_payload_doubles(6 * h->dc.nmax, h->dc.max_len);    // the full window's payload: what the receive buffer is sized for
     nccl_allgather_fn ag = (nccl_allgather_fn)allgather;
     if (comm && !ag && !(ag = resolve_allgather(&h->err))) return RVIO_ERR_UNSUPPORTED;
     if (comm && h->gathered_world < world) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         void* q = nullptr;
-        HIPCHK(h, hipMalloc(&q, sizeof(double) * nblk * (size_t)world));
+        HIPCHK(h, hipMalloc(&q, sizeof(double) * nblk_max * (size_t)world));
         h->allocs.push_back(q);
         h->gathered = (double*)q; h->gathered_world = world;
     }
@@ -1806,6 +1806,7 @@ int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, co
         rc = update_local_dev(h, rank, world, false);
         const double* blocks = h->block;
         if (rc == RVIO_OK && comm) {
+            const size_t nblk = (size_t)shard_payload_doubles(6 * h->n_clones_host, h->dc.max_len);     // (grows with the window: 8 + 256 doubles per carried tile)
             const int nrc = ag(h->block, h->gathered, nblk, /*ncclFloat64*/ 8, comm, h->stream);
             if (nrc != 0) { h->err = "ncclAllGather failed (ncclResult_t " + std::to_string(nrc) + ")"; rc = RVIO_ERR_NO_DEVICE; }
             blocks = h->gathered;

@@ -303,7 +303,7 @@ class RvioHip:
                     else:
                         if getattr(self, "_local_key", None) != (ptr, n):  # the block lives in one fixed device buffer: wrap it once
                             self._local_key, self._local = (ptr, n), torch.as_tensor(DeviceArray(ptr, n), device="cuda")
-                        dist.all_gather_into_tensor(gathered, self._local)
+                        dist.all_gather_into_tensor(gathered[: world * n], self._local)     # (the payload grows with the window: n doubles per rank, rank-major)
                     self.update_global(gathered.data_ptr(), world)
                 else:
                     self._ck(self.L.rvio_hip_update_tracked(self.h), "update_tracked")
@@ -318,7 +318,7 @@ class RvioHip:
             ptr, n = self.update_local_tracked(rank, world)
             self.sync()                                   # block ready (handle stream) before the collective's stream reads it
             local = torch.as_tensor(DeviceArray(ptr, n), device="cuda")
-            dist.all_gather_into_tensor(gathered, local)
+            dist.all_gather_into_tensor(gathered[: world * n], local)
             torch.cuda.current_stream().synchronize()     # gathered blocks visible before the handle stream consumes them
             self.update_global(gathered.data_ptr(), world)
         self.augment_compose(do_augment)

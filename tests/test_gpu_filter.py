@@ -156,14 +156,18 @@ def test_sharded_updater_fake_shards_on_one_gpu(hipB, recB, world):
     gb = blocks[1].cpu().numpy()
     ldh = 6 * (cfg.max_track_len - 1) + 1
     part = ldh * (ldh - 1)
-    assert nb == 2 * ldh * ldh and len(ob) == 2 * part + 8
-    # (the device carries the 16-column tiles on and above the diagonal only: A is symmetric, the lower tiles are mirrored after the sum)
-    pp, qq = np.divmod(np.arange(part), ldh)
-    upper = (qq >> 4) >= (pp >> 4)
-    for pt in range(2):
-        a, b = gb[pt * ldh * ldh: pt * ldh * ldh + part][upper], ob[pt * part: (pt + 1) * part][upper]
-        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.max(np.abs(ob[: 2 * part])))
-    assert np.array_equal(gb[part: part + 5], ob[2 * part: 2 * part + 5])
+    c6 = 6 * ((len(r["x1"]) - 26) // 7)
+    # the payload is the WIRE FORMAT of csrc/rvio_dev.h shard_layout (abi.shard_pack is its NumPy mirror): 8 counters, then the 16 x 16 tiles of the
+    # type-'2' part and of the type-'1' part that can be non-zero, tiles on and above the diagonal only (A is symmetric: mirrored after the sum)
+    assert nb == abi.shard_payload_doubles(c6, cfg.max_track_len) and len(ob) == 2 * part + 8
+    assert nb * 8 <= 0.55 * 2 * ldh * ldh * 8          # (rounds 2-5 gathered 2 (6n + 1)^2 doubles)
+    parts = np.stack([ob[pt * part: (pt + 1) * part].reshape(ldh - 1, ldh) for pt in range(2)])
+    want, live = abi.shard_pack(parts, ob[2 * part: 2 * part + 8], c6, cfg.max_track_len)
+    assert np.allclose(gb[live][8:], want[live][8:], rtol=1e-9, atol=1e-9 * np.max(np.abs(ob[: 2 * part])))
+    assert np.array_equal(gb[:5], want[:5])
+    # what the wire format leaves out of the type-'2' part is zero in the oracle's block too
+    back, _ = abi.shard_unpack(want, c6, cfg.max_track_len, ldh)
+    assert np.allclose(back[0][:c6, : c6 + 1], parts[0][:c6, : c6 + 1], atol=1e-12 * np.max(np.abs(parts)))
     hipB.update_global(allb.data_ptr(), world)
     x, P = hipB.get_state()
     assert S.state_delta(x, xo) <= X_TOL

@@ -287,6 +287,14 @@ def test_left_over_state_is_never_read(gpu_required, stock_b, sync_ref):
     assert same_bits(r, sync_ref["host"]), first_diff(r, sync_ref["host"])
 
 
+def test_left_over_state_is_never_read_on_the_long_window(gpu_required, stock_c):
+    """the same at cfg C (6n = 120): there the Cholesky factor of the NEXT update's clone block is handed from one frame to the next through the
+    solve's slab (its own queue, an event in front of the solve) — the poison fills that slab too, so the hand-over is dropped with it and the
+    solve factors the clone block itself: the same bits as the synchronised run (round 5's advisor finding: the flags used to survive the fill)"""
+    r = run_hip(stock_c, "host", True, sync_every=True, poison=7)
+    assert same_bits(r, stock_c["ref"]), first_diff(r, stock_c["ref"])
+
+
 def test_paranoid_mode_gives_the_same_bits(gpu_required, stock_b, sync_ref, tmp_path):
     """RVIO_PARANOID=1 (read when the library is loaded: a child process): default-flag events, no device-side polls, plain streams, host
     waits behind the staging copies, every frame drained — the A/B of every non-default mechanism in one switch"""

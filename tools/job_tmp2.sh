@@ -1,8 +1,11 @@
 set -u
-mkdir -p gpurun_out/r06h
+mkdir -p gpurun_out/r06i
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_filter.py tests/test_gpu_golden.py tests/test_gpu_configs.py tests/test_gpu_batch.py tests/test_gpu_solve9.py tests/test_gpu_frontend.py -x -q 2>&1 | tail -3
-RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so timeout 300 python tools/feat_phase_clocks.py 120 2>&1 | grep -v amdgpu | tee gpurun_out/r06h/feat_phase.txt
-tools/ab_batch.sh r-vio_amd/librvio_base.so 2 2>&1 | tee gpurun_out/r06h/ab_batch.txt
-echo "--- klt mul24 off (base) vs on (new)"
-tools/ab_lib.sh r-vio_amd/librvio_nomul24.so 2 2>&1 | tee gpurun_out/r06h/ab_mul24.txt
+timeout 1200 python -m pytest tests/test_gpu_filter.py tests/test_gpu_sharded_ranks.py tests/test_gpu_multi_rccl.py tests/test_gpu_configs.py tests/test_gpu_flatout.py -x -q 2>&1 | tail -4
+L="--no-cpu --no-latency --no-streams --batch= --batch-streams="
+for rep in 1 2; do
+python bench.py --steps 200 --warmup 40 $L 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plain   steps200 %.0f frames/s' % d['value'])"
+python bench.py --steps 200 --warmup 40 $L --force-sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sharded steps200 %.0f frames/s' % d['value'], d.get('max_state_delta_sharded_vs_single_gpu'))"
+done
+python bench.py --config E --steps 40 --warmup 40 $L 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plain   cfgE %.0f frames/s' % d['value'])"
+python bench.py --config E --steps 40 --warmup 40 $L --force-sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sharded cfgE %.0f frames/s' % d['value'])"
