@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RVIO_HIP_ABI_VERSION 4   /* 3: rvio_hip_frame_sharded_dev, IMU batches of any length, error bits 4 (hard) / 8;  4: the rvio_hip_debug_poison / _stall / _noise / _kernel_forms test hooks are part of the exported surface */
+#define RVIO_HIP_ABI_VERSION 5   /* 3: rvio_hip_frame_sharded_dev, IMU batches of any length, error bits 4 (hard) / 8;  4: the rvio_hip_debug_poison / _stall / _noise / _kernel_forms test hooks are part of the exported surface;  5: the payload of rvio_hip_update_local / _global is the packed wire format of csrc/rvio_dev.h shard_layout */
 /* IMU samples the staging of the host-buffer entry points is allocated for (0.96 s at 200 Hz).  PreIntegrator::propagate iterates any
  * list (PreIntegrator.cc:96-97), and so does every entry point here: a longer batch (dropped images) is accepted — the staging grows once,
  * at the price of one host synchronisation; the _dev entry points take any m. */

@@ -7,7 +7,7 @@ import ctypes as C
 import math
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class rvio_config(C.Structure):

@@ -492,7 +492,10 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
     const size_t ldh = d.ldh;
     // launch geometry (decides two optional slab members)
     if (d.Fu > GRAM_MAX_FEATS) { h->err = "Tracker.nFeatures too large for the Gram stage (ceil(F/2) <= 2048)"; return RVIO_ERR_UNSUPPORTED; }
-    h->feat_threads = (d.ldh <= 128) ? 128 : 256;
+#ifndef FEAT_T_SMALL
+#define FEAT_T_SMALL 128     // threads of a per-feature workgroup at 6n <= 127 (same-box A/B of 64 against 128 at B = 2048: profiles/r06_feat_threads_ab.txt)
+#endif
+    h->feat_threads = (d.ldh <= 128) ? FEAT_T_SMALL : 256;
     if (const char* ft = ab_env("RVIO_FEAT_THREADS")) h->feat_threads = atoi(ft);   // A/B timing only (64, 128 or 256)
     h->trunc_lds = trunc_lds_doubles(d.max_len) * sizeof(double);
     {   // the literal sweep runs in the workgroup that finishes the reduction (literal.h): its ring / rotation tables always in that launch's LDS, the

@@ -1,11 +1,10 @@
 set -u
-mkdir -p gpurun_out/r06i
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_filter.py tests/test_gpu_sharded_ranks.py tests/test_gpu_multi_rccl.py tests/test_gpu_configs.py tests/test_gpu_flatout.py -x -q 2>&1 | tail -4
-L="--no-cpu --no-latency --no-streams --batch= --batch-streams="
-for rep in 1 2; do
-python bench.py --steps 200 --warmup 40 $L 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plain   steps200 %.0f frames/s' % d['value'])"
-python bench.py --steps 200 --warmup 40 $L --force-sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sharded steps200 %.0f frames/s' % d['value'], d.get('max_state_delta_sharded_vs_single_gpu'))"
+export RVIO_HIP_LIB=r-vio_amd/librvio_dbg.so
+for T in 128 64 128 64 256; do
+RVIO_FEAT_THREADS=$T python bench.py --steps 20 --warmup 5 --no-cpu --no-latency --no-streams --batch 2048 --batch-streams '' 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+bf=d['batched_filter']['sizes'][-1]; dl=d.get('batched_filter_at_defined_load',{}).get('sizes',[{}])[-1]
+print('T=$T filter B=2048 %.0f frames/s %.4f ms frac %.4f | defined load %s' % (bf['filter_frames_per_s'], bf['ms_per_batched_frame'], bf['frac_fp64_peak'], {k:(round(v['ms_per_batched_frame'],3), round(v['frac_fp64_peak'],4)) for k,v in dl.items() if isinstance(v,dict) and 'frac_fp64_peak' in v}))"
 done
-python bench.py --config E --steps 40 --warmup 40 $L 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plain   cfgE %.0f frames/s' % d['value'])"
-python bench.py --config E --steps 40 --warmup 40 $L --force-sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sharded cfgE %.0f frames/s' % d['value'])"
