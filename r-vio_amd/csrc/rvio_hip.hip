@@ -947,7 +947,14 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
         switch (h->solve9_nt) {
         case 4:
             static const bool s9_generic = ab_env("RVIO_S9_GENERIC") != nullptr;   // A/B timing: the generic kernel (tiles through the L2 slab) at 6n <= 64
-            if (pre && !s9_generic) hipLaunchKernelGGL(solve9_small_kernel, dim3(1), dim3(1024), sizeof(S9SmallLds), h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout);
+            if (pre && !s9_generic) {
+                // in the frame's update the Joseph stage follows on the stream: dx = Pc y and the state injection become role workgroups of that launch (launch_ug_final)
+                static const bool no_dx_small = ab_env("RVIO_S9_NO_DX_ROLE") != nullptr;   // A/B timing
+                const bool role = defer_dx && h->batch == 1 && 6 * n <= 60 && !no_dx_small && !ab_env("RVIO_NO_JOSEPH_LDS");
+                hipLaunchKernelGGL(solve9_small_kernel, dim3(1), dim3(1024), sizeof(S9SmallLds), h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout,
+                                   role ? h->S9scr + S9_YP_OFF(4) : (double*)nullptr);
+                h->dx_pending = role;
+            }
             else if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
             else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes,
                                     h->batch > 1 ? S9_SLAB_DOUBLES(4) * sizeof(double) : (size_t)0);
@@ -1027,7 +1034,10 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
     if (h->jb_lds && ug && fin) {   // batch handle, 6n <= 60: P -> P+ in one kernel (U, G, P1 never leave the CU)
         hipLaunchKernelGGL(joseph_batch_kernel, dim3(1, 1, B), dim3(JB_THREADS), h->jb_lds, h->stream, d, n, Pc, h->W, Ab, Pn, bs);
     } else if (B == 1 && c6 <= 60 && ug && fin && !no_jl) {   // one instance, short window: both stages in ONE launch, a workgroup per tile pair of P+
-        hipLaunchKernelGGL(joseph_lds_kernel, dim3(npair), dim3(256), JL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, Pn);
+        const bool dxr = h->dx_pending;   // the all-LDS solve left dx = Pc y and the state injection to role workgroups of this launch
+        h->dx_pending = false;
+        hipLaunchKernelGGL(joseph_lds_kernel, dim3(npair + (dxr ? (dd + 23) / 24 : 0)), dim3(256), JL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, Pn,
+                           h->meta, (const double*)h->x[h->cur], h->x[h->cur ^ 1], dxr ? (const double*)h->S9scr : (const double*)nullptr, npair);
     } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
         if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
         if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);

@@ -812,7 +812,9 @@ struct S9SmallLds {
 };
 __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
                                                             const double* __restrict__ x, const double* __restrict__ P, const double* __restrict__ scr,
-                                                            double* __restrict__ Wout, double* __restrict__ x_out) {
+                                                            double* __restrict__ Wout, double* __restrict__ x_out, double* __restrict__ yp_out) {
+    // yp_out != NULL (round 6, the frame's update): the kernel ends with W and the four row-tile shares of y = W b in the slab — dx = Pc y and the state
+    // injection (4.7 of its 29 us: nothing the Joseph stage needs) are role workgroups of the Joseph launch right behind it (s9_dx_role), as in the split form
     constexpr int NT = 4, NTH = 1024;
     extern __shared__ __align__(16) double s9s_dyn[];
     S9SmallLds& sh = *reinterpret_cast<S9SmallLds*>(s9s_dyn);
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMe
     if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; sh.bad = 0; }
     if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
         for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
-        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        if (!yp_out) for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];      // (deferred: the roles pass the state through)
         return;
     }
     DBG_T(30);
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMe
 #pragma unroll
     for (int u = 0; u < PCN; ++u) {
         const int e = tid + u * NTH, k = e / 88, i = e - k * 88;
-        pc[u] = (k < c6 && i < d) ? P[(size_t)i + (size_t)(24 + k) * ld] : 0.0;
+        pc[u] = (!yp_out && k < c6 && i < d) ? P[(size_t)i + (size_t)(24 + k) * ld] : 0.0;
     }
     if (tid < 64) sh.b[tid] = (tid < c6) ? Ab[(size_t)tid * ldh + c6] : 0.0;
     if (tid == 0 && scr[(size_t)5 * NT * NT * S9_TILE] != 0.0) sh.bad = 1;     // the Cholesky role's verdict
@@ -933,8 +935,10 @@ __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMe
     DBG_T(36);
     // park Pc in the dead Q | R region (64 KB >= 88 x 64 doubles) for dx
     double* pcs = &sh.Q[0][0];
+    if (!yp_out) {
 #pragma unroll
-    for (int u = 0; u < PCN; ++u) { const int e = tid + u * NTH; if (e < 88 * 64) ((s9_lds_t*)pcs)[e] = pc[u]; }
+        for (int u = 0; u < PCN; ++u) { const int e = tid + u * NTH; if (e < 88 * 64) ((s9_lds_t*)pcs)[e] = pc[u]; }
+    }
     // ---- W^T = (I - L V) / s2  (Wt(i, j) = (delta - sum_{k <= i} G(k, i)^T V(k, j)) / s2);  W(16 j + b, 16 i + a) = Wt(a, b);  y = W b by tile
     {
         const double is2 = 1.0 / s2;
@@ -951,11 +955,17 @@ __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMe
             t = fma(w, sh.b[a], t);                     // this tile's share of y[bcol]: over its 16 rows a — four in the lane, then the four lane groups (fixed order)
         }
         t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-        if (lk == 0) sh.yp[ti][16 * tj + li] = t;
+        if (lk == 0) { if (yp_out) yp_out[ti * 64 + 16 * tj + li] = t; else sh.yp[ti][16 * tj + li] = t; }
     }
     if (bad) atomicOr(&sh.bad, 1);
     __syncthreads();
     if (tid == 0 && sh.bad) atomicOr(&meta->err, 1);
+    if (yp_out) {      // the roles of the Joseph launch sum the shares in the same fixed order, form dx = Pc y from P itself and inject the state
+        if (tid == 0) yp_out[-7] = 0.0;     // (the sweep's verdict word of the slab, S9_YP_OFF - 7: reported through meta->err above)
+        DBG_T(37); DBG_T(38);
+        DBG_R(true, 7);
+        return;
+    }
     if (tid < 64) sh.y[tid] = ((sh.yp[0][tid] + sh.yp[1][tid]) + sh.yp[2][tid]) + sh.yp[3][tid];
     __syncthreads();
     DBG_T(37);
