@@ -618,7 +618,8 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
          "match": solve_match, "launched_by_timed_path": solve_name,
          "achieved": fl_solve / t_solve / 1e12, "peak": PEAK_F64, "unit": "TFLOP/s", "avg_us": t_solve * 1e6,
          "note": "blocked symmetric sweep of M = s2 I + L^T A L + Woodbury on FP64 MFMA tiles; 6n <= 96: one workgroup on ONE CU (%.2f TFLOP/s of the chip's %.1f), the Cholesky of the "
-                 "clone block rides in the per-feature launch (off the chain: NOT in avg_us, and its c6^3 / 3 flops are not in `achieved`); 6n > 96: the four product phases are "
+                 "clone block rides in the per-feature launch (off the chain: NOT in avg_us, and its c6^3 / 3 flops are not in `achieved`), dx = Pc y and the state injection are role "
+                 "workgroups of the Joseph launch behind it (not in avg_us either: timed as the frame's update launches it); 6n > 96: the four product phases are "
                  "chip-wide launches, the sweep one workgroup, the Cholesky factor runs beside the filter chain on a queue of its own; latency bound: %d 16 x 16 in-wave "
                  "factorisations in sequence" % (PEAK_F64 / 256.0, PEAK_F64, (c6 + 15) // 16)},
         {"bound": "hbm", "kernel": "klt_kernel3 (4-level pyramidal LK, one wave per feature)", "match": "klt_kernel3", "launched_by_timed_path": "klt_kernel3 (forward match)",

@@ -2047,7 +2047,8 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
         } else
         if (which == 0) {
             h->chol_ready = h->solve9_nt && (h->solve9_nt <= 6 || h->stream_l) && !ab_env("RVIO_S9_FULL");   // (time what the chain sees: the Cholesky factor rides in the per-feature launch / runs on its own queue; the slab holds the factor of the last update)
-            launch_solve(h, n, h->block);
+            launch_solve(h, n, h->block, /*defer_dx=*/true);   // as the frame's update launches it: dx = Pc y and the state injection are roles of the Joseph launch behind it
+            h->dx_pending = false;
         } else if (which == 1) {
             // KLT as the frame ran it cannot be repeated (book-keeping has moved the features to where they were tracked): match the CURRENT
             // image back onto the PREVIOUS one from the current feature positions instead — the same displacement magnitudes, reversed, the
