@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NMS_T) void nms_threshold_kernel(DetDev d, size_t b
 }
 
 // The two-pass form of rounds 1-3 (the map through HBM), kept for A/B timing in the instrumented build and for rvio_hip_get_corners(eig)
+#ifdef RVIO_DBG_CLOCKS   // (the two-pass form of rounds 1-3, RVIO_DET_TWO_PASS: instrumented build only)
 __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     det_shift(d, (size_t)blockIdx.z * bs);
     const int W = d.W, H = d.H;
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(DET_T) void nms_kernel(DetDev d, size_t bs) {
     d.cell_ent[slot] = key;
     d.cell_ci[slot] = ci;
 }
+#endif
 
 #define NEIGH_T 1024
 #define NEIGH_BLOCKS 8

@@ -607,12 +607,17 @@ static int create_impl(const rvio_config* cfg, int device, int batch, bool front
             // launch — as the batch form at 6n <= 64, RVIO_BATCH_SOLVE7: 2.62 ms per batched frame at B = 2048 against 2.29 with solve6 behind gemm_T)
             if (batch > 1 && h->solve5_variant && !ab_env("RVIO_SOLVE7") && !(h->solve7_variant == 1 && ab_env("RVIO_BATCH_SOLVE7"))) h->solve7_variant = 0;
             if (batch > 1 && h->solve7_variant == 1) h->solve7_variant = 5;
+#ifdef RVIO_DBG_CLOCKS
             if (h->solve7_variant == 1)
             {
                 HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 16, 4>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
                 HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 8, 8>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
                 HIPCHK(h, lds_attr((const void*)solve7_kernel<1, 4, 16>, (3 * 64 * 65 + 24 * 64) * (int)sizeof(double)));
             }
+#else
+            // shipping library: the register-tableau solve survives for batch handles beyond solve6's windows only (6n > 126: solve7_kernel<3, 16, 12>)
+            if (h->solve7_variant != 4 || h->solve9_nt) h->solve7_variant = 0;
+#endif
             if (h->solve5_variant) {
                 h->solve5_lds = (size_t)(nw * rpw) * (64 * nch + 1) * sizeof(double);
                 const int lds = (int)std::max(h->solve5_lds, (size_t)1024);
@@ -955,7 +960,9 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
                                    role ? h->S9scr + S9_YP_OFF(4) : (double*)nullptr);
                 h->dx_pending = role;
             }
+#ifdef RVIO_DBG_CLOCKS   // (A/B form RVIO_S9_GENERIC: compiled into the instrumented build only — round 6, kernel forms no handle of the shipping library launches)
             else if (pre) hipLaunchKernelGGL((solve9_kernel<1, 4, true>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+#endif
             else hipLaunchKernelGGL((solve9_kernel<1, 4>), gb, dim3(1024), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes,
                                     h->batch > 1 ? S9_SLAB_DOUBLES(4) * sizeof(double) : (size_t)0);
             return;
@@ -980,10 +987,14 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
         hipLaunchKernelGGL(solve9_prod_kernel<0>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
         hipLaunchKernelGGL(solve9_prod_kernel<1>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
         static const bool sweep4 = ab_env("RVIO_S9_SWEEP4") != nullptr;   // A/B timing: the sweep on 2 x 2 waves with 16 / 36 tiles each (no spills, one wave per matrix pipe)
+#ifdef RVIO_DBG_CLOCKS
         if (sweep4) {
             if (NT == 8) hipLaunchKernelGGL((solve9_sweep_kernel<4, 2>), dim3(1), dim3(256), 0, h->stream, d, Ab, h->S9scr);
             else hipLaunchKernelGGL((solve9_sweep_kernel<6, 2>), dim3(1), dim3(256), 0, h->stream, d, Ab, h->S9scr);
         } else
+#else
+        (void)sweep4;
+#endif
         if (NT == 8) hipLaunchKernelGGL((solve9_sweep_kernel<2, 4>), dim3(1), dim3(1024), 0, h->stream, d, Ab, h->S9scr);
         else hipLaunchKernelGGL((solve9_sweep_kernel<3, 4>), dim3(1), dim3(1024), 0, h->stream, d, Ab, h->S9scr);
         hipLaunchKernelGGL(solve9_prod_kernel<2>, dim3(nwg), dim3(256), 0, h->stream, d, n, Ab, h->S9scr, h->W, NT);
@@ -994,6 +1005,7 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
         return;
     }
     switch (h->solve7_variant) {   // T = s2 I + A Pcc is formed by the kernel itself
+#ifdef RVIO_DBG_CLOCKS   // (the register-tableau solve of rounds 3-4 at 6n <= 128: plain handles run solve9, batch handles solve6 there — A/B forms of the instrumented build)
     case 1: {
         static const int nw = ab_env("RVIO_S7_NW") ? atoi(ab_env("RVIO_S7_NW")) : 4;
         const size_t lds = (size_t)(3 * 64 * 65 + 24 * 64) * sizeof(double);
@@ -1010,8 +1022,9 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
         return;
     }
     case 3: hipLaunchKernelGGL((solve7_kernel<2, 16, 8>), gb, dim3(512), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
-    case 4: hipLaunchKernelGGL((solve7_kernel<3, 16, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     case 5: hipLaunchKernelGGL((solve7_kernel<1, 16, 4, false, 8>), gb, dim3(256), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
+#endif
+    case 4: hipLaunchKernelGGL((solve7_kernel<3, 16, 12>), gb, dim3(768), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->Tbuf, h->W, xout, h->slab_bytes); return;
     default: break;
     }
     if (h->solve5_variant == 1)
@@ -1275,12 +1288,16 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
         hipLaunchKernelGGL(mineig_nms_strip_kernel, dim3((d.W + DET_SW - 1) / DET_SW, (d.H + DET_SH - 1) / DET_SH, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));
         hipLaunchKernelGGL(nms_threshold_kernel, dim3(16, 1, B), dim3(NMS_T), 0, ds, q, bs);
-    } else if (two_pass) {   // rounds 1-3: the map through HBM
+    }
+#ifdef RVIO_DBG_CLOCKS
+    else if (two_pass) {   // rounds 1-3: the map through HBM
         const dim3 g((d.W + DET_TW - 1) / DET_TW, (d.H + DET_TH - 1) / DET_TH, B);
         hipLaunchKernelGGL(mineig_kernel, g, dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // nms reads mbIsTheFirstImage as book-keeping(k-1) left it
         hipLaunchKernelGGL(nms_kernel, g, dim3(DET_T), 0, ds, q, bs);
-    } else {
+    }
+#endif
+    else {
         // one stream: min-eigenvalue map + strict 3x3 local maxima in one pass (the map stays in LDS), then the image-wide threshold on the provisional list
         hipLaunchKernelGGL(mineig_nms_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_FH - 1) / DET_FH, B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // the threshold pass reads mbIsTheFirstImage (cell size) as book-keeping(k-1) left it
