@@ -129,7 +129,7 @@ __device__ long long g_ring3[64 * 8];   // the image chain of frame `tag` (CLAHE
 #define DBG_U(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) g_dbg2[i] = wall_clock64(); } while (0)
 /* per-phase durations over ALL workgroups of a launch (10 ns ticks): g_dbg2[i] = the longest, g_dbg3[i] = the sum, g_dbg3[i + 32] = the count (i < 32 after the offset) */
 #define DBG_P0() long long dbg_prev_ = wall_clock64()
-#define DBG_P(i) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); atomicMax((unsigned long long*)&g_dbg2[i], (unsigned long long)(t_ - dbg_prev_)); \
+#define DBG_P(i) do { if (threadIdx.x == 0 && (gridDim.z == 1 || ((blockIdx.z & 63) == 0 && blockIdx.x < 4))) {   /* (a batch: a sample of the workgroups — the atomics of 200 k workgroups would be the kernel) */ const long long t_ = wall_clock64(); atomicMax((unsigned long long*)&g_dbg2[i], (unsigned long long)(t_ - dbg_prev_)); \
                       atomicAdd((unsigned long long*)&g_dbg3[(i) - 30], (unsigned long long)(t_ - dbg_prev_)); atomicAdd((unsigned long long*)&g_dbg3[(i) + 2], 1ull); dbg_prev_ = t_; } } while (0)
 #define DBG_R(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring_frame = g_ring_frame + 1; g_ring[(g_ring_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
 #define DBG_S(cond, id) do { if (threadIdx.x == 0 && (cond)) { if ((id) == 0) g_ring2_frame = g_ring2_frame + 1; g_ring2[(g_ring2_frame & 63) * 8 + (id)] = wall_clock64(); } } while (0)
