@@ -205,7 +205,7 @@ inline int der(const Level& L, int x, int y, int c) { return (x < 0 || y < 0 || 
 // converted and added in row-major window order (lkpyramid.cpp LKTrackerInvoker, acctype = itemtype = float without SIMD).  It is one of the
 // build-dependent orders the header of this file speaks of; tests/test_opencv_distance.py reports how far the exact-sum definition sits from it.
 // (measurement only: iteration counts of the calls so far — [points, iterations summed, largest per point, restages a 32 x 32 staged region would need])
-static long long g_lk_stat[4] = {0, 0, 0, 0};
+static thread_local long long g_lk_stat[4] = {0, 0, 0, 0};   // (per thread: the multi-core build walks the features in parallel)
 void lk_point(const Pyramid& P, const Pyramid& N, float px, float py, float* ox, float* oy, unsigned char* st, bool float_acc = false) {
     long long its_pt = 0;
     const int maxLevel = (int)std::min(P.lv.size(), N.lv.size()) - 1;
