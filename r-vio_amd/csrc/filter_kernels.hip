@@ -52,6 +52,27 @@ __device__ __forceinline__ double fast_rcp(double v) {
     return fma(fma(-v, y, 1.0), y, y);
 }
 
+// U1 relative-pose chain (Updater.cc:114-141) of a track of at most 16 observations as a PREFIX SCAN inside one 16-lane DPP row (round 6): lane l
+// holds clone l's rotation R_l = R(q_l) and position p_l, i.e. the affine map A_l(x) = R_l (x - p_l) = R_l x + c_l; the chain R_I(l) = R_l R_I(l-1),
+// t_I(l) = R_l (t_I(l-1) - p_l) is the composition A_l o ... o A_0 applied to 0, and compositions associate: four Hillis-Steele steps (row_shr 1, 2, 4, 8
+// through DPP) instead of up to 15 serial 3 x 3 products with an LDS round trip each (3.2 us of the per-feature stage's ~26 in situ).  The association
+// differs from the serial order: rounding-level differences (1e-16), like the reference's own quaternion / rotation round trips.  Used by the single-
+// stream kernel (wave 0, row 0) and by geom4_kernel (a feature per row): the same expressions in both.
+template <int CTRL>
+__device__ __forceinline__ void chain_step(m33& R, d3& c, bool take) {
+    m33 Rp; d3 cp;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp.m[k] = dpp_f64<CTRL>(R.m[k]);
+    cp.x = dpp_f64<CTRL>(c.x); cp.y = dpp_f64<CTRL>(c.y); cp.z = dpp_f64<CTRL>(c.z);
+    if (take) { c = add3(mv33(R, cp), c); R = mul33(R, Rp); }     // (R, c) o (Rp, cp): the later map after the earlier one
+}
+__device__ __forceinline__ void pose_chain_row16(m33& R, d3& c, int l) {      // in: R_l, c_l = -R_l p_l; out: R_I(l), t_I(l)
+    chain_step<0x111>(R, c, l >= 1);
+    chain_step<0x112>(R, c, l >= 2);
+    chain_step<0x114>(R, c, l >= 4);
+    chain_step<0x118>(R, c, l >= 8);
+}
+
 // gamma = r^T S^-1 r by the square-root-free L D L^T of S, IN ONE WAVE: lane i holds row i of the lower triangle (lane rr: the residual as an extra
 // row) in NMAX registers, the pivot row's entries reach the other lanes by v_readlane, no LDS traffic and no barrier between the rr pivots
 // (round 6).  The thread-per-element form below it costs a barrier, five LDS loads per element and two reciprocals per pair of pivots on every
@@ -156,6 +177,22 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     // R_I(i) = R(q_i) R_I(i-1), t_I(i) = R(q_i) (t_I(i-1) - p_i) as a short serial product of 3x3 matrices, then the
     // camera-frame poses in parallel again.  The reference carries the chain as normalised quaternions and passes
     // R_c through RotToQuat/QuatToRot; both are the same rotations up to O(1e-16).
+    if (wave0 && !gpose && nPh <= 15) {     // (every window up to 15 clones: the chain as a prefix scan inside the wave's first DPP row, no LDS in between)
+        const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
+        const int ll = lane < nPh ? lane : 0;
+        m33 RI = q2r(ldq(rel + 7 * ll));
+        d3 tI = scl3(-1.0, mv33(RI, ld3(rel + 7 * ll + 4)));
+        pose_chain_row16(RI, tI, lane);
+        if (lane < nPh) {
+            double* o = pose + lane * 24;
+            const m33 RciRI = mul33(Rci, RI);
+            const m33 Rc = mul33(RciRI, Ric);
+            const d3 tC = add3(add3(mv33(RciRI, tic), mv33(Rci, tI)), tci);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { o[k] = RI.m[k]; o[12 + k] = Rc.m[k]; }
+            st3(o + 9, tI); st3(o + 21, tC);
+        }
+    } else
     if (wave0 && !gpose) {
         const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
         if (lane < nPh) {
@@ -669,46 +706,22 @@ __global__ __launch_bounds__(64) void geom4_kernel(DevCfg cfg, int n, const doub
     const d3 tic = ld3(cfg.tic), tci = ld3(cfg.tci);
     __syncthreads();
     double* pose = poses[g];
-    // ---- U1 (feat_build_kernel, same expressions)
+    // ---- U1 (feat_build_kernel, same expressions: the chain as a prefix scan inside the feature's 16-lane row)
     const double* rel = (type == '1') ? (xcl + 7 * n - 7 * nPh) : xcl;
-    if (active && l < nPh) {
-        const m33 Rl = q2r(ldq(rel + 7 * l));
-        double* o = pose + l * 24 + 12;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o[k] = Rl.m[k];
-    }
-    __syncthreads();
     {
-        m33 RI = ldm33(pose + 12);
-        d3 tI = scl3(-1.0, mv33(RI, ld3(rel + 4)));
-        for (int i = 0; i < ML - 1; ++i) {
-            if (__builtin_amdgcn_readfirstlane(__any(active && i < nPh)) == 0) break;
-            if (active && i < nPh) {
-                if (i > 0) {
-                    const m33 Ri = ldm33(pose + i * 24 + 12);
-                    tI = mv33(Ri, sub3(tI, ld3(rel + 7 * i + 4)));
-                    RI = mul33(Ri, RI);
-                }
-                if (l == 0) {
-                    double* o = pose + i * 24;
+        const int ll = (active && l < nPh) ? l : 0;
+        m33 RI = q2r(ldq(rel + 7 * ll));
+        d3 tI = scl3(-1.0, mv33(RI, ld3(rel + 7 * ll + 4)));
+        pose_chain_row16(RI, tI, l);
+        if (active && l < nPh) {
+            double* o = pose + l * 24;
+            const m33 RciRI = mul33(Rci, RI);
+            const m33 Rc = mul33(RciRI, Ric);
+            const d3 tC = add3(add3(mv33(RciRI, tic), mv33(Rci, tI)), tci);
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) o[k] = RI.m[k];
-                    st3(o + 9, tI);
-                }
-            }
+            for (int k = 0; k < 9; ++k) { o[k] = RI.m[k]; o[12 + k] = Rc.m[k]; }
+            st3(o + 9, tI); st3(o + 21, tC);
         }
-    }
-    __syncthreads();
-    if (active && l < nPh) {
-        double* o = pose + l * 24;
-        const m33 RIl = ldm33(o);
-        const d3 tIl = ld3(o + 9);
-        const m33 RciRI = mul33(Rci, RIl);
-        const m33 Rc = mul33(RciRI, Ric);
-        const d3 tC = add3(add3(mv33(RciRI, tic), mv33(Rci, tIl)), tci);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o[12 + k] = Rc.m[k];
-        st3(o + 21, tC);
     }
     __syncthreads();
     // ---- U2 (feat_build_kernel, same expressions; lane l of the row <-> observation l)
@@ -889,7 +902,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     if (lit.rows) { lit.rows = zoffi(lit.rows, bs, bi.z); lit.n_feat = zoffi(lit.n_feat, bin.n_feat, bi.z); if (lit.state) lit.state = zoffi(lit.state, bs, bi.z); }
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
-    DBG_T(41);
+    DBG_T(41); DBG_U(45);
     DBG_R(bi.x == 0, 1);
     // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2', bits 16..19 / 20..23 the
     // first / last 16-column tile of the feature's range (feat_build_kernel stores a share's tiles inside that range only)
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     const int ng = s_base;
     const size_t gs = (size_t)ldh * ldh;
     double* S2 = block; double* S1 = block + gs;
-    DBG_T(42);
+    DBG_T(42); DBG_U(46);
     // counters of this shard (wave 0 of every workgroup: Fu small integers): accepted features, their rows, the rows / last column of
     // type '2', the first column of type '1'
     if (tid < 64) {
@@ -938,6 +951,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
         if (tid == 0) { s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin; }
     }
     __syncthreads();
+    DBG_U(47);
     // a small stack whose rank decision the structure does not settle (literal.h): block 0 runs the reference's sweep + scan on the exported
     // rows and writes [A|b] itself; the shares are not needed.  (Unsharded update only: a shard's counters are partial — there the decision
     // is taken on the gathered whole, block_sum_kernel.)
@@ -954,7 +968,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     const bool cand = s_cnt[0] > 2 && s_cnt[1] > c6 && s_cnt[3] >= 0 && s_cnt[3] < c6 && s_cnt[4] < TR_NONE && s_cnt[4] > s_cnt[3] && s_cnt[2] >= s_cnt[3] + 1;
     const bool direct = combine && !cand;
     const bool split = !direct;                          // S2 and S1 are needed apart (a shard of the sharded updater, or a candidate)
-    DBG_T(43);
+    DBG_T(43); DBG_U(48);
     const int trq = c6 >> 4;                             // tile of the residual column
     // The shares were written by ~100 other CUs: every load here is a remote (fabric) round trip, and what one CU can keep in flight
     // bounds its rate.  So the reduction is spread wide: a workgroup covers only 64 consecutive elements, its four waves split the
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
             store(e, q, pq, pt, qt, a2, a1);
         }
     }
-    DBG_T(44);
+    DBG_T(44); DBG_U(49);
     if (direct) {
         if (bi.x == 0 && tid == 0) { double* mr = S2 + (size_t)ldh * (ldh - 1); mr[0] = s_cnt[0]; mr[1] = s_cnt[1]; mr[2] = -1.0; mr[5] = -1.0; }
         return;

@@ -26,7 +26,7 @@ d_imu = torch.from_numpy(imu_arr.view(np.uint8).reshape(n_frames, -1)).cuda()
 torch.cuda.synchronize()
 h.initialize(*seq.init_from_static(bench.K0))
 names = ["loads", "barrier", "U1 pose chain", "U2 LM", "U3 Jacobians", "blocks + reflectors", "apply reflectors", "gate H Pcc", "S", "LDLt", "shares"]
-means, maxs, counts = [], [], []
+means, maxs, counts, gram = [], [], [], []
 out, mx = (C.c_longlong * 64)(), (C.c_longlong * 64)()
 h.L.rvio_hip_debug_phases(h.h, out, mx)
 for i in range(n_frames):
@@ -40,9 +40,12 @@ for i in range(n_frames):
         means.append(s[0:11] / np.maximum(cnt, 1) / 100.0)
         maxs.append(m[30:41] / 100.0)
         counts.append(cnt)
+        gram.append(np.diff(m[45:50]) / 100.0)      # gram_reduce_kernel workgroup 0 (DBG_U 45..49): list, counters, decision, sums
 means, maxs, counts = np.array(means), np.array(maxs), np.array(counts)
+gram = np.array(gram)
 print("frames with an update: %d; features per update (workgroups past the header): median %d" % (len(means), int(np.median(counts[:, 0]))))
 for k, nm in enumerate(names):
     print("  %-22s mean over features %6.2f us | longest %6.2f us | reached by %3d workgroups" % (nm, np.median(means[:, k]), np.median(maxs[:, k]), int(np.median(counts[:, k]))))
 print("  sum of the longest phases %.1f us; sum of the means %.1f us" % (np.sum(np.median(maxs, axis=0)), np.sum(np.median(means, axis=0))))
+print("gram_reduce_kernel workgroup 0 (us, medians): accepted-feature list %.2f | counters %.2f | literal / candidate decision %.2f | sums %.2f" % tuple(np.median(gram, axis=0)))
 h.close()
