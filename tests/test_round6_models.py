@@ -1,4 +1,5 @@
-"""Round 6: RANSAC's SetPointPair (Ransac.cc:50-83) runs on the device as a WAVE-PARALLEL walk of glibc's rand() stream
+"""Round 6: NumPy models of three device-side reformulations, each against the serial form it replaces (SetPointPair, the squared-distance threshold,
+the pose-chain scan).  First: RANSAC's SetPointPair (Ransac.cc:50-83) runs on the device as a WAVE-PARALLEL walk of glibc's rand() stream
 (csrc/frontend_kernels.hip ransac_body): the additive-feedback generator r[i] = r[i-3] + r[i-31] advances 31 draws per "turn" of its ring as a
 stride-3 prefix sum, a draw is accepted exactly when its value has not been drawn before (first occurrence), the 16 pairs are the first 32
 accepted draws in order and the stream stops at the draw that delivered the 32nd.  This is the NumPy model of that algorithm, step for step
@@ -145,3 +146,29 @@ def test_squared_distance_threshold_takes_the_same_decisions_as_the_sqrt_compari
         for v in around:
             if v >= 0:
                 assert (np.sqrt(v) > m) == (v > T), (m, v, T)
+
+
+def test_pose_chain_as_a_prefix_scan_of_affine_maps():
+    """U1 (Updater.cc:114-141): R_I(i) = R(q_i) R_I(i-1), t_I(i) = R(q_i) (t_I(i-1) - p_i).  The device evaluates it as an inclusive Hillis-Steele scan of
+    the affine maps A_i(x) = R_i x - R_i p_i over a 16-lane row (csrc/filter_kernels.hip pose_chain_row16: steps 1, 2, 4, 8).  NumPy model of exactly
+    those steps against the serial recursion: equal to rounding for every chain length the row holds."""
+    rng = np.random.default_rng(3)
+    for n in range(1, 16):
+        q = rng.standard_normal((n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        p = rng.standard_normal((n, 3))
+        R = np.stack([O.quat_to_rot(qi) for qi in q])
+        RI, tI, want = R[0], -R[0] @ p[0], []
+        for i in range(n):
+            if i > 0:
+                tI = R[i] @ (tI - p[i]); RI = R[i] @ RI
+            want.append((RI.copy(), tI.copy()))
+        Rs, cs = R.copy(), np.stack([-R[i] @ p[i] for i in range(n)])
+        d = 1
+        while d < 16:
+            Rp, cp = Rs.copy(), cs.copy()
+            for l in range(d, n):
+                cs[l] = Rp[l] @ cp[l - d] + cp[l]
+                Rs[l] = Rp[l] @ Rp[l - d]
+            d *= 2
+        for i in range(n):
+            assert np.max(np.abs(Rs[i] - want[i][0])) < 1e-14 and np.max(np.abs(cs[i] - want[i][1])) < 1e-13 * (1 + np.max(np.abs(want[i][1])))
