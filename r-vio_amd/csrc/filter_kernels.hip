@@ -1995,12 +1995,12 @@ __global__ __launch_bounds__(256) void final_lds_kernel(DevCfg cfg, int n, const
 #define JL_LDS_DOUBLES (3 * 60 * JL_LS + 8 * 16 * JL_LS + 16)
 __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, const double* __restrict__ P, const double* __restrict__ W, const double* __restrict__ Ab,
                                                          double* __restrict__ Pout, FilterMeta* __restrict__ meta, const double* __restrict__ x, double* __restrict__ x_out,
-                                                         const double* __restrict__ dx_scr, int n_pairs) {
+                                                         const double* __restrict__ dx_scr, int n_pairs, int dx_nt) {
     // dx_scr != NULL (round 6): the workgroups behind the n_pairs tile pairs are the solve's dx / state-injection roles (solve9.hip s9_dx_role): dx = Pc y
     // needs W complete exactly like U = Pc W, and nothing in this launch needs dx — 4.7 us less on the filter chain's serial path
     if (dx_scr && (int)blockIdx.x >= n_pairs) {
         __shared__ S9DxLds dxl;
-        s9_dx_role(cfg, meta, n, Ab, x, P, dx_scr, x_out, 4, (int)blockIdx.x - n_pairs, dxl);
+        s9_dx_role(cfg, meta, n, Ab, x, P, dx_scr, x_out, dx_nt, (int)blockIdx.x - n_pairs, dxl);
         return;
     }
     extern __shared__ __align__(16) double jl[];

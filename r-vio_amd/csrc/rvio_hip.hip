@@ -967,8 +967,15 @@ static void launch_solve(rvio_hip* h, int n, const double* Ab, bool defer_dx = f
                                     h->batch > 1 ? S9_SLAB_DOUBLES(4) * sizeof(double) : (size_t)0);
             return;
         case 6:
-            if (pre) hipLaunchKernelGGL((solve9_kernel<2, 3, true>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
-            else hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0);
+        {
+            // the frame's update at 64 < 6n_max <= 96: dx = Pc y and the state injection ride in the Joseph stage's launch (joseph_lds_kernel while the window still
+            // holds <= 10 clones, ug_tile_kernel<0> beyond 64 columns; the two-launch LDS form in between has no roles)
+            static const bool no_dx_mid = ab_env("RVIO_S9_NO_DX_ROLE") != nullptr;   // A/B timing
+            const bool role = defer_dx && h->batch == 1 && !no_dx_mid && (6 * n <= 60 ? !ab_env("RVIO_NO_JOSEPH_LDS") : (6 * n > 64 && !ab_env("RVIO_NO_UG_TILE")));
+            if (pre) hipLaunchKernelGGL((solve9_kernel<2, 3, true>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0, role ? 1 : 0);
+            else hipLaunchKernelGGL((solve9_kernel<2, 3>), gb, dim3(576), 0, h->stream, d, h->meta, n, Ab, xin, Pc, h->S9scr, h->W, xout, h->slab_bytes, (size_t)0, role ? 1 : 0);
+            h->dx_pending = role;
+        }
             return;
         default: break;
         }
@@ -1050,7 +1057,7 @@ static void launch_ug_final(rvio_hip* h, int n, const double* Ab, double* Pn, bo
         const bool dxr = h->dx_pending;   // the all-LDS solve left dx = Pc y and the state injection to role workgroups of this launch
         h->dx_pending = false;
         hipLaunchKernelGGL(joseph_lds_kernel, dim3(npair + (dxr ? (dd + 23) / 24 : 0)), dim3(256), JL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, Pn,
-                           h->meta, (const double*)h->x[h->cur], h->x[h->cur ^ 1], dxr ? (const double*)h->S9scr : (const double*)nullptr, npair);
+                           h->meta, (const double*)h->x[h->cur], h->x[h->cur ^ 1], dxr ? (const double*)h->S9scr : (const double*)nullptr, npair, h->solve9_nt);
     } else if (B == 1 && c6 <= 64 && !no_ugl) {   // one instance, short window: every operand of a workgroup staged in LDS with one batch of loads
         if (ug) hipLaunchKernelGGL(ug_lds_kernel, dim3(nt), dim3(256), UGL_LDS_DOUBLES * sizeof(double), h->stream, d, n, Pc, h->W, Ab, h->U, h->G, h->Pt1);
         if (fin) hipLaunchKernelGGL(final_lds_kernel, dim3((npair + 3) / 4), dim3(256), FNL_LDS_DOUBLES * sizeof(double), h->stream, d, n, h->Pt1, h->G, h->U, Pn);

@@ -388,7 +388,9 @@ __device__ __forceinline__ void s9_sweep(s9_d4 (&S)[BS * BS], double (*s_rowp)[W
 template <int BS, int WGR, bool PRE = false>
 __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, FilterMeta* __restrict__ meta, int n, const double* __restrict__ Ab,
                                                                 const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ scr,
-                                                                double* __restrict__ Wout, double* __restrict__ x_out, size_t bs, size_t scr_bs) {
+                                                                double* __restrict__ Wout, double* __restrict__ x_out, size_t bs, size_t scr_bs, int defer_dx = 0) {
+    // defer_dx (round 6; one instance, the frame's update): the kernel ends with W and the by-tile-column shares of y = W b in the slab; dx = Pc y and the
+    // state injection are role workgroups of the Joseph launch right behind it (s9_dx_role), as in the split form and in solve9_small_kernel
     meta = zoff(meta, bs); Ab = zoff(Ab, bs); x = zoff(x, bs); P = zoff(P, bs); Wout = zoff(Wout, bs); x_out = zoff(x_out, bs);
     scr = (double*)((char*)scr + (size_t)blockIdx.z * scr_bs);
     constexpr int NW = WGR * WGR, NT = WGR * BS, NTH = 64 * NW, TS = BS * BS, NP = 16 * NT;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     if (tid == 0) { meta->n_good = n_good; meta->n_rows = n_rows; meta->updated = upd ? 1 : 0; meta->trunc_at = (int)Ab[(size_t)ldh * (ldh - 1) + 2]; s_bad = 0; }
     if (!upd) {                                        // pass-through (Updater.cc:621-627): W = 0 => U = G = 0 => P+ = P exactly
         for (int e = tid; e < c6 * c6; e += NTH) Wout[(size_t)(e / c6) * ldh + (e % c6)] = 0.0;
-        for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];
+        if (!defer_dx) for (int i = tid; i < xd; i += NTH) x_out[i] = x[i];      // (deferred: the roles pass the state through)
         return;
     }
     DBG_T(30);
@@ -532,6 +534,14 @@ __global__ __launch_bounds__(64 * WGR * WGR) void solve9_kernel(DevCfg cfg, Filt
     if (bad) atomicOr(&s_bad, 1);
     __syncthreads();
     if (tid == 0 && s_bad) atomicOr(&meta->err, 1);
+    if (defer_dx) {      // the shares of y go to the slab in the layout of the split form (S9_YP_OFF: [tile column][row]); the sweep's verdict word is reported above
+        double* ypg = scr + S9_YP_OFF(NT);
+        for (int e = tid; e < NT * NP; e += NTH) ypg[e] = s_yp[e / NP][e % NP];
+        if (tid == 0) scr[(size_t)5 * NT * NT * S9_TILE + 1] = 0.0;
+        DBG_T(37); DBG_T(38);
+        DBG_R(true, 7);
+        return;
+    }
     for (int i = tid; i < NP; i += NTH) { double acc = s_yp[0][i]; for (int j = 1; j < NT; ++j) acc += s_yp[j][i]; s_y[i] = acc; }
     __syncthreads();
 
