@@ -30,7 +30,14 @@ def test_the_drivers_bench_command_prints_its_line(gpu_required):
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["achieved"] > 0 and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     hot = [o for o in out["roofline_other"] if "section 8(f)" not in o["kernel"]]
-    assert "traffic" in rf and rf["avg_us"] >= max(o["avg_us"] for o in hot)     # the dominant kernel is the slowest hot-path kernel timed
+    assert "traffic" in rf and rf["avg_us"] > 0
+    # the identity: the hot-path kernel with the largest average in the committed kernel trace of this configuration (round 6: the same kernel in every invocation) —
+    # or, for a configuration without a committed trace, the slowest hot-path kernel timed live
+    if "trace_avg_us" in rf:
+        assert all("trace_avg_us" in o for o in hot) and rf["trace_avg_us"] >= max(o["trace_avg_us"] for o in hot)
+        assert "klt_kernel3" in rf["kernel"]                                      # (what profiles/r06_kernel_stats_stream.md says for the stock configuration)
+    else:
+        assert rf["avg_us"] >= max(o["avg_us"] for o in hot)
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("port", "reference") and cb["sample"]
     par = out["parity"]
