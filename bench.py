@@ -653,6 +653,9 @@ def latency_pass(cfg, torch, fs, wi, ai, ni, device=0, name="B"):
         tm = [v for k, v in trace.items() if c["launched_by_timed_path"].split()[0].split("<")[0] in k]
         if tm and "+" not in c["launched_by_timed_path"]:       # (the split solve is six launches: no single trace row stands for it — live rule for those windows)
             c["trace_avg_us"], c["trace_median_us"] = tm[0]
+            if c["achieved"] is not None:       # the same algorithmic work over the AVERAGE launch of the traced run (every frame, the fast-motion ones included): the conservative figure
+                c["achieved_at_trace_avg"] = c["achieved"] * c["avg_us"] / c["trace_avg_us"]
+                c["frac_at_trace_avg"] = c["achieved_at_trace_avg"] / c["peak"]
     if all("trace_avg_us" in c for c in cands):
         cands.sort(key=lambda c: -c["trace_avg_us"])
         how = ("the largest average in the committed kernel trace of the default run (profiles/%s: %s) among the section-8(a) kernels of the frame; kernels whose duration contains a "
