@@ -2022,7 +2022,10 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
     int I = 0, rem = blockIdx.x;
     while (rem >= nt - I) { rem -= nt - I; ++I; }
     const int J = I + rem;
+    // (first rows of strip I and strip J; selected with a compare, never indexed with a run-time value: a two-element array indexed by `sidx & 1` lived in
+    //  SCRATCH — a private-memory load in front of every strip load and operand fetch of this kernel, round 6)
     const int r0[2] = {I * 16, J * 16};
+    auto r0of = [&](int sidx) { return sidx ? J * 16 : I * 16; };
     DBG_T(20);
     double p0[4] = {0, 0, 0, 0}, p0t[4] = {0, 0, 0, 0};   // wave 0: the P tiles of the closing stage, in flight from the start — p0[q] = P(I16 + lk + 4q, J16 + li),
     if (wave == 0) {                                        // p0t[q] = P(J16 + li, I16 + lk + 4q) (the (J, I) tile in the transposed lane layout)
@@ -2047,7 +2050,7 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;     // 2 strips x 60 columns x 16 rows
-            const int row = r0[sidx & 1] + rr;
+            const int row = r0of(sidx & 1) + rr;
             vs[u] = (e < 1920 && k < c6 && row < d) ? P[(size_t)row + (size_t)(24 + k) * ld] : 0.0;
         }
 #pragma unroll
@@ -2110,7 +2113,7 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
     const int nprod = (I == J) ? 3 : 6;
     auto product = [&](int pidx) -> d4 {
         const int sa = pidx / 3, sb = sa ^ 1, kind = pidx - 3 * sa;       // rows of strip sa, columns of strip sb
-        const int i0 = r0[sa], c = r0[sb] + li;
+        const int i0 = r0of(sa), c = r0of(sb) + li;
         const double* Xa = (kind == 1 ? Qs : Gs) + sa * SS;
         const double* Yb = (kind == 0 ? PcS : (kind == 1 ? Gs : Us)) + sb * SS;
         const bool rowok = kind == 0 || i0 + li < d;
