@@ -51,6 +51,30 @@ __device__ __forceinline__ double fast_rcp(double v) {
     y = fma(fma(-v, y, 1.0), y, y);
     return fma(fma(-v, y, 1.0), y, y);
 }
+// sin and cos of a bearing angle (round 6): one Cody-Waite step to |r| <= pi/4 and the two minimax kernels of the public fdlibm (k_sin.c / k_cos.c
+// coefficients, < 1 ulp each) — ~40 instructions against the ~215 of the library's double-double sincos, which the LM loop ran once per iteration and
+// the Jacobian phase twice (a quarter of an LM iteration).  The angles of a valid feature stay inside +-pi/2; anything the iteration throws outside
+// 1e5 (or a NaN) takes the library routine, so a diverging feature ends the way it did.  Differences from the library: last-bit.
+__device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
+    if (!(fabs(x) < 1e5)) { sincos(x, sp, cp); return; }
+    const double kf = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-kf, 1.57079632679489655800e+00, x);
+    r = fma(-kf, 6.12323399573676603587e-17, r);
+    const int q = (int)kf & 3;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06); ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03); ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07); pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03); pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + (z * z) * pc);
+    const double s = (q & 1) ? cr : sr, c = (q & 1) ? sr : cr;
+    *sp = (q & 2) ? -s : s;
+    *cp = ((q + 1) & 2) ? -c : c;
+}
 
 // U1 relative-pose chain (Updater.cc:114-141) of a track of at most 16 observations as a PREFIX SCAN inside one 16-lane DPP row (round 6): lane l
 // holds clone l's rotation R_l = R(q_l) and position p_l, i.e. the affine map A_l(x) = R_l (x - p_l) = R_l x + c_l; the chain R_I(l) = R_l R_I(l-1),
@@ -241,26 +265,32 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
         if (tid == 0) { misc[0] = pfinv_out[3 * f]; misc[1] = pfinv_out[3 * f + 1]; misc[2] = pfinv_out[3 * f + 2]; misc[3] = gvalid[f] ? 1.0 : 0.0; }
     } else
     if (wave0) {
-        phi = atan2((double)fy0, sqrt((double)fx0 * (double)fx0 + 1));
-        psi = atan2((double)fx0, 1.0);
+        {   // one atan2 for both angles (even lanes phi, odd lanes psi), as the sincos below
+            const double av = atan2((lane & 1) ? (double)fx0 : (double)fy0, (lane & 1) ? 1.0 : sqrt((double)fx0 * (double)fx0 + 1));
+            phi = readlane_f64(av, 0); psi = readlane_f64(av, 1);
+        }
         if (fabs(phi) > .5 * 3.14 || fabs(psi) > .5 * 3.14) valid = false;
-        const bool act = lane < L;
-        const float mx = mxv, my = myv;
+        // a track of at most 16 observations: EVERY 16-lane row computes observation (lane & 15), and each row reduces its own three of the ten
+        // sums (same DPP order inside a row: same bits) — three row reductions per iteration instead of ten
+        const bool packed = L <= 16;
+        const int ob = packed ? (lane & 15) : lane;
+        const bool act = ob < L;
+        const float mx = packed ? __shfl(mxv, ob, 64) : mxv, my = packed ? __shfl(myv, ob, 64) : myv;
         m33 Rc = eye33(); d3 tc = mk3(0, 0, 0);
-        if (act && lane > 0) { Rc = ldm33(pose + (lane - 1) * 24 + 12); tc = ld3(pose + (lane - 1) * 24 + 21); }
+        if (act && ob > 0) { Rc = ldm33(pose + (ob - 1) * 24 + 12); tc = ld3(pose + (ob - 1) * 24 + 21); }
         const double ri = 1. / sig2;
         double lambda = 0.01, lastCost = INFINITY;
         if (valid) {
             for (int it = 0; it < 10; ++it) {
                 // one sincos for both angles: even lanes take phi, odd lanes psi (every lane would compute the same pair anyway)
                 double sv, cv;
-                sincos((lane & 1) ? psi : phi, &sv, &cv);
+                sincos_fast((lane & 1) ? psi : phi, &sv, &cv);
                 const double sph = readlane_f64(sv, 0), cph = readlane_f64(cv, 0), sps = readlane_f64(sv, 1), cps = readlane_f64(cv, 1);
                 const d3 ep = mk3(cph * sps, sph, cph * cps);
                 const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
                 double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, g0 = 0, g1 = 0, g2 = 0, cost = 0;
                 if (act) {
-                    d3 h = (lane == 0) ? ep : add3(mv33(Rc, ep), scl3(rho, tc));
+                    d3 h = (ob == 0) ? ep : add3(mv33(Rc, ep), scl3(rho, tc));
                     // (reciprocal by estimate + two Newton steps; the five IEEE divisions of this block were a fifth of the iteration)
                     const double iz = fast_rcp(h.z);
                     const double Hp0[3] = {iz, 0, -(h.x * iz) * iz}, Hp1[3] = {0, iz, -(h.y * iz) * iz};
@@ -275,7 +305,7 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                     H0[1] = HR0[0] * J01 + HR0[2] * J21;
                     H1[0] = HR1[0] * J00 + HR1[1] * J10 + HR1[2] * J20;
                     H1[1] = HR1[0] * J01 + HR1[2] * J21;
-                    if (lane == 0) { H0[2] = 0; H1[2] = 0; }
+                    if (ob == 0) { H0[2] = 0; H1[2] = 0; }
                     else { H0[2] = Hp0[0] * tc.x + Hp0[2] * tc.z; H1[2] = Hp1[1] * tc.y + Hp1[2] * tc.z; }
                     const float px = (float)(h.x * iz), py = (float)(h.y * iz);    // cv::Point2f rounding (Updater.cc:197-202)
                     const double e0 = (double)(mx - px), e1 = (double)(my - py);
@@ -290,11 +320,15 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
                     g1 = (H0[1] * ri) * e0 + (H1[1] * ri) * e1;
                     g2 = (H0[2] * ri) * e0 + (H1[2] * ri) * e1;
                 }
-                if (L <= 16) {   // all observations sit in the first 16-lane row: same sums, no cross-row combine
-                    cost = row16_sum(cost);
-                    c00 = row16_sum(c00); c01 = row16_sum(c01); c02 = row16_sum(c02);
-                    c11 = row16_sum(c11); c12 = row16_sum(c12); c22 = row16_sum(c22);
-                    g0 = row16_sum(g0); g1 = row16_sum(g1); g2 = row16_sum(g2);
+                if (packed) {    // row 0: cost c00 c01 | row 1: c02 c11 c12 | row 2: c22 g0 g1 | row 3: g2
+                    const int rw = lane >> 4;
+                    double q0 = rw == 0 ? cost : rw == 1 ? c02 : rw == 2 ? c22 : g2;
+                    double q1 = rw == 0 ? c00 : rw == 1 ? c11 : g0;
+                    double q2 = rw == 0 ? c01 : rw == 1 ? c12 : g1;
+                    q0 = row16_allsum(q0); q1 = row16_allsum(q1); q2 = row16_allsum(q2);
+                    cost = readlane_f64(q0, 0); c02 = readlane_f64(q0, 16); c22 = readlane_f64(q0, 32); g2 = readlane_f64(q0, 48);
+                    c00 = readlane_f64(q1, 0); c11 = readlane_f64(q1, 16); g0 = readlane_f64(q1, 32);
+                    c01 = readlane_f64(q2, 0); c12 = readlane_f64(q2, 16); g1 = readlane_f64(q2, 32);
                 } else {
                     cost = wave_sum(cost);
                     c00 = wave_sum(c00); c01 = wave_sum(c01); c02 = wave_sum(c02);
@@ -338,7 +372,11 @@ __device__ __forceinline__ void feat_build_body(DevCfg cfg, int n, const double*
     const int nStartCol = (type == '1') ? 6 * (n - (Lu - 1)) : 0;
     const int cLo = nStartCol, cHi = nStartCol + 6 * (Lu - 1);   // non-zero column range of this feature
     double sph, cph, sps, cps;
-    sincos(phi, &sph, &cph); sincos(psi, &sps, &cps);
+    {
+        double sv, cv;
+        sincos_fast((tid & 1) ? psi : phi, &sv, &cv);
+        sph = readlane_f64(sv, 0); cph = readlane_f64(cv, 0); sps = readlane_f64(sv, 1); cps = readlane_f64(cv, 1);
+    }
     const d3 ep = mk3(cph * sps, sph, cph * cps);
     const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;
     for (int e = tid; e < M2 * ldh; e += T) Hx[e] = 0.0;
@@ -726,8 +764,11 @@ __global__ __launch_bounds__(64) void geom4_kernel(DevCfg cfg, int n, const doub
     __syncthreads();
     // ---- U2 (feat_build_kernel, same expressions; lane l of the row <-> observation l)
     const float fx0 = __shfl(mxv, lane & 48, 64), fy0 = __shfl(myv, lane & 48, 64);
-    double phi = atan2((double)fy0, sqrt((double)fx0 * (double)fx0 + 1));
-    double psi = atan2((double)fx0, 1.0);
+    double phi, psi;
+    {
+        const double av = atan2((l & 1) ? (double)fx0 : (double)fy0, (l & 1) ? 1.0 : sqrt((double)fx0 * (double)fx0 + 1));
+        phi = row_bcast(av, 0); psi = row_bcast(av, 1);
+    }
     double rho = 0;
     bool valid = true;
     if (fabs(phi) > .5 * 3.14 || fabs(psi) > .5 * 3.14) valid = false;
@@ -742,7 +783,7 @@ __global__ __launch_bounds__(64) void geom4_kernel(DevCfg cfg, int n, const doub
         for (int it = 0; it < 10; ++it) {
             if (__builtin_amdgcn_readfirstlane(__any(!done)) == 0) break;
             double sv, cv;
-            sincos((l & 1) ? psi : phi, &sv, &cv);
+            sincos_fast((l & 1) ? psi : phi, &sv, &cv);
             const double sph = row_bcast(sv, 0), cph = row_bcast(cv, 0), sps = row_bcast(sv, 1), cps = row_bcast(cv, 1);
             const d3 ep = mk3(cph * sps, sph, cph * cps);
             const double J00 = -sph * sps, J01 = cph * cps, J10 = cph, J20 = -sph * cps, J21 = -cph * sps;

@@ -263,6 +263,13 @@ __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_f64<0x121>(v);
     return readlane_f64(v, 0);
 }
+__device__ __forceinline__ double row16_allsum(double v) {   // the same four rotations in every 16-lane row; the first lane of a row holds row16_sum's bits
+    v += dpp_f64<0x128>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x121>(v);
+    return v;
+}
 template <int CTRL>
 __device__ __forceinline__ long long dpp_i64(long long v) {
     int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
