@@ -2078,32 +2078,46 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
             p0t[q] = ok ? P[(size_t)c + (size_t)row * ld] : 0.0;
         }
     }
-    {   // ONE batch of coalesced loads: W, A (row-major, ld = ldh), Pcc and the two Pc strips (column-major sources)
-        double vw[15], va[15], vc[15], vs[8];
+    // ONE batch of coalesced loads: W and the two Pc strips first (what U = Pc W needs), then A and Pcc (column-major source) — those two stay in
+    // registers through the first strip round and go to LDS behind it (round 6; vmcnt retires in issue order).
+    // NO predicated load anywhere in this kernel (round 6): `ok ? mem[i] : 0.0` compiles to an exec-mask save / restore around every single load — ten
+    // instructions per LDS read, 403 such sequences, ~3 k of a strip round's ~6 k cycles.  Global loads take a clamped address and a select; the LDS
+    // operands need no mask at all: every buffer is zero beyond 6n columns / d rows (the staging writes zeros there, the strips' outputs start zeroed
+    // and are stored up to column 60), so the products add the same exact zeros the masks produced.  Columns 60..63 of a tile's B operand read past
+    // the row (finite or not: a column of the product nobody stores; the A operand is always initialised).
+    auto ldz = [](const double* __restrict__ p, size_t i, bool ok) { const double v = p[ok ? i : 0]; return ok ? v : 0.0; };
+    double vw[15], va[15], vc[15], vs[8];
 #pragma unroll
-        for (int u = 0; u < 15; ++u) {
-            const int e = tid + u * 256, k = e / 60, j = e - k * 60;            // 3600 = 60 x 60 elements
-            const bool ok = e < 3600 && k < c6 && j < c6;
-            vw[u] = ok ? W[(size_t)k * ldh + j] : 0.0;
-            va[u] = ok ? Ab[(size_t)k * ldh + j] : 0.0;
-            vc[u] = ok ? P[(size_t)(24 + j) + (size_t)(24 + k) * ld] : 0.0;      // element (row c = j, k) of Pcc read down column k: consecutive threads, consecutive rows
-        }
+    for (int u = 0; u < 15; ++u) {
+        const int e = tid + u * 256, k = e / 60, j = e - k * 60;            // 3600 = 60 x 60 elements
+        vw[u] = ldz(W, (size_t)k * ldh + j, e < 3600 && k < c6 && j < c6);
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;     // 2 strips x 60 columns x 16 rows
-            const int row = r0of(sidx & 1) + rr;
-            vs[u] = (e < 1920 && k < c6 && row < d) ? P[(size_t)row + (size_t)(24 + k) * ld] : 0.0;
-        }
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;     // 2 strips x 60 columns x 16 rows
+        const int row = r0of(sidx & 1) + rr;
+        vs[u] = ldz(P, (size_t)row + (size_t)(24 + k) * ld, e < 1920 && k < c6 && row < d);
+    }
 #pragma unroll
-        for (int u = 0; u < 15; ++u) {
-            const int e = tid + u * 256, k = e / 60, j = e - k * 60;
-            if (e < 3600) { Wl[k * LS + j] = vw[u]; Al[k * LS + j] = va[u]; Ccl[j * LS + k] = vc[u]; }
-        }
+    for (int u = 0; u < 15; ++u) {
+        const int e = tid + u * 256, k = e / 60, j = e - k * 60;
+        va[u] = ldz(Ab, (size_t)k * ldh + j, e < 3600 && k < c6 && j < c6);
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;
-            if (e < 1920) PcS[(sidx & 1) * SS + rr * LS + k] = vs[u];
-        }
+    for (int u = 0; u < 15; ++u) {
+        const int e = tid + u * 256, k = e / 60, j = e - k * 60;
+        vc[u] = ldz(P, (size_t)(24 + j) + (size_t)(24 + k) * ld, e < 3600 && k < c6 && j < c6);      // element (row c = j, k) of Pcc read down column k: consecutive threads, consecutive rows
+    }
+    for (int e = tid; e < 6 * SS; e += 256) Us[e] = 0.0;     // U, G, P1c strips (contiguous): zero beyond the columns the rounds store
+#pragma unroll
+    for (int u = 0; u < 15; ++u) {
+        const int e = tid + u * 256, k = e / 60, j = e - k * 60;
+        if (e < 3600) Wl[k * LS + j] = vw[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * 256, sidx = e / 960, ee = e - sidx * 960, k = ee >> 4, rr = ee & 15;
+        if (e < 1920) PcS[(sidx & 1) * SS + rr * LS + k] = vs[u];
     }
     __syncthreads();
     DBG_T(21);
@@ -2113,32 +2127,37 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
     // matrix pipe idle between issues; the pipe of one SIMD — 64 cycles per 16x16x4 — is what bounds this kernel).  Yt: Y(k, c) = Ym[c * LS + k]
     auto strips = [&](const double* X, const double* Ym, bool Yt, double* out, const double* sub) {
         const int t0 = wave, t1 = wave + 4, ntile = 2 * ntj;
-        const int s0 = t0 / ntj, c0 = (t0 - s0 * ntj) * 16 + li, s1 = t1 / ntj, c1 = (t1 - s1 * ntj) * 16 + li;
-        const bool v0 = t0 < ntile, v1 = t1 < ntile;
-        double a0[16], b0[16], a1[16], b1[16];
+        const bool v0 = t0 < ntile, v1 = t1 < ntile;      // (a tile past the last one: computed on clamped operands, not stored)
+        const int s0 = min(t0 / ntj, 1), c0 = (t0 % ntj) * 16 + li, s1 = min(t1 / ntj, 1), c1 = (t1 % ntj) * 16 + li;
+        double a0[15], b0[15], a1[15], b1[15];     // 6n <= 60: fifteen k-blocks (a sixteenth would add zeros)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 15; ++u) {
             const int k = 4 * u + lk;
-            const bool kok = k < c6;
-            a0[u] = (kok && v0) ? X[s0 * SS + li * LS + k] : 0.0;
-            b0[u] = (kok && v0 && c0 < c6) ? (Yt ? Ym[c0 * LS + k] : Ym[k * LS + c0]) : 0.0;
-            a1[u] = (kok && v1) ? X[s1 * SS + li * LS + k] : 0.0;
-            b1[u] = (kok && v1 && c1 < c6) ? (Yt ? Ym[c1 * LS + k] : Ym[k * LS + c1]) : 0.0;
+            a0[u] = X[s0 * SS + li * LS + k];
+            b0[u] = Yt ? Ym[c0 * LS + k] : Ym[k * LS + c0];
+            a1[u] = X[s1 * SS + li * LS + k];
+            b1[u] = Yt ? Ym[c1 * LS + k] : Ym[k * LS + c1];
         }
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 15; ++u) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
         }
+        const bool st0 = v0 && c0 < 60, st1 = v1 && c1 < 60;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = lk + 4 * q;
-            if (v0 && c0 < c6) out[s0 * SS + row * LS + c0] = sub ? (sub[s0 * SS + row * LS + c0] - acc0[q]) : acc0[q];
-            if (v1 && c1 < c6) out[s1 * SS + row * LS + c1] = sub ? (sub[s1 * SS + row * LS + c1] - acc1[q]) : acc1[q];
+            if (st0) out[s0 * SS + row * LS + c0] = sub ? (sub[s0 * SS + row * LS + min(c0, 59)] - acc0[q]) : acc0[q];
+            if (st1) out[s1 * SS + row * LS + c1] = sub ? (sub[s1 * SS + row * LS + min(c1, 59)] - acc1[q]) : acc1[q];
         }
     };
     strips(PcS, Wl, false, Us, nullptr);             // U = Pc W
+#pragma unroll
+    for (int u = 0; u < 15; ++u) {
+        const int e = tid + u * 256, k = e / 60, j = e - k * 60;
+        if (e < 3600) { Al[k * LS + j] = va[u]; Ccl[j * LS + k] = vc[u]; }
+    }
     __syncthreads();
     DBG_T(22);
     strips(Us, Al, false, Gs, nullptr);              // G = U A
@@ -2153,17 +2172,15 @@ __global__ __launch_bounds__(256) void joseph_lds_kernel(DevCfg cfg, int n, cons
     double (*const xt)[16][17] = reinterpret_cast<double (*)[16][17]>(Wl);
     const int nprod = (I == J) ? 3 : 6;
     auto product = [&](int pidx) -> d4 {
-        const int sa = pidx / 3, sb = sa ^ 1, kind = pidx - 3 * sa;       // rows of strip sa, columns of strip sb
-        const int i0 = r0of(sa), c = r0of(sb) + li;
+        const int sa = pidx / 3, sb = sa ^ 1, kind = pidx - 3 * sa;       // rows of strip sa, columns of strip sb (rows past d are zero in every strip)
         const double* Xa = (kind == 1 ? Qs : Gs) + sa * SS;
         const double* Yb = (kind == 0 ? PcS : (kind == 1 ? Gs : Us)) + sb * SS;
-        const bool rowok = kind == 0 || i0 + li < d;
-        double a1[16], b1[16];
+        double a1[15], b1[15];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int k = 4 * u + lk; a1[u] = (k < c6 && rowok) ? Xa[li * LS + k] : 0.0; b1[u] = (k < c6 && c < d) ? Yb[li * LS + k] : 0.0; }
+        for (int u = 0; u < 15; ++u) { const int k = 4 * u + lk; a1[u] = Xa[li * LS + k]; b1[u] = Yb[li * LS + k]; }
         d4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+        for (int u = 0; u < 15; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
         return acc;
     };
     {

@@ -93,4 +93,9 @@ if g:
     g = np.array(g)
     print("filter stream: augcomp(f-1) block 0 end -> gate(f) start %.1f us, gate start -> end %.1f us, gate end -> feat_prop(f) start %.1f us (means)" % tuple(g.mean(0)))
     print("gate duration per frame (us):", " ".join("%.0f" % v for v in g[:, 1]))
+ck = (C.c_longlong * 64)()
+h.L.rvio_hip_debug_clocks(h.h, ck)
+ck = np.array(list(ck), dtype=np.float64) / 100.0
+if ck[20] > 0 and ck[25] > ck[20]:
+    print("joseph_lds_kernel workgroup 0, last frame (us): loads %.2f | U = Pc W %.2f | G = U A %.2f | P1c %.2f | closing products %.2f" % tuple(ck[21:26] - ck[20:25]))
 h.close()
