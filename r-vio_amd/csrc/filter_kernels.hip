@@ -943,28 +943,35 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     if (lit.rows) { lit.rows = zoffi(lit.rows, bs, bi.z); lit.n_feat = zoffi(lit.n_feat, bin.n_feat, bi.z); if (lit.state) lit.state = zoffi(lit.state, bs, bi.z); }
     const int c6 = 6 * n, ldh = cfg.ldh, Fu = cfg.Fu;
     const int total = c6 * ldh;
+    const int nf_lit = (combine && lit.rows) ? *lit.n_feat : 0;      // (in flight with the list's loads)
     DBG_T(41); DBG_U(45);
     DBG_R(bi.x == 0, 1);
     // ascending list of the accepted features (wave ballots: order-preserving compaction); bit 30 marks type '2', bits 16..19 / 20..23 the
     // first / last 16-column tile of the feature's range (feat_build_kernel stores a share's tiles inside that range only)
-    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5];
+    __shared__ int s_list[GRAM_MAX_FEATS], s_wtot[4], s_base, s_cnt[5], s_wc[4][5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int f0 = 0; f0 < Fu; f0 += 256) {
-        const int f = f0 + tid;
-        const bool flag = f < Fu && nrows[f] > 0;
+    // (round 6: a feature's row count, length and type in ONE batch of unpredicated loads — the list and the counters below each took their own
+    //  dependent round trips through these three arrays: 1.2 + 0.9 us of the stage)
+    int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;       // this thread's part of the shard's counters: accepted features, their rows,
+    for (int f0 = 0; f0 < Fu; f0 += 256) {                             // the rows / last column of type '2', the first column of type '1'
+        const int f = f0 + tid, fc = f < Fu ? f : 0;
+        const int r = nrows[fc], L = lens[fc];
+        const bool t2 = types[fc] == '2';
+        const bool flag = f < Fu && r > 0;
         const unsigned long long mask = __ballot(flag);
         if (lane == 0) s_wtot[wave] = __popcll(mask);
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
         if (flag) {
-            const int L = lens[f];
-            const bool t2 = types[f] == '2';
             const int Lu = t2 ? (L + 1) / 2 : L, lo = t2 ? 0 : 6 * (n - (Lu - 1)), hi = lo + 6 * (Lu - 1);
             const int slot = off + __popcll(mask & ((1ull << lane) - 1ull));
             s_list[slot] = f | (t2 ? (1 << 30) : 0) | ((lo >> 4) << 16) | (((hi - 1) >> 4) << 20);
+            good++; rows += r;
+            if (t2) { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
+            else smin = min(smin, 6 * (n - (L - 1)));
         }
         __syncthreads();
         if (tid == 0) s_base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
@@ -974,22 +981,13 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     const size_t gs = (size_t)ldh * ldh;
     double* S2 = block; double* S1 = block + gs;
     DBG_T(42); DBG_U(46);
-    // counters of this shard (wave 0 of every workgroup: Fu small integers): accepted features, their rows, the rows / last column of
-    // type '2', the first column of type '1'
-    if (tid < 64) {
-        int good = 0, rows = 0, rows2 = 0, e2 = -1, smin = TR_NONE;
-        for (int f = tid; f < Fu; f += 64) {
-            const int r = nrows[f];
-            if (r > 0) {
-                good++; rows += r;
-                const int L = lens[f];
-                if (types[f] == '2') { rows2 += r; e2 = max(e2, 6 * ((L + 1) / 2 - 1) - 1); }
-                else smin = min(smin, 6 * (n - (L - 1)));
-            }
-        }
-        good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
-        for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
-        if (tid == 0) { s_cnt[0] = good; s_cnt[1] = rows; s_cnt[2] = rows2; s_cnt[3] = e2; s_cnt[4] = smin; }
+    good = (int)wave_sum_i64(good); rows = (int)wave_sum_i64(rows); rows2 = (int)wave_sum_i64(rows2);
+    for (int o = 32; o > 0; o >>= 1) { e2 = max(e2, __shfl_xor(e2, o, 64)); smin = min(smin, __shfl_xor(smin, o, 64)); }
+    if (lane == 0) { s_wc[wave][0] = good; s_wc[wave][1] = rows; s_wc[wave][2] = rows2; s_wc[wave][3] = e2; s_wc[wave][4] = smin; }
+    __syncthreads();
+    if (tid < 5) {
+        const int a0 = s_wc[0][tid], a1 = s_wc[1][tid], a2 = s_wc[2][tid], a3 = s_wc[3][tid];
+        s_cnt[tid] = tid < 3 ? a0 + a1 + a2 + a3 : tid == 3 ? max(max(a0, a1), max(a2, a3)) : min(min(a0, a1), min(a2, a3));
     }
     __syncthreads();
     DBG_U(47);
@@ -997,7 +995,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(DevCfg cfg, int n, con
     // rows and writes [A|b] itself; the shares are not needed.  (Unsharded update only: a shard's counters are partial — there the decision
     // is taken on the gathered whole, block_sum_kernel.)
     if (combine && lit.rows) {
-        const int nf = *lit.n_feat;
+        const int nf = nf_lit;
         if (lit_decide(lit.rows, n, nf, s_cnt[0], s_cnt[1], nrows, types, lens)) {
             if (bi.x != 0) return;
             lit_finish(cfg, n, nf, nrows, types, lens, lit.rows, block, s_cnt[0], s_cnt[1], lit.state ? lit.state : g_dyn + lit_aux_doubles(cfg.ldh, cfg.rho_max), lit.state == nullptr, g_dyn, lit.lds_doubles);
