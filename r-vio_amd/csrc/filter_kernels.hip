@@ -107,7 +107,10 @@ template <int NMAX>
 __device__ __forceinline__ double ldlt_gamma_wave(const double* S, int lds_s, int rr, int lane, bool* bad) {
     double row[NMAX];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) row[j] = (lane <= rr && j <= lane && j < rr) ? S[lane * lds_s + j] : 0.0;
+    for (int j = 0; j < NMAX; ++j) {                 // (clamped address + select: a predicated load costs an exec-mask save / restore each)
+        const double v = S[min(lane, rr) * lds_s + min(j, rr)];
+        row[j] = (lane <= rr && j <= lane && j < rr) ? v : 0.0;
+    }
     double gl = 0;
     bool neg = false;
 #pragma unroll

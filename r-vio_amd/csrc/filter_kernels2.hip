@@ -67,7 +67,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
         Psi[i][j] = (i == j) ? 1.0 : 0.0;
     }
     if (tid < 26) xs[tid] = x[tid];
-    DBG_T(10);
+    DBG_T(10); DBG_W(tid == 0, 26);
     __syncthreads();
     DBG_T(11);
     const d3 bg = ld3(xs + 20), ba = ld3(xs + 23);
@@ -302,7 +302,7 @@ __device__ __forceinline__ void propagate_body(DevCfg cfg, FilterMeta* __restric
             }
         }
     }
-    DBG_T(17);
+    DBG_T(17); DBG_W(tid == 0, 27);
 }
 
 __global__ __launch_bounds__(256) void propagate_kernel3(DevCfg cfg, FilterMeta* __restrict__ meta, int n, double* __restrict__ x,
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void feat_prop_kernel(DevCfg cfg, int n, doubl
                                                         FilterMeta* meta, const rvio_imu* imu, int m, double* chol_scr, int chol_nt, int shard_rank, int shard_world,
                                                         double* lit_rows) {
     DBG_R(blockIdx.x == 0, 0);
+    DBG_W(blockIdx.x == 0 && threadIdx.x == 0, 28);
     extern __shared__ __align__(16) double fp_dyn[];
     if (blockIdx.x == gridDim.x - 1) { propagate_body<16>(cfg, meta, n, x, P, imu, m, 0, 0, *reinterpret_cast<Prop3Lds<16>*>(fp_dyn)); return; }   // (its LDS: the launch's dynamic LDS)
     if (chol_scr && blockIdx.x == gridDim.x - 2) {
