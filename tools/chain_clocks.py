@@ -97,7 +97,7 @@ ck = (C.c_longlong * 64)()
 h.L.rvio_hip_debug_clocks(h.h, ck)
 ck = np.array(list(ck), dtype=np.float64) / 100.0
 if ck[20] > 0 and ck[25] > ck[20]:
-    print("joseph_lds_kernel workgroup 0, last frame (us): loads %.2f | U = Pc W %.2f | G = U A %.2f | P1c %.2f | closing products %.2f" % tuple(ck[21:26] - ck[20:25]))
+    print("joseph_lds_kernel workgroup 0, last frame (clock64 ticks / 100, ~2.35 GHz): loads %.2f | U = Pc W %.2f | G = U A %.2f | P1c %.2f | closing products %.2f" % tuple(ck[21:26] - ck[20:25]))
 if ck[38] > ck[30] > 0:
     print("solve9_small_kernel, last frame (clock64 ticks / 100): " + " | ".join("%d:+%.1f" % (i, ck[i] - ck[i - 1]) for i in range(31, 39)))
 if ck[27] > ck[26] > 0:
