@@ -814,6 +814,7 @@ struct S9SmallLds {
     double R[16][S9_TILE];                             // R(i, j) = (G A)(i, j)
     double rowp[2][4][S9_TILE];
     double F[2][S9_TILE];
+    double Z[4][S9_TILE];                              // Z(t) = F^-T-products of the sweep's row panel: formed ONCE per step (four waves), read by all
     S9Wave ws;
     double b[64], y[64], yp[4][64];
     double dx[24 + 64];
@@ -909,21 +910,27 @@ __global__ __launch_bounds__(1024) void solve9_small_kernel(DevCfg cfg, FilterMe
             s9_sts(sh.F[1], lane, Ft);
         }
         __syncthreads();
+        // (round 6) Z(t) = Ft^T rowp[t], t = 0..3, formed ONCE by waves 0..3 (one per SIMD) and shared through LDS: every wave used to form its own Zr = Z(ti)
+        // and Zc = Z(tj) — 32 tile products per step for 4 distinct results, and the FP64 matrix pipe of a SIMD (64 cycles per 16x16x4, four waves to a
+        // SIMD) was the step: 12 MFMAs x 4 waves = 3 k cycles.  Now 4 + 4 x 4 = 1.3 k and a barrier.  Same products on the same operands: same bits.
         F = s9_lds(sh.F[0], lane);
-        Ft = s9_lds(sh.F[1], lane);
-        const s9_d4 Zr = s9_tn(Ft, s9_lds(rowp[ti], lane), s9_zero());
-        const s9_d4 Zc = s9_tn(Ft, s9_lds(rowp[tj], lane), s9_zero());
+        if (wv < NT) {
+            Ft = s9_lds(sh.F[1], lane);
+            s9_sts(sh.Z[wv], lane, s9_tn(Ft, s9_lds(rowp[wv], lane), s9_zero()));
+        }
+        __syncthreads();
         if (ti == k && tj == k) {
             const s9_d4 dd = s9_tn(F, F, s9_zero());
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[r] = -dd[r];
-        } else if (ti == k) S = s9_tn(F, Zc, s9_zero());
-        else if (tj == k) S = s9_tn(Zr, F, s9_zero());
+        } else if (ti == k) S = s9_tn(F, s9_lds(sh.Z[tj], lane), s9_zero());
+        else if (tj == k) S = s9_tn(s9_lds(sh.Z[ti], lane), F, s9_zero());
         else {
+            const s9_d4 Zr = s9_lds(sh.Z[ti], lane);
             s9_d4 nz;
 #pragma unroll
             for (int r = 0; r < 4; ++r) nz[r] = -Zr[r];
-            S = s9_tn(nz, Zc, S);
+            S = s9_tn(nz, s9_lds(sh.Z[tj], lane), S);
         }
     }
     {
