@@ -96,7 +96,8 @@ __device__ __forceinline__ void klt3_stage_i_slow(uint8_t* Ipl, const uint8_t* _
 }
 
 __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int levels, const int* __restrict__ n_pts_ptr,
-                                                  const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status, size_t bs) {
+                                                  const float* __restrict__ pts, float* __restrict__ out, unsigned char* __restrict__ status, size_t bs,
+                                                  const unsigned long long* pyr_ready, unsigned long long pyr_target, FilterMeta* meta) {
     DBG_S(blockIdx.x == 0 && blockIdx.z == 0, 0);
     DBG_U(17);
     const size_t zo = (size_t)blockIdx.z * bs;
@@ -106,7 +107,12 @@ __global__ __launch_bounds__(64) void klt_kernel3(PyrDev prev, PyrDev next, int 
     __shared__ __align__(16) uint8_t Jr[4][KLT3_JR * KLT3_JR];
     const int f = blockIdx.x, lane = threadIdx.x;
     const float px = pts[2 * f], py = pts[2 * f + 1];
-    if (f >= *n_pts_ptr) return;
+    const int n_pts = *n_pts_ptr;
+    // pyr_ready (round 6, one pipelined stream): the new image's pyramid comes from the image chain's queue — instead of a stream-level event wait in front of this
+    // launch (a barrier packet on the side chain's serial path, ~3 us per frame) every workgroup polls the chain's counter here, under its first loads' latency.
+    // A wait that times out: the sticky error bit is set, nothing is written (status and positions stay as book-keeping left them) and the sequence fails at the next sync.
+    if (pyr_ready && !stage_wait_wave(pyr_ready, pyr_target, meta)) return;
+    if (f >= n_pts) return;
     if (levels > 4) levels = 4;
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2 = 0.01 * 0.01;

@@ -298,7 +298,7 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
 // One-workgroup consumers poll them; a stream-level event in their place costs the WAITING stream ~10-20 us of its serial chain in the
 // pipelined run (measured in situ, profiles/r03_chain_clocks.txt).
 #define RVIO_MAX_IC 3
-struct StageSync { unsigned long long aug, handover, corners[RVIO_MAX_IC]; };
+struct StageSync { unsigned long long aug, handover, corners[RVIO_MAX_IC], pyr[RVIO_MAX_IC]; };     // pyr (round 6): the pyramid of an image chain's frame is complete (-> klt_kernel3)
 // every thread of the workgroup calls these
 __device__ __forceinline__ void stage_signal(unsigned long long* c) {
     __threadfence();                         // each wave: its stores written back and performed at agent scope
@@ -328,6 +328,20 @@ __device__ __forceinline__ bool stage_wait(const unsigned long long* c, unsigned
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's vector cache and the XCD's L2 drop what the producers have rewritten
     return s_stage_ok != 0;
+}
+// the same for a ONE-WAVE workgroup (every lane polls the same word: one request; no LDS, no barrier)
+__device__ __forceinline__ bool stage_wait_wave(const unsigned long long* c, unsigned long long target, FilterMeta* meta) {
+    bool ok = true;
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__hip_atomic_load(&meta->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) { ok = false; break; }
+            if (wall_clock64() - t0 > STAGE_WAIT_TICKS) { if ((threadIdx.x & 63) == 0) atomicOr(&meta->err, 4); ok = false; break; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
 }
 
 

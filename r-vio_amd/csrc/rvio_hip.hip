@@ -79,6 +79,7 @@ struct rvio_hip {
     int solve5_variant = 0;      // solve6_kernel (the LDS-tableau solve behind gemm_T_kernel: batch handles): 0 none, 1: <1,8,8>  2: <2,12,8>  3: <2,16,8>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
+    const unsigned long long* klt_wait = nullptr; unsigned long long klt_target = 0;   // this frame's klt_kernel3 polls the image chain's pyramid counter
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     int solve9_nt = 0;           // solve9_kernel (solve9.hip): tiles per side of the padded clone block (4, 6, 8, 12), 0: not used (batch handles, RVIO_SOLVE7=1)
     double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles (+ the verdict of the Cholesky role)
@@ -1390,8 +1391,15 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             // the longest serial chain of the front end — 19 us less of it; the image chain has the slack
             launch_pyramid(cs);
             pyramid_done = true;
-            HIPCHK(h, hipEventRecord(h->evC[h->ic], cs));
-            HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->ic], 0));
+            static const bool no_pyr_poll = ab_env("RVIO_NO_PYR_POLL") != nullptr;   // A/B timing
+            if (h->dev_sync && !h->wide_px && !no_pyr_poll) {   // klt_kernel3 polls the chain's counter itself (no barrier packet on the side stream)
+                hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, cs, &h->stage_sync->pyr[h->ic]);
+                h->stage_tgt.pyr[h->ic]++;
+                h->klt_wait = &h->stage_sync->pyr[h->ic]; h->klt_target = h->stage_tgt.pyr[h->ic];
+            } else {
+                HIPCHK(h, hipEventRecord(h->evC[h->ic], cs));
+                HIPCHK(h, hipStreamWaitEvent(h->stream_d, h->evC[h->ic], 0));
+            }
             forked = true;
         }
     }
@@ -1518,7 +1526,8 @@ static int track_dev_impl(rvio_hip* h, const uint8_t* d_img, int stride, const r
                            h->t.tracked, h->t.status, h->slab_bytes);
     else
         hipLaunchKernelGGL(klt_kernel3, dim3(h->dc.F, 1, h->batch), dim3(64), 0, h->side, h->pyr[h->pyr_cur], h->pyr[nb], h->dc.levels, h->t.n_pts, h->t.feats,
-                           h->t.tracked, h->t.status, h->slab_bytes);
+                           h->t.tracked, h->t.status, h->slab_bytes, h->klt_wait, h->klt_target, h->meta);
+    h->klt_wait = nullptr;
     rc = post_klt_dev(h, d_imu, m, d_cand, std::min(n_cand, h->dc.F));
     h->pyr_cur = nb;   // im.copyTo(mLastImage), Tracker.cc:395
     return rc;
@@ -2079,7 +2088,7 @@ int rvio_hip_debug_time_kernel(rvio_hip* h, int which, int iters, float* avg_us)
             // refilled corners included (they exist in the previous image too).  Outputs land in t.tracked / t.status (scratch between frames).
             if (h->batch > 1) return RVIO_ERR_UNSUPPORTED;
             hipLaunchKernelGGL(klt_kernel3, dim3(d.F), dim3(64), 0, h->stream, h->pyr[h->pyr_cur], h->pyr[(h->pyr_cur + 3) % 4], d.levels, h->t.n_pts, h->t.feats,
-                               h->t.tracked, h->t.status, (size_t)0);
+                               h->t.tracked, h->t.status, (size_t)0, (const unsigned long long*)nullptr, 0ull, h->meta);
         } else if (which == 2) {
             if (h->batch == 1)
             hipLaunchKernelGGL(feat_build_kernel<16>, dim3(d.Fu, 1, h->batch), dim3(h->feat_threads), h->feat_lds, h->stream, d, n, h->x[h->cur], h->P[h->cur],
