@@ -145,8 +145,11 @@ __global__ __launch_bounds__(DET_T) void mineig_kernel(const uint8_t* __restrict
 // Scharr-scaled Sobel gradients in float, the three product planes' vertical three-sums (p(i) + p(i+1)) + p(i+2) formed once per column in
 // double and shared through LDS, a pixel adds three of them left to right: the canonical additions in the canonical order.
 #define DET_FH 16                                   // tile rows of the fused pass
-__global__ __launch_bounds__(DET_T) void mineig_nms_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag) {
+// pyr_signal (round 6, one pipelined stream): the counter klt_kernel3 polls for "this image chain's pyramid is complete" — the pyramid launch precedes this one on
+// the same queue, so its stores are complete and visible device-wide when this kernel starts: workgroup 0 just bumps the counter (no launch of its own on the image chain)
+__global__ __launch_bounds__(DET_T) void mineig_nms_kernel(const uint8_t* __restrict__ src, int stride, DetDev d, size_t src_bs, size_t bs, int dbg_tag, unsigned long long* pyr_signal) {
     DBG_I(blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, dbg_tag, 1);
+    if (pyr_signal && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(pyr_signal, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     src = zoff(src, src_bs); det_shift(d, (size_t)blockIdx.z * bs);
     constexpr int TH = DET_FH, TW = DET_TW;
     constexpr int EW = TW + 2, EH = TH + 2;          // map incl. the ring:    rows y0-1 .. y0+TH,   columns x0-1 .. x0+TW

@@ -79,7 +79,8 @@ struct rvio_hip {
     int solve5_variant = 0;      // solve6_kernel (the LDS-tableau solve behind gemm_T_kernel: batch handles): 0 none, 1: <1,8,8>  2: <2,12,8>  3: <2,16,8>
     StageSync* stage_sync = nullptr;   // device-side completion counter of the filter chain (aug) and the value it reaches after the launches so far
     StageSync stage_tgt = {};
-    const unsigned long long* klt_wait = nullptr; unsigned long long klt_target = 0;   // this frame's klt_kernel3 polls the image chain's pyramid counter
+    const unsigned long long* klt_wait = nullptr; unsigned long long klt_target = 0;
+    unsigned long long* pyr_signal = nullptr;   // pending: the next detector launch on the image chain's queue bumps it   // this frame's klt_kernel3 polls the image chain's pyramid counter
     int solve7_variant = 0;      // register-tableau solve with the T prologue (solve7.hip): 1: 6n <= 64, 2: <= 96, 3: <= 128, 4: <= 192
     int solve9_nt = 0;           // solve9_kernel (solve9.hip): tiles per side of the padded clone block (4, 6, 8, 12), 0: not used (batch handles, RVIO_SOLVE7=1)
     double* S9scr = nullptr;     // its slab of tiles in L2: 5 NT^2 x 256 doubles (+ the verdict of the Cholesky role)
@@ -1291,6 +1292,7 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
     const hipStream_t ds = image_stream(h);
     h->det_set_last = h->runahead ? h->ic : 0;
     static const bool two_pass = ab_env("RVIO_DET_TWO_PASS") != nullptr;   // A/B timing
+    if (h->pyr_signal && (h->wide_px || two_pass)) { hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, ds, h->pyr_signal); h->pyr_signal = nullptr; }   // (forms without the folded signal)
     if (h->wide_px && !two_pass) {
         // batch handles of >= 8 instances: the fused pass in its throughput form (one wave per strip, rows walked with the state in registers)
         hipLaunchKernelGGL(mineig_nms_strip_kernel, dim3((d.W + DET_SW - 1) / DET_SW, (d.H + DET_SH - 1) / DET_SH, B), dim3(64), 0, ds, img, stride, q, src_bs, bs);
@@ -1307,7 +1309,8 @@ static int detect_dev(rvio_hip* h, const uint8_t* img, int stride, size_t src_bs
 #endif
     else {
         // one stream: min-eigenvalue map + strict 3x3 local maxima in one pass (the map stays in LDS), then the image-wide threshold on the provisional list
-        hipLaunchKernelGGL(mineig_nms_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_FH - 1) / DET_FH, B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no);
+        hipLaunchKernelGGL(mineig_nms_kernel, dim3((d.W + DET_TW - 1) / DET_TW, (d.H + DET_FH - 1) / DET_FH, B), dim3(DET_T), 0, ds, img, stride, q, src_bs, bs, (int)h->frame_no, h->pyr_signal);
+        h->pyr_signal = nullptr;
         if (first_flag_ready && !(kDbgSkip & 2)) HIPCHK(h, hipStreamWaitEvent(ds, first_flag_ready, 0));   // the threshold pass reads mbIsTheFirstImage (cell size) as book-keeping(k-1) left it
         hipLaunchKernelGGL(nms_threshold_kernel, dim3(16, 1, B), dim3(NMS_T), 0, ds, q, bs);
     }
@@ -1393,7 +1396,7 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             pyramid_done = true;
             static const bool no_pyr_poll = ab_env("RVIO_NO_PYR_POLL") != nullptr;   // A/B timing
             if (h->dev_sync && !h->wide_px && !no_pyr_poll) {   // klt_kernel3 polls the chain's counter itself (no barrier packet on the side stream)
-                hipLaunchKernelGGL(stage_signal_kernel, dim3(1), dim3(64), 0, cs, &h->stage_sync->pyr[h->ic]);
+                h->pyr_signal = &h->stage_sync->pyr[h->ic];      // bumped by the detector's first launch on this queue (detect_dev), right behind the pyramid
                 h->stage_tgt.pyr[h->ic]++;
                 h->klt_wait = &h->stage_sync->pyr[h->ic]; h->klt_target = h->stage_tgt.pyr[h->ic];
             } else {
