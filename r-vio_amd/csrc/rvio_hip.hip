@@ -140,6 +140,7 @@ struct rvio_hip {
     hipStream_t tail = nullptr;                   // stream that ran book-keeping in the call in progress (the hand-over event is recorded there)
     bool runahead = false;                        // call in progress: pipelined whole-frame path with the device detector
     bool private_queues = false;                  // this handle's streams own hardware queues (make_stream)
+    bool queues_shared = false;                   // ... unless one of them had to come from the shared pool after all
     bool dev_sync = false;                        // ... of ONE instance: hand-over -> filter and corners -> refill go through device-side counters (StageSync)
     bool gate_pending = false;                    // the filter of the frame in flight starts behind stage_gate_kernel (target: gate_target)
     unsigned long long gate_target = 0;
@@ -404,7 +405,7 @@ static int alloc_frontend_slab(rvio_hip* h) {
 static std::atomic<int> g_private_queue_handles{0};
 static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = false) {
     static const int mode = (paranoid_bits() & PAR_PLAIN_STREAMS) ? 0 : (ab_env("RVIO_STREAM_MODE") ? atoi(ab_env("RVIO_STREAM_MODE")) : 1);
-    if (mode == 0 || !h->private_queues) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (mode == 0 || !h->private_queues) { h->queues_shared = true; return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, h->device);
     if (e != hipSuccess) return e;
@@ -415,7 +416,7 @@ static hipError_t make_stream(rvio_hip* h, hipStream_t* s, bool front_end = fals
     static const int fe_skip = ab_env("RVIO_FE_SKIP") ? atoi(ab_env("RVIO_FE_SKIP")) : 0;
     if (front_end && fe_skip > 1) for (int c = 0; c < prop.multiProcessorCount; ++c) if (c % fe_skip == 0) mask[c / 32] &= ~(1u << (c % 32));
     e = hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
-    if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+    if (e != hipSuccess) { (void)hipGetLastError(); h->queues_shared = true; return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
     return e;
 }
 
@@ -1395,7 +1396,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             launch_pyramid(cs);
             pyramid_done = true;
             static const bool no_pyr_poll = ab_env("RVIO_NO_PYR_POLL") != nullptr;   // A/B timing
-            if (h->dev_sync && !h->wide_px && !no_pyr_poll) {   // klt_kernel3 polls the chain's counter itself (no barrier packet on the side stream)
+            // klt_kernel3 polls the chain's counter itself (no barrier packet on the side stream) — on a handle whose four streams own their hardware queues only (the first
+            // live handle of the process, make_stream): 200 polling workgroups per frame in front of kernels of OTHER handles on a shared queue timed the eight-handle
+            // leg of the bench out (a consumer may only spin where everything it waits for was submitted earlier to queues nobody else feeds)
+            if (h->dev_sync && h->private_queues && !h->queues_shared && !h->wide_px && !no_pyr_poll) {
                 h->pyr_signal = &h->stage_sync->pyr[h->ic];      // bumped by the detector's first launch on this queue (detect_dev), right behind the pyramid
                 h->stage_tgt.pyr[h->ic]++;
                 h->klt_wait = &h->stage_sync->pyr[h->ic]; h->klt_target = h->stage_tgt.pyr[h->ic];
