@@ -756,9 +756,11 @@ __global__ __launch_bounds__(1024) void ransac_book_kernel(DevCfg cfg, TrackerDe
     __threadfence_block();
     __syncthreads();
     bookkeep_a_body(cfg, t, bs, done, done_target, meta);
+    // the refill half reads what the hand-over half wrote through global memory (tmp_feats, tmp_un, tmp_slot, mid, hist_len): an agent-scope release by every
+    // wave + a workgroup barrier — exactly what stage_signal does in front of its atomic, so with a hand-over counter nothing more is needed (round 6: a second
+    // device-scope fence here — an L2 write-back on the multi-XCD part — sat on the side chain's serial path)
     if (hand) stage_signal(hand);
-    __threadfence();        // the refill half reads what the hand-over half wrote through global memory (tmp_feats, tmp_un, tmp_slot, mid, hist_len)
-    __syncthreads();
+    else { __threadfence(); __syncthreads(); }
     bookkeep_b_body(cfg, t, cand, 0, n_cand_dev, bs, corners, corners_target, meta, dsh_rb);
 }
 // direct-track mode: the caller supplies vFeatsTracked / vInlierFlag (the KLT result)
