@@ -301,9 +301,15 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {   // exact: ord
 struct StageSync { unsigned long long aug, handover, corners[RVIO_MAX_IC], pyr[RVIO_MAX_IC]; };     // pyr (round 6): the pyramid of an image chain's frame is complete (-> klt_kernel3)
 // every thread of the workgroup calls these
 __device__ __forceinline__ void stage_signal(unsigned long long* c) {
-    __threadfence();                         // each wave: its stores written back and performed at agent scope
+    // every wave: its stores performed in the XCD's L2 (workgroup scope) — then ONE wave writes that L2 back (agent scope: cumulative over what the barrier
+    // ordered before it) and bumps the counter.  (Round 6: every wave ran the agent-scope release itself — up to sixteen L2 write-backs per signal.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(c, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // Returns false when the counter has not arrived within STAGE_WAIT_TICKS of the constant 100 MHz clock (30 s: the producer's queue is
 // dead or starved beyond anything a shared / preempted GPU does).  The caller then must NOT rewrite what the producer may still read:
