@@ -331,8 +331,10 @@ __device__ __forceinline__ bool stage_wait(const unsigned long long* c, unsigned
         }
         s_stage_ok = ok;
     }
+    // this CU's vector cache and the XCD's L2 drop what the producers have rewritten: ONE wave's agent-scope acquire (the caches are the CU's / the XCD's, not a
+    // wave's), made the workgroup's by the barrier behind it (round 6: every wave ran the invalidate)
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's vector cache and the XCD's L2 drop what the producers have rewritten
     return s_stage_ok != 0;
 }
 // the same for a ONE-WAVE workgroup (every lane polls the same word: one request; no LDS, no barrier)
