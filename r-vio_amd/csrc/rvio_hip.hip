@@ -141,6 +141,7 @@ struct rvio_hip {
     bool runahead = false;                        // call in progress: pipelined whole-frame path with the device detector
     bool private_queues = false;                  // this handle's streams own hardware queues (make_stream)
     bool queues_shared = false;                   // ... unless one of them had to come from the shared pool after all
+    bool extra_queues = false;                    // a collective's queues run beside this handle's (rvio_hip_frame_sharded_dev with a communicator)
     bool dev_sync = false;                        // ... of ONE instance: hand-over -> filter and corners -> refill go through device-side counters (StageSync)
     bool gate_pending = false;                    // the filter of the frame in flight starts behind stage_gate_kernel (target: gate_target)
     unsigned long long gate_target = 0;
@@ -1399,7 +1400,10 @@ static int build_pyramid_dev(rvio_hip* h, const uint8_t* d_img, int stride, int 
             // klt_kernel3 polls the chain's counter itself (no barrier packet on the side stream) — on a handle whose four streams own their hardware queues only (the first
             // live handle of the process, make_stream): 200 polling workgroups per frame in front of kernels of OTHER handles on a shared queue timed the eight-handle
             // leg of the bench out (a consumer may only spin where everything it waits for was submitted earlier to queues nobody else feeds)
-            if (h->dev_sync && h->private_queues && !h->queues_shared && !h->wide_px && !no_pyr_poll) {
+            // ... and not on a handle that runs the sharded frame over a real collective, nor at long windows (6n > 96: the Cholesky factor's launches share the
+            // copy queue): with the forced-sharded cfg E run of the bench two runs in six stalled for the poll's full 30 s (none in six without it) — more busy
+            // queues than the command processor keeps resident, and a queue of spinning workgroups in front of the one that would release them
+            if (h->dev_sync && h->private_queues && !h->queues_shared && !h->extra_queues && 6 * h->dc.nmax <= 96 && !h->wide_px && !no_pyr_poll) {
                 h->pyr_signal = &h->stage_sync->pyr[h->ic];      // bumped by the detector's first launch on this queue (detect_dev), right behind the pyramid
                 h->stage_tgt.pyr[h->ic]++;
                 h->klt_wait = &h->stage_sync->pyr[h->ic]; h->klt_target = h->stage_tgt.pyr[h->ic];
@@ -1842,6 +1846,7 @@ int rvio_hip_frame_sharded_dev(rvio_hip* h, const uint8_t* d_img, int stride, co
     if (!h || !d_img || world < 1 || rank < 0 || rank >= world || (!comm && world > 1)) return RVIO_ERR_INVALID;
     FRONT_END_ONLY(h);
     HIPCHK(h, hipSetDevice(h->device));
+    if (comm) h->extra_queues = true;   // the collective brings queues of its own: more than the four this handle's chains own (see the pyramid poll, build_pyramid_dev)
     const size_t nblk_max = (size_t)shard_payload_doubles(6 * h->dc.nmax, h->dc.max_len);    // the full window's payload: what the receive buffer is sized for
     nccl_allgather_fn ag = (nccl_allgather_fn)allgather;
     if (comm && !ag && !(ag = resolve_allgather(&h->err))) return RVIO_ERR_UNSUPPORTED;
